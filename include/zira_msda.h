@@ -1,0 +1,90 @@
+/*
+ * zira_msda.h -- C ABI of the MI355X-native multi-scale deformable attention (MSDA) op.
+ *
+ * This is the drop-in boundary for the reference's native extension `groundingdino._C`
+ * (pybind module, reference csrc/vision.cpp:53-56), i.e. for
+ *
+ *   at::Tensor  ms_deform_attn_forward (value, spatial_shapes, level_start_index,
+ *                                       sampling_loc, attn_weight, im2col_step)
+ *   vector<Tensor> ms_deform_attn_backward(value, spatial_shapes, level_start_index,
+ *                                       sampling_loc, attn_weight, grad_output, im2col_step)
+ *
+ * declared at reference csrc/MsDeformAttn/ms_deform_attn.h:21-61 and implemented (CUDA
+ * only) at csrc/MsDeformAttn/ms_deform_attn_cuda.cu:21-81 / :84-154 on top of the kernels in
+ * csrc/MsDeformAttn/ms_deform_im2col_cuda.cuh.  The reference binds those two functions
+ * through libtorch; this library exposes the same two operations with plain pointers and
+ * sizes so that any host (ctypes, pybind, cgo ...) can bind it -- see INTEGRATION.md.
+ *
+ * Contract (all entry points):
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch ROCm tensor storage), including
+ *     the two int64 arrays -- exactly as the reference requires (ms_deform_attn_cuda.cu:35-39);
+ *   - tensors are dense row-major ("contiguous"):
+ *       value[B,S,M,D]  spatial_shapes[L,2]=(H,W)  level_start_index[L]
+ *       sampling_loc[B,Q,M,L,P,2] (x, y normalised to [0,1])   attn_weight[B,Q,M,L,P]
+ *       out / grad_out [B,Q,M*D]
+ *   - buffers are caller-owned; outputs need NOT be zeroed by the caller: the forward
+ *     overwrites `out`, the backward zero-fills `grad_value` itself (asynchronously, on
+ *     `stream`) and overwrites `grad_sampling_loc` / `grad_attn_weight`;
+ *   - `stream` is a hipStream_t (NULL = the default stream); work is enqueued, never
+ *     synchronised: no host sync, no allocation, safe to capture in a hipGraph;
+ *   - re-entrant and stateless (thread-safe for distinct output buffers);
+ *   - return value: 0 (hipSuccess) or a hipError_t cast to int; never throws, never prints
+ *     (the reference only printf()s launch errors, cuh:948-952 -- we return them);
+ *     ZIRA_MSDA_EINVAL marks argument errors detected before any launch;
+ *   - the reference's `im2col_step` only chunks the batch into several launches
+ *     (ms_deform_attn_cuda.cu:51-76); it does not change results.  This ABI takes the whole
+ *     batch in one launch; the Python binding keeps the argument and its divisibility
+ *     check for signature compatibility.
+ *   - sizes: per-batch-element element counts (S*M*D and Q*M*L*P*2) must be < 2^31
+ *     (the reference uses 32-bit indices throughout, cuh:255-269).
+ */
+#ifndef ZIRA_MSDA_H_
+#define ZIRA_MSDA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZIRA_MSDA_EINVAL 1 /* == hipErrorInvalidValue */
+
+/* Replaces ms_deform_attn_forward for float32 (ms_deform_attn.h:21-40). */
+int zira_msda_fwd_f32(const float *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const float *sampling_loc,
+                      const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                      float *out, void *stream);
+
+/* Replaces ms_deform_attn_backward for float32 (ms_deform_attn.h:42-61). */
+int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const float *sampling_loc,
+                      const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                      float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                      void *stream);
+
+/* float64 twins: the reference dispatches AT_DISPATCH_FLOATING_TYPES = {float, double}
+ * (ms_deform_attn_cuda.cu:65, :135). */
+int zira_msda_fwd_f64(const double *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const double *sampling_loc,
+                      const double *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                      double *out, void *stream);
+
+int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t *spatial_shapes,
+                      const int64_t *level_start_index, const double *sampling_loc,
+                      const double *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                      double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
+                      void *stream);
+
+/* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
+const char *zira_msda_version(void);
+
+/* Name of the kernel variant the f32 entry points pick for channel width D
+ * ("rows<8>" = wave-per-(b,q,m) fast path, "generic" = element-per-thread path).
+ * Host-only helper for tests/bench labelling. Static storage. */
+const char *zira_msda_variant_f32(int D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZIRA_MSDA_H_ */

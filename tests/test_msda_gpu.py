@@ -1,0 +1,236 @@
+"""Parity of the HIP kernels (through the `_C` drop-in -> C ABI) against
+(1) the golden vectors produced by the reference's own CPU path and
+(2) the CPU oracle on seeded inputs, up to the BASELINE shapes; plus size-independent
+properties at full size and the reference's error behaviour at the boundary.
+
+Tolerances (north_star: "within 1e-3 fp32"): we hold fp32 results to 2e-5 relative to the
+tensor's scale -- the only differences are summation order (4 corners x 16 samples folded by
+shuffles, atomics in grad_value) -- and fp64 to 1e-11.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_msda_cases, load_npz
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from ziragroundingdino_amd import _C, MultiScaleDeformableAttnFunction
+
+DEV = "cuda"
+NORTH_STAR_SHAPES = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+def _tol(dtype):
+    return 2e-5 if dtype in (np.float32, torch.float32) else 1e-11
+
+
+def _close(got, want, tol, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max()) / scale
+    assert err <= tol, "%s: max err %.3e (scaled) > %.1e" % (what, err, tol)
+
+
+def _to_dev(g):
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    return (t("value"), t("spatial_shapes"), t("level_start_index"), t("sampling_loc"),
+            t("attn_weight"), t("grad_output"))
+
+
+def _minus_one_edge(g):
+    sh = g["spatial_shapes"]
+    dt = g["value"].dtype
+    W = sh[:, 1][None, None, None, :, None].astype(dt)
+    H = sh[:, 0][None, None, None, :, None].astype(dt)
+    loc = g["sampling_loc"]
+    return (loc[..., 0] * W - 0.5 == -1) | (loc[..., 1] * H - 0.5 == -1)
+
+
+@pytest.mark.parametrize("path", golden_msda_cases(), ids=lambda p: os.path.basename(p)[5:-4])
+def test_hip_matches_reference_golden(path):
+    g = load_npz(path)
+    tol = _tol(g["value"].dtype.type)
+    value, shapes, start, loc, attn, go = _to_dev(g)
+    out = _C.ms_deform_attn_forward(value, shapes, start, loc, attn, 64)
+    _close(out, g["output"], tol, "output")
+    gv, gl, ga = _C.ms_deform_attn_backward(value, shapes, start, loc, attn, go, 64)
+    _close(gv, g["grad_value"], tol, "grad_value")
+    _close(ga, g["grad_attn_weight"], tol, "grad_attn_weight")
+    ref_gl = g["grad_sampling_loc"].copy()
+    edge = _minus_one_edge(g)  # see tests/test_oracle_golden.py: CUDA-kernel semantics there
+    gl = gl.cpu().numpy()
+    assert not gl[edge].any()
+    ref_gl[edge] = 0
+    _close(gl, ref_gl, tol, "grad_sampling_loc")
+
+
+def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1, clustered=False):
+    rng = np.random.default_rng(seed)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = rng.standard_normal((B, S, M, D)).astype(dtype)
+    if clustered:  # decoder-like: box centre + small offsets
+        centre = rng.uniform(0.1, 0.9, (B, Q, 1, 1, 1, 2))
+        loc = (centre + 0.05 * rng.standard_normal((B, Q, M, L, P, 2))).astype(dtype)
+    else:
+        loc = rng.uniform(lo, hi, (B, Q, M, L, P, 2)).astype(dtype)
+    logits = rng.standard_normal((B, Q, M, L * P))
+    attn = np.exp(logits - logits.max(-1, keepdims=True))
+    attn = (attn / attn.sum(-1, keepdims=True)).reshape(B, Q, M, L, P).astype(dtype)
+    go = rng.standard_normal((B, Q, M * D)).astype(dtype)
+    sh = np.asarray(shapes, dtype=np.int64)
+    start = np.concatenate([[0], np.cumsum(sh[:, 0] * sh[:, 1])[:-1]]).astype(np.int64)
+    return value, sh, start, loc, attn, go
+
+
+def _away_from_pixel_borders(loc, sh, margin=1e-3):
+    """True where neither pixel coordinate is within `margin` of an integer: only there is
+    grad_loc (piecewise constant in the fractional part) insensitive to 1-ulp differences."""
+    W = sh[:, 1][None, None, None, :, None].astype(loc.dtype)
+    H = sh[:, 0][None, None, None, :, None].astype(loc.dtype)
+    x = loc[..., 0] * W - 0.5
+    y = loc[..., 1] * H - 0.5
+    fx = np.abs(x - np.round(x))
+    fy = np.abs(y - np.round(y))
+    return (fx > margin) & (fy > margin)
+
+
+CASES = [
+    # (id, B, Q, M, D, shapes, P, kwargs)
+    ("northstar_decoder", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(lo=0.0, hi=1.0)),
+    ("northstar_clustered", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(clustered=True)),
+    ("oob_heavy", 2, 333, 8, 32, [(20, 31), (10, 16), (5, 8), (3, 4)], 4, dict(lo=-0.5, hi=1.5)),
+    ("lp_not_16", 3, 57, 4, 32, [(12, 9), (6, 5), (3, 3), (2, 2), (1, 1)], 5, {}),
+    ("one_level_p1", 2, 200, 2, 32, [(17, 23)], 1, {}),
+    ("d16", 2, 101, 8, 16, [(20, 31), (10, 16)], 4, {}),
+    ("d64", 2, 101, 4, 64, [(20, 31), (10, 16)], 4, {}),
+    ("d128", 1, 64, 2, 128, [(9, 7), (4, 4)], 2, {}),
+    ("d4", 1, 77, 3, 4, [(9, 7), (4, 4)], 4, {}),
+    ("d24_generic", 2, 50, 3, 24, [(9, 7), (4, 4)], 4, {}),
+    ("h1_w1_levels", 2, 90, 4, 32, [(1, 9), (7, 1), (1, 1)], 4, dict(lo=-0.3, hi=1.3)),
+    ("f64", 2, 150, 8, 32, [(20, 31), (10, 16), (5, 8), (3, 4)], 4, dict(dtype=np.float64)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_hip_matches_oracle(oracle, case):
+    _, B, Q, M, D, shapes, P, kw = case
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=zlib.crc32(case[0].encode()) % 1000, **kw)
+    tol = _tol(value.dtype.type)
+    want_out = oracle.msda_forward(value, sh, start, loc, attn)
+    want_gv, want_gl, want_ga = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    tv, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    out = _C.ms_deform_attn_forward(tv, tsh, tst, tloc, tattn, 64)
+    _close(out, want_out, tol, "output")
+    gv, gl, ga = _C.ms_deform_attn_backward(tv, tsh, tst, tloc, tattn, tgo, 64)
+    _close(gv, want_gv, tol, "grad_value")
+    _close(ga, want_ga, tol, "grad_attn_weight")
+    # the kernels form the pixel coordinate exactly like the oracle (mul, then sub, no fma),
+    # so floor() agrees everywhere and grad_loc can be compared on every sample
+    _close(gl, want_gl, tol, "grad_sampling_loc")
+
+
+def test_encoder_shape_against_oracle(oracle):
+    """Q = S (every pixel is a query, reference transformer_for_adapter.py:893-900); B=1 to
+    keep the CPU side in seconds."""
+    shapes = NORTH_STAR_SHAPES
+    sh = np.asarray(shapes, dtype=np.int64)
+    S = int((sh[:, 0] * sh[:, 1]).sum())
+    B, M, D, L, P = 1, 8, 32, 4, 4
+    rng = np.random.default_rng(5)
+    value, _, start, _, attn, go = _random_case(B, S, M, D, shapes, P, seed=5)
+    # reference points = pixel centres of every level's grid, replicated over levels
+    ref = np.concatenate([
+        np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2)
+        for h, w in shapes]).astype(np.float32)                                  # [S,2] (x,y)
+    off_px = 2.0 * rng.standard_normal((B, S, M, L, P, 2)).astype(np.float32)
+    norm = np.stack([sh[:, 1], sh[:, 0]], -1).astype(np.float32)[None, None, None, :, None, :]
+    loc = (ref[None, :, None, None, None, :] + off_px / norm).astype(np.float32)
+    want_out = oracle.msda_forward(value, sh, start, loc, attn)
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    tv, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    _close(_C.ms_deform_attn_forward(tv, tsh, tst, tloc, tattn, 64), want_out, 2e-5, "output")
+    got = _C.ms_deform_attn_backward(tv, tsh, tst, tloc, tattn, tgo, 64)
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        _close(g, w, 5e-5 if name == "grad_value" else 2e-5, name)
+
+
+def test_full_size_properties():
+    """BASELINE shape (B=2,Q=900,M=8,D=32,L=4,P=4), no oracle: linearity in value / attn /
+    grad_out, zero for fully-outside samples, adjointness <out, go> == <value, grad_value>."""
+    value, sh, start, loc, attn, go = _random_case(2, 900, 8, 32, NORTH_STAR_SHAPES, 4, seed=11)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    v2 = torch.randn_like(v)
+    f = lambda vv, aa: _C.ms_deform_attn_forward(vv, tsh, tst, tloc, aa, 64)
+    o1, o2 = f(v, tattn), f(v2, tattn)
+    torch.testing.assert_close(f(2 * v - 3 * v2, tattn), 2 * o1 - 3 * o2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f(v, 0.25 * tattn), 0.25 * o1, rtol=1e-5, atol=1e-6)
+    gv, gl, ga = _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo, 64)
+    # adjoint identity: the op is linear in value, so <f(v), go> == <v, grad_value>
+    lhs = (o1.double() * tgo.double()).sum()
+    rhs = (v.double() * gv.double()).sum()
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (lhs, rhs)
+    # ... and linear in attn: <f, go> == <attn, grad_attn>
+    rhs_a = (tattn.double() * ga.double()).sum()
+    assert abs(lhs - rhs_a) <= 1e-5 * max(1.0, abs(lhs)), (lhs, rhs_a)
+    gv2, gl2, ga2 = _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, 2 * tgo, 64)
+    torch.testing.assert_close(gl2, 2 * gl, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gv2, 2 * gv, rtol=1e-4, atol=1e-5)
+    far = torch.full_like(tloc, 2.5)
+    assert not f(v, far.contiguous()).any()
+    z = _C.ms_deform_attn_backward(v, tsh, tst, far, tattn, tgo, 64)
+    assert not z[0].any() and not z[1].any() and not z[2].any()
+
+
+def test_outputs_need_no_preinit_and_rerun_is_stable():
+    value, sh, start, loc, attn, go = _random_case(2, 64, 8, 32, [(8, 9), (4, 5)], 4, seed=3)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    args = list(map(t, (value, sh, start, loc, attn)))
+    tgo = t(go)
+    a = _C.ms_deform_attn_backward(*args, tgo, 64)
+    b = _C.ms_deform_attn_backward(*args, tgo, 64)
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)   # atomics: order may differ
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])      # shuffle reductions: bitwise
+    assert torch.equal(_C.ms_deform_attn_forward(*args, 64), _C.ms_deform_attn_forward(*args, 64))
+
+
+def test_autograd_function_and_stream():
+    value, sh, start, loc, attn, go = _random_case(2, 40, 8, 32, [(8, 9), (4, 5)], 4, seed=4)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    v.requires_grad_(True); tloc.requires_grad_(True); tattn.requires_grad_(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # the op must launch on torch's *current* stream
+        out = MultiScaleDeformableAttnFunction.apply(v, tsh, tst, tloc, tattn, 64)
+        out.backward(tgo)
+    torch.cuda.current_stream().wait_stream(side)
+    ref = _C.ms_deform_attn_backward(v.detach(), tsh, tst, tloc.detach(), tattn.detach(), tgo, 64)
+    torch.testing.assert_close(v.grad, ref[0], rtol=1e-5, atol=1e-6)
+    assert torch.equal(tloc.grad, ref[1]) and torch.equal(tattn.grad, ref[2])
+
+
+def test_boundary_errors_match_reference():
+    value, sh, start, loc, attn, go = _random_case(3, 8, 2, 32, [(4, 5)], 2, seed=6)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        _C.ms_deform_attn_forward(v.cpu(), tsh, tst, tloc, tattn, 64)
+    with pytest.raises(RuntimeError, match="spatial_shapes must be a CUDA tensor"):
+        _C.ms_deform_attn_forward(v, tsh.cpu(), tst, tloc, tattn, 64)
+    with pytest.raises(RuntimeError, match="value tensor has to be contiguous"):
+        _C.ms_deform_attn_forward(v.transpose(2, 3), tsh, tst, tloc, tattn, 64)
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        _C.ms_deform_attn_forward(v, tsh, tst, tloc, tattn, 2)     # batch 3 % 2 != 0
+    with pytest.raises(RuntimeError, match="grad_output tensor has to be contiguous"):
+        _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo.transpose(0, 1).contiguous().transpose(0, 1), 64)
+    with pytest.raises(RuntimeError, match="not implemented for"):
+        _C.ms_deform_attn_forward(v.half(), tsh, tst, tloc.half(), tattn.half(), 64)

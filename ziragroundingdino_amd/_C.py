@@ -1,0 +1,106 @@
+"""Drop-in for the reference's native module ``groundingdino._C``.
+
+Same two functions, same argument order and meaning, same error behaviour as the pybind
+module built from reference csrc/vision.cpp:53-56 (implementation
+csrc/MsDeformAttn/ms_deform_attn.h:21-61 and ms_deform_attn_cuda.cu:21-154), but backed by the
+hand-written gfx950 kernels behind the C ABI of include/zira_msda.h.
+
+    from ziragroundingdino_amd import _C
+    out = _C.ms_deform_attn_forward(value, spatial_shapes, level_start_index,
+                                    sampling_loc, attn_weight, im2col_step)
+    gv, gl, ga = _C.ms_deform_attn_backward(value, spatial_shapes, level_start_index,
+                                            sampling_loc, attn_weight, grad_output, im2col_step)
+"""
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _check_common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
+    named = (("value", value), ("spatial_shapes", spatial_shapes),
+             ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+             ("attn_weight", attn_weight)) + tuple(extra)
+    # ms_deform_attn.h:29-40 -- device dispatch happens on `value` first
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    # ms_deform_attn_cuda.cu:29-39 / :94-106
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+    if value.dtype not in _SUFFIX:
+        # AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:65)
+        raise RuntimeError('"ms_deform_attn_forward_cuda" not implemented for \'%s\''
+                           % str(value.dtype).replace("torch.", "").capitalize())
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("expected scalar type Long for spatial_shapes / level_start_index")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("expected sampling_loc and attn_weight to have the dtype of value")
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5 \
+            or spatial_shapes.dim() != 2:
+        raise RuntimeError("ms_deform_attn: value[B,S,M,D], spatial_shapes[L,2], "
+                           "sampling_loc[B,Q,M,L,P,2], attn_weight[B,Q,M,L,P] expected")
+
+
+def _dims(value, spatial_shapes, sampling_loc, im2col_step):
+    B, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Q = sampling_loc.shape[1]
+    P = sampling_loc.shape[4]
+    step = min(B, int(im2col_step))
+    # ms_deform_attn_cuda.cu:51-53
+    if step <= 0 or B % step != 0:
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (B, step))
+    return B, S, M, D, L, Q, P
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _raise_on(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: hipError %d" % (what, rc))
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    """-> output[B, Q, M*D].  Reference: ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:21-81)."""
+    _check_common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    B, S, M, D, L, Q, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    lib = _lib.load()
+    out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        fn = getattr(lib, "zira_msda_fwd_" + _SUFFIX[value.dtype])
+        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Q, P,
+                out.data_ptr(), _stream())
+    _raise_on(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight].
+    Reference: ms_deform_attn_cuda_backward (ms_deform_attn_cuda.cu:84-154)."""
+    _check_common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                  extra=(("grad_output", grad_output),))
+    B, S, M, D, L, Q, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    if grad_output.dtype != value.dtype:
+        raise RuntimeError("expected grad_output to have the dtype of value")
+    lib = _lib.load()
+    grad_value = torch.empty_like(value)          # zero-filled by the callee on the stream
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        fn = getattr(lib, "zira_msda_bwd_" + _SUFFIX[value.dtype])
+        rc = fn(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                B, S, M, D, L, Q, P, grad_value.data_ptr(), grad_loc.data_ptr(),
+                grad_attn.data_ptr(), _stream())
+    _raise_on(rc, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_attn]

@@ -1,0 +1,55 @@
+"""ctypes binding of the C ABI declared in include/zira_msda.h.
+
+There is deliberately no fallback: if ``libzira_msda.so`` is missing the import of the op
+raises, so a GPU box can never silently run a non-HIP path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzira_msda.so")
+
+# every symbol include/zira_msda.h declares (tests check the .so exports exactly these)
+SYMBOLS = (
+    "zira_msda_fwd_f32", "zira_msda_bwd_f32", "zira_msda_fwd_f64", "zira_msda_bwd_f64",
+    "zira_msda_version", "zira_msda_variant_f32",
+)
+
+_lib = None
+
+
+class ExtensionMissingError(ImportError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle of libzira_msda.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissingError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or python -m ziragroundingdino_amd.build). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    fwd_args = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp]
+    bwd_args = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, vp]
+    for suffix in ("f32", "f64"):
+        f = getattr(lib, "zira_msda_fwd_" + suffix)
+        f.argtypes, f.restype = fwd_args, i
+        f = getattr(lib, "zira_msda_bwd_" + suffix)
+        f.argtypes, f.restype = bwd_args, i
+    lib.zira_msda_version.restype = ctypes.c_char_p
+    lib.zira_msda_variant_f32.argtypes = [i]
+    lib.zira_msda_variant_f32.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().zira_msda_version().decode()
+
+
+def variant_f32(D):
+    return load().zira_msda_variant_f32(int(D)).decode()

@@ -1,0 +1,541 @@
+// msda.hip -- multi-scale deformable attention sampling + aggregation for gfx950 (MI355X).
+//
+// Hand-written for CDNA4 (64-wide wavefronts); not derived from the reference's CUDA
+// kernels.  The arithmetic that has to match is that of the reference op
+// (groundingdino/models/GroundingDINO/csrc/MsDeformAttn/ms_deform_im2col_cuda.cuh:
+//  forward :237-299 + bilinear :33-84, backward :87-159 inside :301-403); the C ABI that
+// wraps these kernels is declared in include/zira_msda.h.
+//
+// Work decomposition ("rows" path, fp32, D = 4*LPR channels per head):
+//   * one wavefront owns one (b, q, m) item: LP = L*P samples, 4 bilinear corners each;
+//   * phase 1: lane i owns corner (i & 3) of sample (i >> 2) of the current 16-sample chunk:
+//     it reads that sample's (x, y, attn) -- 192 contiguous bytes per chunk for the wave --
+//     and derives the corner's value-row offset and its weight, once (the reference
+//     recomputes this per channel, 32x);
+//   * phase 2: the 64 corner rows of the chunk are gathered RPI = 64/LPR rows at a time:
+//     LPR consecutive lanes read one whole D*4-byte row with one 16-byte load each (a
+//     128-B line for D = 32), the row's (offset, weight) arriving by ds_bpermute;
+//   * the RPI partial sums are folded with xor-shuffles and LPR lanes store the D outputs.
+//   The backward reuses phases 1-2 to form <grad_out, value_row> per corner row, hands each
+//   dot product back to the lane that owns the corner (which holds the bilinear
+//   coefficients), and reduces the 4 corners of a sample with two xor-shuffles -- no LDS
+//   barrier, no serial reduction.  grad_value is accumulated with hardware fp32 atomics
+//   shaped as whole D*4-byte rows (two 128-B segments per wave instruction for D = 32).
+//
+// Any other D, and float64, run the "generic" element-per-thread kernels further down.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zira_msda.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+// Blocks b and b+8 share an XCD (and its L2) under round-robin dispatch; give every XCD one
+// contiguous run of items so that neighbouring queries (which sample neighbouring pixels in
+// the encoder call) meet in the same L2.  Pure placement hint: bijective for any grid size.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nblocks)
+{
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = nblocks >> 3, rem = nblocks & 7;
+    return xcd * base + (xcd < rem ? xcd : rem) + idx;
+}
+
+struct Corner {
+    float w;     // bilinear weight * attention weight (0 when the corner contributes nothing)
+    int off;     // element offset of the corner's value row inside this batch element
+    float wb;    // bilinear weight alone
+    float cx;    // d(sample)/d(w_im) coefficient of this corner's value
+    float cy;    // d(sample)/d(h_im) coefficient of this corner's value
+    float a;     // attention weight of the sample
+    float Wf, Hf;
+    bool inb;    // corner inside the map and sample inside the (-1,H)x(-1,W) window
+};
+
+// Phase 1 for one lane: sample s of item, corner c = (dy, dx).
+// Pixel coordinates are formed with separately rounded mul and sub (no fma contraction) so
+// that floor() lands on the same pixel as the CPU restatement in oracle/msda_oracle.c.
+template <bool kNeedGrad>
+__device__ __forceinline__ Corner corner_setup(const int64_t *__restrict__ shapes,
+                                               const int64_t *__restrict__ start,
+                                               const float *__restrict__ loc_i,
+                                               const float *__restrict__ att_i, int s, int c,
+                                               int LP, int P, int M, int D, int m)
+{
+#pragma clang fp contract(off)
+    Corner k;
+    k.w = 0.f; k.off = 0; k.wb = 0.f; k.cx = 0.f; k.cy = 0.f; k.a = 0.f;
+    k.Wf = 0.f; k.Hf = 0.f; k.inb = false;
+    if (s < LP) {
+        const int l = s / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const int st = (int)start[l];
+        const float2 xy = *reinterpret_cast<const float2 *>(loc_i + 2 * s);
+        const float a = att_i[s];
+        const float h_im = xy.y * (float)H - 0.5f;
+        const float w_im = xy.x * (float)W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lh = h_im - hf, lw = w_im - wf;
+            const int dy = c >> 1, dx = c & 1;
+            const int y = (int)hf + dy, x = (int)wf + dx;
+            const float wy = dy ? lh : 1.f - lh;
+            const float wx = dx ? lw : 1.f - lw;
+            if (y >= 0 && y <= H - 1 && x >= 0 && x <= W - 1) {
+                k.inb = true;
+                k.wb = wy * wx;
+                k.w = k.wb * a;
+                k.off = ((st + y * W + x) * M + m) * D;
+                if (kNeedGrad) {
+                    k.cx = dx ? wy : -wy;
+                    k.cy = dy ? wx : -wx;
+                }
+            }
+            if (kNeedGrad) { k.a = a; k.Wf = (float)W; k.Hf = (float)H; }
+        }
+    }
+    return k;
+}
+
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int mask)
+{
+    float4 r;
+    r.x = __shfl_xor(v.x, mask);
+    r.y = __shfl_xor(v.y, mask);
+    r.z = __shfl_xor(v.z, mask);
+    r.w = __shfl_xor(v.w, mask);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, rows path
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void msda_fwd_rows(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ start, const float *__restrict__ loc,
+    const float *__restrict__ attn, int S, int M, int L, int Q, int P, long nitems,
+    float *__restrict__ out)
+{
+    constexpr int D = 4 * LPR;
+    constexpr int RPI = kWave / LPR;  // value rows gathered per wave instruction
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long item = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    if (item >= nitems) return;  // wave-uniform
+    const int m = (int)(item % M);
+    const int b = (int)(item / ((long)M * Q));
+    const int LP = L * P;
+    const float *vb = value + (size_t)b * S * M * D;
+    const float *loc_i = loc + item * LP * 2;
+    const float *att_i = attn + item * LP;
+    const int r = lane / LPR, cq = lane % LPR;
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < LP; s0 += 16) {
+        const Corner k = corner_setup<false>(shapes, start, loc_i, att_i, s0 + (lane >> 2),
+                                             lane & 3, LP, P, M, D, m);
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int src = j * RPI + r;
+            const float wj = __shfl(k.w, src);
+            const int oj = __shfl(k.off, src);
+            const float4 v = *reinterpret_cast<const float4 *>(vb + oj + cq * 4);
+            acc.x = fmaf(wj, v.x, acc.x);
+            acc.y = fmaf(wj, v.y, acc.y);
+            acc.z = fmaf(wj, v.z, acc.z);
+            acc.w = fmaf(wj, v.w, acc.w);
+        }
+    }
+#pragma unroll
+    for (int d = LPR; d < kWave; d <<= 1) {
+        const float4 o = shfl_xor4(acc, d);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    if (lane < LPR) *reinterpret_cast<float4 *>(out + item * D + cq * 4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, rows path (grad_value by fp32 atomics)
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void msda_bwd_rows_atomic(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Q,
+    int P, long nitems, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attn)
+{
+    constexpr int D = 4 * LPR;
+    constexpr int RPI = kWave / LPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long item = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    if (item >= nitems) return;
+    const int m = (int)(item % M);
+    const int b = (int)(item / ((long)M * Q));
+    const int LP = L * P;
+    const size_t boff = (size_t)b * S * M * D;
+    const float *vb = value + boff;
+    float *gvb = grad_value + boff;
+    const float *loc_i = loc + item * LP * 2;
+    const float *att_i = attn + item * LP;
+    const float *g_i = grad_out + item * D;
+    const int r = lane / LPR, cq = lane % LPR;
+    const float4 g4 = *reinterpret_cast<const float4 *>(g_i + cq * 4);
+
+    for (int s0 = 0; s0 < LP; s0 += 16) {
+        const int s = s0 + (lane >> 2);
+        const Corner k =
+            corner_setup<true>(shapes, start, loc_i, att_i, s, lane & 3, LP, P, M, D, m);
+
+        // <grad_out, value_row> for the 64 corner rows; row i's result ends in lane i.
+        float dot_mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int src = j * RPI + r;
+            const int oj = __shfl(k.off, src);
+            const float4 v = *reinterpret_cast<const float4 *>(vb + oj + cq * 4);
+            float d = v.x * g4.x + v.y * g4.y + v.z * g4.z + v.w * g4.w;
+#pragma unroll
+            for (int x = 1; x < LPR; x <<= 1) d += __shfl_xor(d, x);
+            const float t = __shfl(d, (lane % RPI) * LPR);
+            if (lane / RPI == j) dot_mine = t;
+        }
+        const float d = k.inb ? dot_mine : 0.f;
+        float ga = k.wb * d, gx = k.cx * d, gy = k.cy * d;
+        ga += __shfl_xor(ga, 1); gx += __shfl_xor(gx, 1); gy += __shfl_xor(gy, 1);
+        ga += __shfl_xor(ga, 2); gx += __shfl_xor(gx, 2); gy += __shfl_xor(gy, 2);
+        if ((lane & 3) == 0 && s < LP) {
+            grad_attn[item * LP + s] = ga;
+            float2 gl;
+            gl.x = k.Wf * k.a * gx;
+            gl.y = k.Hf * k.a * gy;
+            *reinterpret_cast<float2 *>(grad_loc + (item * LP + s) * 2) = gl;
+        }
+
+        // grad_value rows: every wave instruction adds whole rows (64/D rows of D floats).
+        if constexpr (D <= kWave) {
+            constexpr int RPA = kWave / D;
+            const int ch = lane % D, rr = lane / D;
+            const float gch = g_i[ch];
+#pragma unroll 4
+            for (int it = 0; it < kWave / RPA; ++it) {
+                const int src = it * RPA + rr;
+                const float wj = __shfl(k.w, src);
+                const int oj = __shfl(k.off, src);
+                if (wj != 0.f) unsafeAtomicAdd(gvb + oj + ch, wj * gch);
+            }
+        } else {
+            for (int row = 0; row < kWave; ++row) {
+                const float wj = __shfl(k.w, row);
+                const int oj = __shfl(k.off, row);
+                if (wj != 0.f)
+                    for (int ch = lane; ch < D; ch += kWave)
+                        unsafeAtomicAdd(gvb + oj + ch, wj * g_i[ch]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic path: any D, float or double; one thread per (b, q, m, c)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct Sample {
+    T w1, w2, w3, w4, lh, lw;
+    int o1, o2, o3, o4;  // element offsets inside the batch element, -1 = outside
+    bool valid;
+};
+
+template <typename T>
+__device__ __forceinline__ T mul_sub_half(T a, T b)
+{
+#pragma clang fp contract(off)
+    const T prod = a * b;
+    return prod - (T)0.5;
+}
+
+template <typename T>
+__device__ __forceinline__ Sample<T> sample_setup(T lx, T ly, int H, int W, int st, int M, int D,
+                                                  int m)
+{
+    Sample<T> s;
+    const T h_im = mul_sub_half<T>(ly, (T)H), w_im = mul_sub_half<T>(lx, (T)W);
+    s.valid = h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W;
+    s.o1 = s.o2 = s.o3 = s.o4 = -1;
+    s.w1 = s.w2 = s.w3 = s.w4 = s.lh = s.lw = 0;
+    if (s.valid) {
+        const T hf = floor(h_im), wf = floor(w_im);
+        const int hl = (int)hf, wl = (int)wf, hh = hl + 1, wh = wl + 1;
+        s.lh = h_im - hf; s.lw = w_im - wf;
+        const T hhw = 1 - s.lh, hww = 1 - s.lw;
+        s.w1 = hhw * hww; s.w2 = hhw * s.lw; s.w3 = s.lh * hww; s.w4 = s.lh * s.lw;
+        if (hl >= 0 && wl >= 0) s.o1 = ((st + hl * W + wl) * M + m) * D;
+        if (hl >= 0 && wh <= W - 1) s.o2 = ((st + hl * W + wh) * M + m) * D;
+        if (hh <= H - 1 && wl >= 0) s.o3 = ((st + hh * W + wl) * M + m) * D;
+        if (hh <= H - 1 && wh <= W - 1) s.o4 = ((st + hh * W + wh) * M + m) * D;
+    }
+    return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void msda_fwd_generic(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ start, const T *__restrict__ loc, const T *__restrict__ attn,
+    int S, int M, int D, int L, int Q, int P, long n, T *__restrict__ out)
+{
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % D);
+        const long item = idx / D;
+        const int m = (int)(item % M);
+        const int b = (int)(item / ((long)M * Q));
+        const T *vb = value + (size_t)b * S * M * D;
+        T col = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)start[l];
+            for (int p = 0; p < P; ++p) {
+                const long si = item * L * P + l * P + p;
+                const Sample<T> s = sample_setup<T>(loc[2 * si], loc[2 * si + 1], H, W, st, M, D, m);
+                if (!s.valid) continue;
+                const T v1 = s.o1 >= 0 ? vb[s.o1 + c] : (T)0;
+                const T v2 = s.o2 >= 0 ? vb[s.o2 + c] : (T)0;
+                const T v3 = s.o3 >= 0 ? vb[s.o3 + c] : (T)0;
+                const T v4 = s.o4 >= 0 ? vb[s.o4 + c] : (T)0;
+                col += (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4) * attn[si];
+            }
+        }
+        out[idx] = col;
+    }
+}
+
+// grad_loc / grad_attn must be zero on entry (they are reduced over the D channel threads
+// with atomics); the C entry point zero-fills all three outputs.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void msda_bwd_generic(
+    const T *__restrict__ grad_out, const T *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+    const T *__restrict__ loc, const T *__restrict__ attn, int S, int M, int D, int L, int Q,
+    int P, long n, T *__restrict__ grad_value, T *__restrict__ grad_loc,
+    T *__restrict__ grad_attn)
+{
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % D);
+        const long item = idx / D;
+        const int m = (int)(item % M);
+        const int b = (int)(item / ((long)M * Q));
+        const size_t boff = (size_t)b * S * M * D;
+        const T *vb = value + boff;
+        T *gvb = grad_value + boff;
+        const T top = grad_out[idx];
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)start[l];
+            for (int p = 0; p < P; ++p) {
+                const long si = item * L * P + l * P + p;
+                const Sample<T> s = sample_setup<T>(loc[2 * si], loc[2 * si + 1], H, W, st, M, D, m);
+                if (!s.valid) continue;
+                const T a = attn[si], tgv = top * a;
+                const T hhw = 1 - s.lh, hww = 1 - s.lw;
+                T v1 = 0, v2 = 0, v3 = 0, v4 = 0, gh = 0, gw = 0;
+                if (s.o1 >= 0) { v1 = vb[s.o1 + c]; gh -= hww * v1; gw -= hhw * v1;
+                                 unsafeAtomicAdd(gvb + s.o1 + c, s.w1 * tgv); }
+                if (s.o2 >= 0) { v2 = vb[s.o2 + c]; gh -= s.lw * v2; gw += hhw * v2;
+                                 unsafeAtomicAdd(gvb + s.o2 + c, s.w2 * tgv); }
+                if (s.o3 >= 0) { v3 = vb[s.o3 + c]; gh += hww * v3; gw -= s.lh * v3;
+                                 unsafeAtomicAdd(gvb + s.o3 + c, s.w3 * tgv); }
+                if (s.o4 >= 0) { v4 = vb[s.o4 + c]; gh += s.lw * v4; gw += s.lh * v4;
+                                 unsafeAtomicAdd(gvb + s.o4 + c, s.w4 * tgv); }
+                const T val = s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
+                unsafeAtomicAdd(grad_attn + si, top * val);
+                unsafeAtomicAdd(grad_loc + 2 * si, (T)W * gw * tgv);
+                unsafeAtomicAdd(grad_loc + 2 * si + 1, (T)H * gh * tgv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+inline int lpr_for(int D)
+{
+    switch (D) {
+        case 4: return 1;
+        case 8: return 2;
+        case 16: return 4;
+        case 32: return 8;
+        case 64: return 16;
+        case 128: return 32;
+        case 256: return 64;
+        default: return 0;
+    }
+}
+
+inline bool args_ok(const void *value, const void *shapes, const void *start, const void *loc,
+                    const void *attn, int B, int S, int M, int D, int L, int Q, int P)
+{
+    if (!value || !shapes || !start || !loc || !attn) return false;
+    if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0) return false;
+    const long long per_value = (long long)S * M * D;
+    const long long per_loc = (long long)Q * M * L * P * 2;
+    if (per_value >= (1LL << 31) || per_loc >= (1LL << 31)) return false;
+    return true;
+}
+
+inline int generic_grid(long n)
+{
+    long blocks = (n + kBlock - 1) / kBlock;
+    const long cap = 256L * 8;  // 256 CUs x 8 blocks, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    return (int)blocks;
+}
+
+template <int LPR>
+int launch_fwd_rows(const float *value, const int64_t *shapes, const int64_t *start,
+                    const float *loc, const float *attn, int B, int S, int M, int L, int Q, int P,
+                    float *out, hipStream_t st)
+{
+    const long nitems = (long)B * Q * M;
+    const int grid = (int)((nitems + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(msda_fwd_rows<LPR>, dim3(grid), dim3(kBlock), 0, st, value, shapes, start,
+                       loc, attn, S, M, L, Q, P, nitems, out);
+    return (int)hipGetLastError();
+}
+
+template <int LPR>
+int launch_bwd_rows(const float *grad_out, const float *value, const int64_t *shapes,
+                    const int64_t *start, const float *loc, const float *attn, int B, int S, int M,
+                    int L, int Q, int P, float *gv, float *gl, float *ga, hipStream_t st)
+{
+    const long nitems = (long)B * Q * M;
+    const int grid = (int)((nitems + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(msda_bwd_rows_atomic<LPR>, dim3(grid), dim3(kBlock), 0, st, grad_out, value,
+                       shapes, start, loc, attn, S, M, L, Q, P, nitems, gv, gl, ga);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int fwd_generic(const T *value, const int64_t *shapes, const int64_t *start, const T *loc,
+                const T *attn, int B, int S, int M, int D, int L, int Q, int P, T *out,
+                hipStream_t st)
+{
+    const long n = (long)B * Q * M * D;
+    hipLaunchKernelGGL(msda_fwd_generic<T>, dim3(generic_grid(n)), dim3(kBlock), 0, st, value,
+                       shapes, start, loc, attn, S, M, D, L, Q, P, n, out);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int bwd_generic(const T *grad_out, const T *value, const int64_t *shapes, const int64_t *start,
+                const T *loc, const T *attn, int B, int S, int M, int D, int L, int Q, int P,
+                T *gv, T *gl, T *ga, hipStream_t st)
+{
+    const long n = (long)B * Q * M * D;
+    const size_t nsamp = (size_t)B * Q * M * L * P;
+    hipError_t e = hipMemsetAsync(gv, 0, sizeof(T) * (size_t)B * S * M * D, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(gl, 0, sizeof(T) * nsamp * 2, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(ga, 0, sizeof(T) * nsamp, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(msda_bwd_generic<T>, dim3(generic_grid(n)), dim3(kBlock), 0, st, grad_out,
+                       value, shapes, start, loc, attn, S, M, D, L, Q, P, n, gv, gl, ga);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *start,
+                      const float *loc, const float *attn, int B, int S, int M, int D, int L,
+                      int Q, int P, float *out, void *stream)
+{
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !out)
+        return ZIRA_MSDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define ZIRA_FWD_CASE(LPR_)                                                                      \
+    case LPR_:                                                                                   \
+        return launch_fwd_rows<LPR_>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
+    switch (lpr_for(D)) {
+        ZIRA_FWD_CASE(1) ZIRA_FWD_CASE(2) ZIRA_FWD_CASE(4) ZIRA_FWD_CASE(8) ZIRA_FWD_CASE(16)
+        ZIRA_FWD_CASE(32) ZIRA_FWD_CASE(64)
+        default: break;
+    }
+#undef ZIRA_FWD_CASE
+    return fwd_generic<float>(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out, st);
+}
+
+int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                      const int64_t *start, const float *loc, const float *attn, int B, int S,
+                      int M, int D, int L, int Q, int P, float *gv, float *gl, float *ga,
+                      void *stream)
+{
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv ||
+        !gl || !ga)
+        return ZIRA_MSDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int lpr = lpr_for(D);
+    if (lpr == 0)
+        return bwd_generic<float>(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
+                                  gv, gl, ga, st);
+    hipError_t e = hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * S * M * D, st);
+    if (e != hipSuccess) return (int)e;
+#define ZIRA_BWD_CASE(LPR_)                                                                      \
+    case LPR_:                                                                                   \
+        return launch_bwd_rows<LPR_>(grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, \
+                                     gv, gl, ga, st);
+    switch (lpr) {
+        ZIRA_BWD_CASE(1) ZIRA_BWD_CASE(2) ZIRA_BWD_CASE(4) ZIRA_BWD_CASE(8) ZIRA_BWD_CASE(16)
+        ZIRA_BWD_CASE(32) ZIRA_BWD_CASE(64)
+        default: break;
+    }
+#undef ZIRA_BWD_CASE
+    return ZIRA_MSDA_EINVAL;
+}
+
+int zira_msda_fwd_f64(const double *value, const int64_t *shapes, const int64_t *start,
+                      const double *loc, const double *attn, int B, int S, int M, int D, int L,
+                      int Q, int P, double *out, void *stream)
+{
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !out)
+        return ZIRA_MSDA_EINVAL;
+    return fwd_generic<double>(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out,
+                               (hipStream_t)stream);
+}
+
+int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t *shapes,
+                      const int64_t *start, const double *loc, const double *attn, int B, int S,
+                      int M, int D, int L, int Q, int P, double *gv, double *gl, double *ga,
+                      void *stream)
+{
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv ||
+        !gl || !ga)
+        return ZIRA_MSDA_EINVAL;
+    return bwd_generic<double>(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P, gv,
+                               gl, ga, (hipStream_t)stream);
+}
+
+const char *zira_msda_version(void) { return "zira_msda 0.1 gfx950"; }
+
+const char *zira_msda_variant_f32(int D)
+{
+    switch (lpr_for(D)) {
+        case 1: return "rows<1>";
+        case 2: return "rows<2>";
+        case 4: return "rows<4>";
+        case 8: return "rows<8>";
+        case 16: return "rows<16>";
+        case 32: return "rows<32>";
+        case 64: return "rows<64>";
+        default: return "generic";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference op module (groundingdino/models/GroundingDINO/ms_deform_attn.py).
+
+Same public names and call signatures:
+
+* ``MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index,
+  sampling_locations, attention_weights, im2col_step)``            (reference :38-87)
+* ``MultiScaleDeformableAttention(embed_dim, num_heads, num_levels, num_points, img2col_step,
+  batch_first)`` with parameters ``sampling_offsets / attention_weights / value_proj /
+  output_proj`` and the same ``forward`` keyword arguments                 (reference :133-355)
+
+The sampling + aggregation itself always runs in the gfx950 kernels behind ``_C`` -- there is
+no Python/CPU fallback here (the reference's ``multi_scale_deformable_attn_pytorch`` lives on
+only as test infrastructure under ``oracle/``).
+"""
+import math
+import warnings
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _C
+
+
+class MultiScaleDeformableAttnFunction(Function):
+    """autograd glue around the two native entry points (reference ms_deform_attn.py:38-87)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = _C.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                           sampling_locations, attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, start, loc, attn = ctx.saved_tensors
+        grad_value, grad_loc, grad_attn = _C.ms_deform_attn_backward(
+            value, shapes, start, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_attn, None
+
+
+def sampling_locations_from_reference_points(reference_points, sampling_offsets, spatial_shapes,
+                                             num_points):
+    """Sampling-location arithmetic of the reference module (ms_deform_attn.py:305-325).
+
+    reference_points ``[B,Q,L,2]`` (encoder: pixel-centre grid) or ``[B,Q,L,4]`` (decoder:
+    cx,cy,w,h boxes); sampling_offsets ``[B,Q,M,L,P,2]``; returns ``[B,Q,M,L,P,2]`` in (x, y).
+    """
+    last = reference_points.shape[-1]
+    if last == 2:
+        # offsets are in pixels of each level: normalise by (W, H)
+        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        return (reference_points[:, :, None, :, None, :]
+                + sampling_offsets / normalizer[None, None, None, :, None, :])
+    if last == 4:
+        # offsets are fractions of half the box size, spread over the P points
+        return (reference_points[:, :, None, :, None, :2]
+                + sampling_offsets / num_points * reference_points[:, :, None, :, None, 2:] * 0.5)
+    raise ValueError(
+        "Last dim of reference_points must be 2 or 4, but get {} instead.".format(last))
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    """Multi-scale deformable attention (Deformable-DETR) with the reference's parameter names.
+
+    State-dict keys: ``sampling_offsets.{weight,bias}`` (M*L*P*2 x C), ``attention_weights.*``
+    (M*L*P x C), ``value_proj.*``, ``output_proj.*`` -- identical to the reference so its
+    checkpoints load unchanged.
+    """
+
+    def __init__(self, embed_dim: int = 256, num_heads: int = 8, num_levels: int = 4,
+                 num_points: int = 4, img2col_step: int = 64, batch_first: bool = False):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError("embed_dim must be divisible by num_heads, but got {} and {}".format(
+                embed_dim, num_heads))
+        head_dim = embed_dim // num_heads
+        if head_dim & (head_dim - 1):
+            warnings.warn("head_dim=%d is not a power of two: the op takes its generic "
+                          "(slower) kernel path" % head_dim)
+        self.batch_first = batch_first
+        self.im2col_step = img2col_step
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.num_levels = num_levels
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dim, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dim, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dim, embed_dim)
+        self.output_proj = nn.Linear(embed_dim, embed_dim)
+        self.init_weights()
+
+    def _reset_parameters(self):
+        return self.init_weights()
+
+    def init_weights(self):
+        """Deterministic init of the reference (ms_deform_attn.py:194-217): zero offset weights,
+        bias = M unit directions (max-norm 1) scaled by the point index, uniform attention."""
+        with torch.no_grad():
+            self.sampling_offsets.weight.zero_()
+            theta = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+            direction = torch.stack([theta.cos(), theta.sin()], -1)
+            direction = direction / direction.abs().max(-1, keepdim=True)[0]
+            grid = direction.view(self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+            grid = grid * torch.arange(1, self.num_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+            self.sampling_offsets.bias.copy_(grid.reshape(-1))
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+
+    def freeze_sampling_offsets(self):
+        print("Freeze sampling offsets")
+        self.sampling_offsets.weight.requires_grad = False
+        self.sampling_offsets.bias.requires_grad = False
+
+    def freeze_attention_weights(self):
+        print("Freeze attention weights")
+        self.attention_weights.weight.requires_grad = False
+        self.attention_weights.bias.requires_grad = False
+
+    def project(self, query, value, key_padding_mask, reference_points, spatial_shapes):
+        """Everything of ``forward`` up to the native call (reference :286-325), batch-first.
+        Returns (value[B,S,M,D], sampling_locations[B,Q,M,L,P,2], attention_weights[B,Q,M,L,P])."""
+        bs, num_query, _ = query.shape
+        num_value = value.shape[1]
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], float(0))
+        value = value.view(bs, num_value, M, -1)
+        offsets = self.sampling_offsets(query).view(bs, num_query, M, L, P, 2)
+        attn = self.attention_weights(query).view(bs, num_query, M, L * P)
+        attn = attn.softmax(-1).view(bs, num_query, M, L, P)
+        loc = sampling_locations_from_reference_points(reference_points, offsets, spatial_shapes, P)
+        return value, loc, attn
+
+    def forward(self, query: torch.Tensor, key: Optional[torch.Tensor] = None,
+                value: Optional[torch.Tensor] = None, query_pos: Optional[torch.Tensor] = None,
+                key_padding_mask: Optional[torch.Tensor] = None,
+                reference_points: Optional[torch.Tensor] = None,
+                spatial_shapes: Optional[torch.Tensor] = None,
+                level_start_index: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+        if value is None:
+            value = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == value.shape[1]
+
+        value, loc, attn = self.project(query, value, key_padding_mask, reference_points,
+                                        spatial_shapes)
+        half = value.dtype in (torch.float16, torch.bfloat16)
+        out_dtype = value.dtype
+        if half:  # the native op is fp32/fp64 (reference :326-344 upcasts fp16 the same way)
+            value, loc, attn = value.float(), loc.float(), attn.float()
+        output = MultiScaleDeformableAttnFunction.apply(
+            value.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
+            attn.contiguous(), self.im2col_step)
+        if half:
+            output = output.to(out_dtype)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return output
