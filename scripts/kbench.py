@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmark of the two native entry points (decoder + encoder shapes).
+Interleaved rounds in one process; prints median/min microseconds and algorithmic GB/s."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import NORTH_STAR_SHAPES, make_msda_inputs, msda_algorithmic_bytes  # noqa: E402
+from ziragroundingdino_amd import _C  # noqa: E402
+
+
+def graphed(fn, n):
+    """Capture n back-to-back calls into a hipGraph so that replay is device-bound (the Python
+    shim costs ~10 us of host time per call, more than the kernels take)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    return g.replay
+
+
+def timeit(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def encoder_loc(B, M, shapes, P, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    sh = torch.tensor(shapes, dtype=torch.float32)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in shapes])
+    S, L = ref.shape[0], len(shapes)
+    off = 2.0 * torch.randn(B, S, M, L, P, 2, generator=g)
+    norm = torch.stack([sh[:, 1], sh[:, 0]], -1)[None, None, None, :, None, :]
+    return (ref[None, :, None, None, None, :] + off / norm).contiguous().to(dev)
+
+
+def main():
+    dev = torch.device("cuda")
+    rounds = int(os.environ.get("ROUNDS", "7"))
+    cfgs = []
+    B, M, D, P = 2, 8, 32, 4
+    shapes = NORTH_STAR_SHAPES
+    S = sum(h * w for h, w in shapes)
+    v, sh, st, loc, attn, go = make_msda_inputs(B, 900, M, D, shapes, P, 0, dev)
+    cfgs.append(("decoder_uniform", (v, sh, st, loc, attn, go), 900, 200))
+    g = torch.Generator().manual_seed(1)
+    centre = torch.rand(B, 900, 1, 1, 1, 2, generator=g) * 0.8 + 0.1
+    cl = (centre + 0.05 * torch.randn(B, 900, M, 4, P, 2, generator=g)).to(dev)
+    cfgs.append(("decoder_clustered", (v, sh, st, cl, attn, go), 900, 200))
+    ve, _, _, _, attne, goe = make_msda_inputs(B, S, M, D, shapes, P, 2, dev)
+    cfgs.append(("encoder", (ve, sh, st, encoder_loc(B, M, shapes, P, 3, dev), attne, goe), S, 20))
+    for name, (v, sh, st, loc, attn, go), Q, iters in cfgs:
+        fb, bb = msda_algorithmic_bytes(B, S, M, D, 4, Q, P)
+        fwd = lambda: _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
+        bwd = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+        for _ in range(3):
+            fwd(); bwd()
+        per = 20
+        gf, gb = graphed(fwd, per), graphed(bwd, per)
+        tf, tb = [], []
+        for _ in range(rounds):
+            tf.append(timeit(gf, max(1, iters // per)) / per)
+            tb.append(timeit(gb, max(1, iters // per)) / per)
+        print("%-18s fwd med %8.2f us (min %8.2f) %7.0f GB/s | bwd med %8.2f us (min %8.2f) %7.0f GB/s"
+              % (name, np.median(tf), min(tf), fb / np.median(tf) / 1e3,
+                 np.median(tb), min(tb), bb / np.median(tb) / 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    main()

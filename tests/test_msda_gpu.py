@@ -185,7 +185,7 @@ def test_full_size_properties():
     torch.testing.assert_close(gl2, 2 * gl, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(gv2, 2 * gv, rtol=1e-4, atol=1e-5)
     far = torch.full_like(tloc, 2.5)
-    assert not f(v, far.contiguous()).any()
+    assert not _C.ms_deform_attn_forward(v, tsh, tst, far, tattn, 64).any()
     z = _C.ms_deform_attn_backward(v, tsh, tst, far, tattn, tgo, 64)
     assert not z[0].any() and not z[1].any() and not z[2].any()
 

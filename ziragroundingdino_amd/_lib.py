@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzira_msda.so")
+LIB_PATH = os.environ.get("ZIRA_MSDA_LIB") or os.path.join(_HERE, "libzira_msda.so")  # env: dev A/B builds
 
 # every symbol include/zira_msda.h declares (tests check the .so exports exactly these)
 SYMBOLS = (

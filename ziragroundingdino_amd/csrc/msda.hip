@@ -29,20 +29,44 @@
 
 #include "zira_msda.h"
 
+#ifndef ZIRA_ABLATE
+#define ZIRA_ABLATE 0  // developer-only ablation switches; 0 in every shipped build
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
 
-// Blocks b and b+8 share an XCD (and its L2) under round-robin dispatch; give every XCD one
-// contiguous run of items so that neighbouring queries (which sample neighbouring pixels in
-// the encoder call) meet in the same L2.  Pure placement hint: bijective for any grid size.
-__device__ __forceinline__ int xcd_contiguous_block(int bid, int nblocks)
+// Head-major placement.  All items of one (b, m) "group" read the same value slice
+// value[b, :, m, :] (S*D*4 bytes: 2.8 MB at S=22223, D=32), which fits one XCD's 4 MiB L2.
+// The item list is therefore walked group-major (b, m, q) and cut into 8 equal contiguous
+// chunks, one per XCD (blocks bid, bid+8, ... share an XCD under round-robin dispatch): every
+// XCD then works through ~B*M/8 groups one after the other, fetches each value row from
+// HBM / Infinity Cache about once and serves the 4-corner re-reads from its own L2.
+// Placement only affects speed; any block->XCD assignment gives the same results.
+// Returns the flat (b, q, m) item index for (block, wave), or -1 when the wave has no item.
+__device__ __forceinline__ long head_major_item(int bid, int wave, long nitems, int Q, int M,
+                                                int &b, int &m)
 {
     const int xcd = bid & 7, idx = bid >> 3;
-    const int base = nblocks >> 3, rem = nblocks & 7;
-    return xcd * base + (xcd < rem ? xcd : rem) + idx;
+    const long per = (nitems + 7) >> 3;
+    const long t0 = xcd * per;
+    const long t = t0 + (long)idx * kWavesPerBlock + wave;
+    const long t1 = (t0 + per < nitems) ? t0 + per : nitems;
+    if (t >= t1) return -1;
+    const long g = t / Q;
+    const int q = (int)(t - g * Q);
+    b = (int)(g / M);
+    m = (int)(g - (long)b * M);
+    return ((long)b * Q + q) * M + m;
+}
+
+inline int head_major_grid(long nitems)
+{
+    const long per = (nitems + 7) >> 3;
+    return (int)(8 * ((per + kWavesPerBlock - 1) / kWavesPerBlock));
 }
 
 struct Corner {
@@ -125,10 +149,9 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_rows(
     constexpr int RPI = kWave / LPR;  // value rows gathered per wave instruction
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long item = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    if (item >= nitems) return;  // wave-uniform
-    const int m = (int)(item % M);
-    const int b = (int)(item / ((long)M * Q));
+    int b, m;
+    const long item = head_major_item(blockIdx.x, wave, nitems, Q, M, b, m);
+    if (item < 0) return;  // wave-uniform
     const int LP = L * P;
     const float *vb = value + (size_t)b * S * M * D;
     const float *loc_i = loc + item * LP * 2;
@@ -174,10 +197,9 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_rows_atomic(
     constexpr int RPI = kWave / LPR;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long item = (long)xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    if (item >= nitems) return;
-    const int m = (int)(item % M);
-    const int b = (int)(item / ((long)M * Q));
+    int b, m;
+    const long item = head_major_item(blockIdx.x, wave, nitems, Q, M, b, m);
+    if (item < 0) return;
     const int LP = L * P;
     const size_t boff = (size_t)b * S * M * D;
     const float *vb = value + boff;
@@ -240,6 +262,184 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_rows_atomic(
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// "lean" path: D = 16*CQR in {16, 32, 64}.
+//
+// The op turned out to be VALU-issue bound on MI355X, not bandwidth bound (removing every
+// gather load from an earlier version only took it from 11.8 to 7.4 us at the north-star
+// shape), so this version is organised around instruction count per (b, q, m) item:
+//   * all index arithmetic is wave-uniform and kept on the scalar unit (32-bit);
+//   * phase 1: lane e owns entry e = (sample e>>2, corner e&3) of the 16-sample chunk -- 64
+//     distinct (offset, weight) pairs, nothing computed twice;
+//   * gather: a 16-lane DPP row R serves channel quads [R*CQR, (R+1)*CQR); inside the row the
+//     lanes are (slot, cq_local), slot = one of SLOTS = 16/CQR value rows per instruction.
+//     Entry -> slot hand-off is one ds_bpermute per operand whose source lane (j*SLOTS+slot)
+//     folds into the instruction's immediate offset;  value rows are addressed as
+//     scalar base + 32-bit byte offset (no 64-bit VALU adds);  4 channels x weight is two
+//     v_pk_fma_f32;
+//   * because all SLOTS partial sums of a channel live in one DPP row, the final reduction
+//     is log2(SLOTS) v_add_f32_dpp row rotations -- no cross-row traffic, no LDS.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x)
+{
+    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+
+struct ItemId {
+    unsigned item;  // flat (b, q, m)
+    unsigned b, m;
+    bool ok;
+};
+
+// n / d for n < 2^31 with a host-prepared multiplier (no hardware integer divide on the GPU:
+// a plain `/` costs ~30 scalar instructions per wave, and the scalar unit is shared by the CU)
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f)
+{
+    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
+}
+
+// head-major placement (see head_major_item), wave-uniform / scalar, 32-bit
+__device__ __forceinline__ ItemId lean_item(unsigned nitems, unsigned per, FastDiv Q, FastDiv M)
+{
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned t0 = xcd * per;
+    const unsigned t = t0 + idx * kWavesPerBlock + wave;
+    const unsigned t1 = (t0 + per < nitems) ? t0 + per : nitems;
+    ItemId r;
+    r.ok = t < t1;
+#if ZIRA_ABLATE == 4
+    r.ok = t < nitems; r.item = t; const unsigned bq = fast_div(t, M); r.m = t - bq * M.d;
+    r.b = fast_div(bq, Q);
+    return r;
+#endif
+    const unsigned g = fast_div(t, Q), q = t - g * Q.d;
+    r.b = fast_div(g, M);
+    r.m = g - r.b * M.d;
+    r.item = (r.b * Q.d + q) * M.d + r.m;
+    return r;
+}
+
+struct Entry {
+    float w;        // bilinear weight x attention weight, 0 for a corner that contributes nothing
+    unsigned offb;  // BYTE offset of the corner's value row inside the batch element (0 if unused)
+    // backward only
+    float wb, cx, cy, a, Wf, Hf;
+    bool inb;
+};
+
+template <bool kNeedGrad>
+__device__ __forceinline__ Entry entry_setup(const int64_t *__restrict__ shapes,
+                                             const int64_t *__restrict__ start,
+                                             const float *__restrict__ loc_i,
+                                             const float *__restrict__ att_i, unsigned s,
+                                             unsigned c, unsigned LP, float invP, unsigned M,
+                                             unsigned D, unsigned m)
+{
+#pragma clang fp contract(off)
+    Entry k;
+    const bool act = s < LP;
+    const unsigned sc = act ? s : 0u;
+    const unsigned l = (unsigned)(((float)sc + 0.5f) * invP);  // == sc / P
+    // low dwords of the int64 level table (sizes are < 2^31)
+    const int2 hw = make_int2(reinterpret_cast<const int *>(shapes)[4 * l],
+                              reinterpret_cast<const int *>(shapes)[4 * l + 2]);
+    const int st = reinterpret_cast<const int *>(start)[2 * l];
+    const float2 xy = *reinterpret_cast<const float2 *>(loc_i + 2 * sc);
+    const float a = att_i[sc];
+    const float Hf = (float)hw.x, Wf = (float)hw.y;
+    const float h_im = xy.y * Hf - 0.5f;
+    const float w_im = xy.x * Wf - 0.5f;
+    const bool valid = act && h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const float lh = h_im - hf, lw = w_im - wf;
+    const int dy = (int)(c >> 1), dx = (int)(c & 1);
+    const int y = (int)hf + dy, x = (int)wf + dx;
+    const float wy = dy ? lh : 1.f - lh;
+    const float wx = dx ? lw : 1.f - lw;
+    k.inb = valid && y >= 0 && y < hw.x && x >= 0 && x < hw.y;
+    k.wb = k.inb ? wy * wx : 0.f;
+    k.w = k.wb * a;
+#if ZIRA_ABLATE == 5
+    k.offb = k.inb ? ((unsigned)(st + y * hw.y + x) + m * 22223u) * (D * 4u) : 0u;  // pretend [B,M,S,D]
+#else
+    k.offb = k.inb ? ((unsigned)(st + y * hw.y + x) * M + m) * (D * 4u) : 0u;
+#endif
+    if (kNeedGrad) {
+        k.cx = k.inb ? (dx ? wy : -wy) : 0.f;
+        k.cy = k.inb ? (dy ? wx : -wx) : 0.f;
+        k.a = valid ? a : 0.f;
+        k.Wf = Wf; k.Hf = Hf;
+    }
+    return k;
+}
+
+__device__ __forceinline__ float4 load_row16(const float *__restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+template <int CQR>
+__global__ __launch_bounds__(kBlock, 8) void msda_fwd_lean(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ start, const float *__restrict__ loc,
+    const float *__restrict__ attn, unsigned S, FastDiv Mdiv, unsigned LP, FastDiv Qdiv,
+    float invP, unsigned nitems, unsigned per_xcd, float *__restrict__ out)
+{
+    constexpr unsigned D = 16 * CQR;
+    constexpr unsigned SLOTS = 16 / CQR;  // value rows per gather instruction
+    constexpr unsigned NI = 64 / SLOTS;   // gather instructions per 64-entry chunk
+    const unsigned M = Mdiv.d;
+    const ItemId id = lean_item(nitems, per_xcd, Qdiv, Mdiv);
+    if (!id.ok) return;  // wave-uniform
+    const unsigned lane = threadIdx.x & 63;
+    const float *vb = value + (size_t)id.b * S * M * D;  // uniform
+    const float *loc_i = loc + (size_t)id.item * LP * 2;
+    const float *att_i = attn + (size_t)id.item * LP;
+
+    const unsigned R = lane >> 4;
+    const unsigned slot = (lane & 15) / CQR;
+    const unsigned cq = R * CQR + (lane & (CQR - 1));
+    const int bp = (int)(slot * 4);  // ds_bpermute byte address of source lane `slot`
+    const unsigned lane_off = cq * 16;
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned s0 = 0; s0 < LP; s0 += 16) {
+        const Entry k = entry_setup<false>(shapes, start, loc_i, att_i, s0 + (lane >> 2),
+                                           lane & 3, LP, invP, M, D, id.m);
+        const int offb_i = (int)k.offb, w_i = __float_as_int(k.w);
+#pragma unroll
+        for (unsigned j = 0; j < NI; ++j) {
+            const int a = bp + (int)(j * SLOTS * 4);
+            const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(a, offb_i);
+            const float wj = __int_as_float(__builtin_amdgcn_ds_bpermute(a, w_i));
+#if ZIRA_ABLATE == 1
+            const float4 v = make_float4((float)oj, 1.f, 2.f, 3.f);
+#else
+            const float4 v = load_row16(vb, oj + lane_off);
+#endif
+            acc.x = fmaf(wj, v.x, acc.x);
+            acc.y = fmaf(wj, v.y, acc.y);
+            acc.z = fmaf(wj, v.z, acc.z);
+            acc.w = fmaf(wj, v.w, acc.w);
+        }
+    }
+    // reduce over the SLOTS lanes (same DPP row) that hold the same channel quad
+    if (CQR <= 1) { acc.x = dpp_add<0x121>(acc.x); acc.y = dpp_add<0x121>(acc.y);
+                    acc.z = dpp_add<0x121>(acc.z); acc.w = dpp_add<0x121>(acc.w); }
+    if (CQR <= 2) { acc.x = dpp_add<0x122>(acc.x); acc.y = dpp_add<0x122>(acc.y);
+                    acc.z = dpp_add<0x122>(acc.z); acc.w = dpp_add<0x122>(acc.w); }
+    acc.x = dpp_add<0x124>(acc.x); acc.y = dpp_add<0x124>(acc.y);
+    acc.z = dpp_add<0x124>(acc.z); acc.w = dpp_add<0x124>(acc.w);
+    acc.x = dpp_add<0x128>(acc.x); acc.y = dpp_add<0x128>(acc.y);
+    acc.z = dpp_add<0x128>(acc.z); acc.w = dpp_add<0x128>(acc.w);
+    if (slot == 0) *reinterpret_cast<float4 *>(out + (size_t)id.item * D + cq * 4) = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -388,6 +588,26 @@ inline bool args_ok(const void *value, const void *shapes, const void *start, co
     return true;
 }
 
+// the lean kernels use 32-bit byte offsets inside a batch element and 32-bit item counts
+inline bool lean_ok(int B, int S, int M, int D, int L, int Q, int P)
+{
+    return (long long)S * M * D * 4 < (1LL << 32) && (long long)B * Q * M < (1LL << 31) &&
+           (long long)L * P < (1 << 20);
+}
+
+// mul, shift with (n * mul) >> shift == n / d for every n < 2^31:
+// s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1 (< 2^32), shift = 31 + s.
+inline FastDiv make_fast_div(unsigned d)
+{
+    FastDiv f;
+    f.d = d;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = 31 + s;
+    f.mul = (unsigned)(((1ull << (31 + s)) / d) + 1);
+    return f;
+}
+
 inline int generic_grid(long n)
 {
     long blocks = (n + kBlock - 1) / kBlock;
@@ -402,9 +622,22 @@ int launch_fwd_rows(const float *value, const int64_t *shapes, const int64_t *st
                     float *out, hipStream_t st)
 {
     const long nitems = (long)B * Q * M;
-    const int grid = (int)((nitems + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int grid = head_major_grid(nitems);
     hipLaunchKernelGGL(msda_fwd_rows<LPR>, dim3(grid), dim3(kBlock), 0, st, value, shapes, start,
                        loc, attn, S, M, L, Q, P, nitems, out);
+    return (int)hipGetLastError();
+}
+
+template <int CQR>
+int launch_fwd_lean(const float *value, const int64_t *shapes, const int64_t *start,
+                    const float *loc, const float *attn, int B, int S, int M, int L, int Q, int P,
+                    float *out, hipStream_t st)
+{
+    const unsigned nitems = (unsigned)B * Q * M;
+    hipLaunchKernelGGL(msda_fwd_lean<CQR>, dim3(head_major_grid(nitems)), dim3(kBlock), 0, st,
+                       value, shapes, start, loc, attn, (unsigned)S, make_fast_div((unsigned)M),
+                       (unsigned)(L * P), make_fast_div((unsigned)Q), 1.0f / (float)P, nitems,
+                       (nitems + 7) >> 3, out);
     return (int)hipGetLastError();
 }
 
@@ -414,7 +647,7 @@ int launch_bwd_rows(const float *grad_out, const float *value, const int64_t *sh
                     int L, int Q, int P, float *gv, float *gl, float *ga, hipStream_t st)
 {
     const long nitems = (long)B * Q * M;
-    const int grid = (int)((nitems + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int grid = head_major_grid(nitems);
     hipLaunchKernelGGL(msda_bwd_rows_atomic<LPR>, dim3(grid), dim3(kBlock), 0, st, grad_out, value,
                        shapes, start, loc, attn, S, M, L, Q, P, nitems, gv, gl, ga);
     return (int)hipGetLastError();
@@ -460,6 +693,11 @@ int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *
     if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !out)
         return ZIRA_MSDA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (lean_ok(B, S, M, D, L, Q, P)) {
+        if (D == 16) return launch_fwd_lean<1>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
+        if (D == 32) return launch_fwd_lean<2>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
+        if (D == 64) return launch_fwd_lean<4>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
+    }
 #define ZIRA_FWD_CASE(LPR_)                                                                      \
     case LPR_:                                                                                   \
         return launch_fwd_rows<LPR_>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
