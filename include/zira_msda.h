@@ -63,6 +63,23 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
                       float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                       void *stream);
 
+/* Atomic-free float32 backward (same results up to summation order).
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size the two-kernel "tiled" backward
+ * needs for these dimensions, or 0 when that path does not apply (the plain entry point is
+ * then the only one).  The workspace is caller-owned DEVICE memory, 16-byte aligned, needs no
+ * initialisation and may be reused by later calls on the same stream; with workspace == NULL
+ * or too small the call degrades to zira_msda_bwd_f32.  grad_value is written exactly once
+ * and never zero-filled.  Extra precondition: the levels tile [0, S) exactly
+ * (level_start_index[l] + H_l*W_l == level_start_index[l+1], last one == S), which the
+ * reference module asserts (ms_deform_attn.py:284). */
+size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P);
+
+int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start_index, const float *sampling_loc,
+                         const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                         float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* float64 twins: the reference dispatches AT_DISPATCH_FLOATING_TYPES = {float, double}
  * (ms_deform_attn_cuda.cu:65, :135). */
 int zira_msda_fwd_f64(const double *value, const int64_t *spatial_shapes,

@@ -234,3 +234,58 @@ def test_boundary_errors_match_reference():
         _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo.transpose(0, 1).contiguous().transpose(0, 1), 64)
     with pytest.raises(RuntimeError, match="not implemented for"):
         _C.ms_deform_attn_forward(v.half(), tsh, tst, tloc.half(), tattn.half(), 64)
+
+
+def test_tiled_and_atomic_backward_agree(oracle):
+    """The default backward is the atomic-free two-kernel path (C ABI zira_msda_bwd_f32_ws);
+    forcing the atomic path (zira_msda_bwd_f32) must give the same three gradients."""
+    from ziragroundingdino_amd import _lib
+
+    lib = _lib.load()
+    for (B, Q, M, D, shapes, P) in [(2, 900, 8, 32, NORTH_STAR_SHAPES, 4),
+                                    (1, 100, 4, 32, [(16, 20)], 4),          # BASELINE configs[0]
+                                    (3, 131, 5, 16, [(9, 11), (4, 6), (2, 3)], 3),
+                                    (2, 77, 2, 64, [(30, 41), (15, 21)], 8)]:  # LP = 16 / 9 / 16
+        S = sum(h * w for h, w in shapes)
+        assert lib.zira_msda_bwd_workspace_bytes(B, S, M, D, len(shapes), Q, P) > 0
+        value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=21, lo=-0.2, hi=1.2)
+        t = lambda a: torch.from_numpy(a).to(DEV)
+        args = list(map(t, (value, sh, start, loc, attn, go)))
+        tiled = _C.ms_deform_attn_backward(*args, 64)
+        _C.USE_TILED_BACKWARD = False
+        try:
+            atomic = _C.ms_deform_attn_backward(*args, 64)
+        finally:
+            _C.USE_TILED_BACKWARD = True
+        want = oracle.msda_backward(go, value, sh, start, loc, attn)
+        for a, b, w, name in zip(tiled, atomic, want, ("grad_value", "grad_loc", "grad_attn")):
+            _close(a, w, 2e-5, "tiled " + name)
+            _close(b, w, 2e-5, "atomic " + name)
+        assert torch.equal(tiled[1], atomic[1]) and torch.equal(tiled[2], atomic[2])
+
+
+def test_tiled_backward_overwrites_poisoned_grad_value():
+    """grad_value is written exactly once by the tiled path: no dependence on prior contents
+    (the torch.empty buffer the binding hands over) and no row left unwritten."""
+    from ziragroundingdino_amd import _lib
+
+    lib = _lib.load()
+    B, Q, M, D, shapes, P = 2, 50, 8, 32, NORTH_STAR_SHAPES, 4
+    S = sum(h * w for h, w in shapes)
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=8)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    n = lib.zira_msda_bwd_workspace_bytes(B, S, M, D, 4, Q, P)
+    ws = torch.full((n,), 0xAB, dtype=torch.uint8, device=DEV)          # garbage workspace
+    gv = torch.full_like(v, float("nan"))
+    gl = torch.full_like(tloc, float("nan"))
+    ga = torch.full_like(tattn, float("nan"))
+    rc = lib.zira_msda_bwd_f32_ws(tgo.data_ptr(), v.data_ptr(), tsh.data_ptr(), tst.data_ptr(),
+                                  tloc.data_ptr(), tattn.data_ptr(), B, S, M, D, 4, Q, P,
+                                  gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), n,
+                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
+    # with Q=50 most value rows receive nothing and must be exactly zero
+    assert (gv == 0).float().mean() > 0.5

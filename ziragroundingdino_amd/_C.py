@@ -58,6 +58,17 @@ def _dims(value, spatial_shapes, sampling_loc, im2col_step):
     return B, S, M, D, L, Q, P
 
 
+USE_TILED_BACKWARD = True  # False forces the atomic backward (tests compare the two)
+_WS_CACHE = {}
+
+
+def _workspace_bytes(lib, *dims):
+    n = _WS_CACHE.get(dims)
+    if n is None:
+        n = _WS_CACHE[dims] = int(lib.zira_msda_bwd_workspace_bytes(*dims))
+    return n
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -97,10 +108,17 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device):
-        fn = getattr(lib, "zira_msda_bwd_" + _SUFFIX[value.dtype])
-        rc = fn(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+        args = (grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 B, S, M, D, L, Q, P, grad_value.data_ptr(), grad_loc.data_ptr(),
-                grad_attn.data_ptr(), _stream())
+                grad_attn.data_ptr())
+        ws_bytes = _workspace_bytes(lib, B, S, M, D, L, Q, P) if value.dtype == torch.float32 else 0
+        if ws_bytes and USE_TILED_BACKWARD:
+            # atomic-free two-kernel backward; scratch comes from torch's caching allocator
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+            rc = lib.zira_msda_bwd_f32_ws(*args, ws.data_ptr(), ws_bytes, _stream())
+        else:
+            fn = getattr(lib, "zira_msda_bwd_" + _SUFFIX[value.dtype])
+            rc = fn(*args, _stream())
     _raise_on(rc, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_attn]

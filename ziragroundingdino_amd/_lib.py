@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("ZIRA_MSDA_LIB") or os.path.join(_HERE, "libzira_msda.
 # every symbol include/zira_msda.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "zira_msda_fwd_f32", "zira_msda_bwd_f32", "zira_msda_fwd_f64", "zira_msda_bwd_f64",
+    "zira_msda_bwd_workspace_bytes", "zira_msda_bwd_f32_ws",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -40,6 +41,10 @@ def load():
         f.argtypes, f.restype = fwd_args, i
         f = getattr(lib, "zira_msda_bwd_" + suffix)
         f.argtypes, f.restype = bwd_args, i
+    lib.zira_msda_bwd_workspace_bytes.argtypes = [i] * 7
+    lib.zira_msda_bwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.zira_msda_bwd_f32_ws.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]
+    lib.zira_msda_bwd_f32_ws.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

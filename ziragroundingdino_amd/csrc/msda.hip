@@ -314,11 +314,6 @@ __device__ __forceinline__ ItemId lean_item(unsigned nitems, unsigned per, FastD
     const unsigned t1 = (t0 + per < nitems) ? t0 + per : nitems;
     ItemId r;
     r.ok = t < t1;
-#if ZIRA_ABLATE == 4
-    r.ok = t < nitems; r.item = t; const unsigned bq = fast_div(t, M); r.m = t - bq * M.d;
-    r.b = fast_div(bq, Q);
-    return r;
-#endif
     const unsigned g = fast_div(t, Q), q = t - g * Q.d;
     r.b = fast_div(g, M);
     r.m = g - r.b * M.d;
@@ -331,6 +326,7 @@ struct Entry {
     unsigned offb;  // BYTE offset of the corner's value row inside the batch element (0 if unused)
     // backward only
     float wb, cx, cy, a, Wf, Hf;
+    unsigned lvl, pix, hw;  // level, pixel index inside the level, pixels in the level
     bool inb;
 };
 
@@ -366,16 +362,15 @@ __device__ __forceinline__ Entry entry_setup(const int64_t *__restrict__ shapes,
     k.inb = valid && y >= 0 && y < hw.x && x >= 0 && x < hw.y;
     k.wb = k.inb ? wy * wx : 0.f;
     k.w = k.wb * a;
-#if ZIRA_ABLATE == 5
-    k.offb = k.inb ? ((unsigned)(st + y * hw.y + x) + m * 22223u) * (D * 4u) : 0u;  // pretend [B,M,S,D]
-#else
     k.offb = k.inb ? ((unsigned)(st + y * hw.y + x) * M + m) * (D * 4u) : 0u;
-#endif
     if (kNeedGrad) {
         k.cx = k.inb ? (dx ? wy : -wy) : 0.f;
         k.cy = k.inb ? (dy ? wx : -wx) : 0.f;
         k.a = valid ? a : 0.f;
         k.Wf = Wf; k.Hf = Hf;
+        k.lvl = l;
+        k.pix = (unsigned)(y * hw.y + x);
+        k.hw = (unsigned)(hw.x * hw.y);
     }
     return k;
 }
@@ -440,6 +435,500 @@ __global__ __launch_bounds__(kBlock, 8) void msda_fwd_lean(
     acc.x = dpp_add<0x128>(acc.x); acc.y = dpp_add<0x128>(acc.y);
     acc.z = dpp_add<0x128>(acc.z); acc.w = dpp_add<0x128>(acc.w);
     if (slot == 0) *reinterpret_cast<float4 *>(out + (size_t)id.item * D + cq * 4) = acc;
+}
+
+// Backward, lean path, grad_value by fp32 atomics (used when no workspace is supplied).
+//
+// Gather layout: CQ = D/4 consecutive lanes read one value row, so <grad_out, row> folds with
+// DPP quad permutes / row mirrors inside a 16-lane row.  Each dot product travels back to the
+// lane that owns the (sample, corner) entry with one ds_bpermute; the four corners of a
+// sample are then combined with two more quad permutes.
+template <int CQ>
+__device__ __forceinline__ float sum_over_row_lanes(float x)
+{
+    x = dpp_add<0xB1>(x);                 // quad_perm:[1,0,3,2]   (xor 1)
+    x = dpp_add<0x4E>(x);                 // quad_perm:[2,3,0,1]   (xor 2)
+    if (CQ >= 8) x = dpp_add<0x141>(x);   // row_half_mirror       (xor 4 on quad sums)
+    if (CQ >= 16) x = dpp_add<0x140>(x);  // row_mirror            (xor 8 on octet sums)
+    return x;
+}
+
+// <grad_out row, value row> for the 64 entries of a chunk; entry e's result lands in lane e.
+template <int CQ>
+__device__ __forceinline__ float chunk_dots(const float *__restrict__ vb, const Entry &k,
+                                            float4 g4, unsigned lane)
+{
+    constexpr unsigned SLOTS = 64 / CQ, NI = CQ;
+    const unsigned slot = lane / CQ, cq = lane % CQ;
+    const int bp = (int)(slot * 4);
+    const int back = (int)((lane % SLOTS) * CQ * 4);
+    const int offb_i = (int)k.offb;
+    float mine = 0.f;
+#pragma unroll
+    for (unsigned j = 0; j < NI; ++j) {
+        const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)(j * SLOTS * 4), offb_i);
+        const float4 v = load_row16(vb, oj + cq * 16);
+        float d = v.x * g4.x;
+        d = fmaf(v.y, g4.y, d);
+        d = fmaf(v.z, g4.z, d);
+        d = fmaf(v.w, g4.w, d);
+        d = sum_over_row_lanes<CQ>(d);
+        const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d)));
+        if (lane / SLOTS == j) mine = t;
+    }
+    return k.inb ? mine : 0.f;
+}
+
+// grad_sampling_loc / grad_attn_weight of the chunk's 16 samples from the per-entry dots
+__device__ __forceinline__ void store_sample_grads(const Entry &k, float d, unsigned lane,
+                                                   unsigned s, unsigned LP,
+                                                   float *__restrict__ gl_i,
+                                                   float *__restrict__ ga_i)
+{
+    float ga = k.wb * d, gx = k.cx * d, gy = k.cy * d;
+    ga = dpp_add<0xB1>(ga); gx = dpp_add<0xB1>(gx); gy = dpp_add<0xB1>(gy);
+    ga = dpp_add<0x4E>(ga); gx = dpp_add<0x4E>(gx); gy = dpp_add<0x4E>(gy);
+    if ((lane & 3) == 0 && s < LP) {
+        ga_i[s] = ga;
+        float2 gl;
+        gl.x = k.Wf * k.a * gx;
+        gl.y = k.Hf * k.a * gy;
+        *reinterpret_cast<float2 *>(gl_i + 2 * s) = gl;
+    }
+}
+
+template <int CQR>
+__global__ __launch_bounds__(kBlock, 8) void msda_bwd_lean_atomic(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+    const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv,
+    unsigned LP, FastDiv Qdiv, float invP, unsigned nitems, unsigned per_xcd,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    constexpr unsigned D = 16 * CQR, CQ = 4 * CQR;
+    const unsigned M = Mdiv.d;
+    const ItemId id = lean_item(nitems, per_xcd, Qdiv, Mdiv);
+    if (!id.ok) return;
+    const unsigned lane = threadIdx.x & 63;
+    const size_t boff = (size_t)id.b * S * M * D;
+    const float *vb = value + boff;
+    float *gvb = grad_value + boff;
+    const float *loc_i = loc + (size_t)id.item * LP * 2;
+    const float *att_i = attn + (size_t)id.item * LP;
+    const float *g_i = grad_out + (size_t)id.item * D;
+    float *gl_i = grad_loc + (size_t)id.item * LP * 2;
+    float *ga_i = grad_attn + (size_t)id.item * LP;
+    const float4 g4 = *reinterpret_cast<const float4 *>(g_i + (lane % CQ) * 4);
+
+    for (unsigned s0 = 0; s0 < LP; s0 += 16) {
+        const unsigned s = s0 + (lane >> 2);
+        const Entry k = entry_setup<true>(shapes, start, loc_i, att_i, s, lane & 3, LP, invP, M,
+                                          D, id.m);
+        const float d = chunk_dots<CQ>(vb, k, g4, lane);
+        store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
+
+        // grad_value: whole rows per wave instruction (64/D rows of D floats)
+        constexpr unsigned RPA = 64 / D >= 1 ? 64 / D : 1;
+        const unsigned ch = lane % D, rr = lane / D;
+        const int w_i = __float_as_int(k.w), offb_i = (int)k.offb;
+        if (D <= 64) {
+            const float gch = g_i[ch];
+#pragma unroll 4
+            for (unsigned it = 0; it < 64 / RPA; ++it) {
+                const int a = (int)((it * RPA + rr) * 4);
+                const float wj = __int_as_float(__builtin_amdgcn_ds_bpermute(a, w_i));
+                const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(a, offb_i);
+                if (wj != 0.f)
+                    unsafeAtomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(gvb) + oj) + ch,
+                                    wj * gch);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward without global atomics ("tiled" path): two kernels and a caller-provided workspace.
+//
+// Global fp32 atomics execute at the memory side on MI355X (~1.3 TB/s of added bytes chip
+// wide): the 118 MB of corner rows the north-star shape scatters into grad_value cost ~90 us
+// that way, 5x the rest of the backward.  Instead:
+//
+//   K1 (msda_bwd_items): one 1024-thread block per IPB = 48 consecutive queries of one
+//      (b, m) head.  Every wave handles 3 items: gather + dot products -> grad_sampling_loc /
+//      grad_attn_weight (as in the atomic kernel), and turns each contributing (sample,
+//      corner) into an 8-byte entry {item_in_block:16 | row_in_tile:16, weight}.  grad_value
+//      of head (b, m) is cut into NT = L*T tiles (level l, t-th of T equal pixel ranges);
+//      the block counting-sorts its entries by tile in LDS and writes them as one contiguous
+//      run per tile into its private slice of the workspace, plus a {offset, count}
+//      descriptor per (tile, block).
+//   K2 (msda_bwd_tiles): one block per tile.  The tile's grad_value rows live in LDS
+//      (<= 60 KB); the block walks the runs addressed to it, multiplies grad_out rows by the
+//      entry weights and accumulates with LDS atomics (ds_add_f32), then stores every row
+//      of the tile exactly once with plain 16-byte stores.
+//
+// grad_value is therefore written once, never zero-filled and never touched by a global
+// atomic; there is no capacity limit or overflow path (a block's slice holds all of its
+// IPB*LP*4 possible entries).  Precondition (as in the reference module,
+// ms_deform_attn.py:284): the levels tile [0, S) exactly.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned kK1Waves = 16, kK1Threads = kK1Waves * 64;
+constexpr unsigned kItemsPerWave = 3, kIPB = kK1Waves * kItemsPerWave;
+constexpr unsigned kK2Threads = 512;
+constexpr unsigned kInvalidEntry = 0xFFFFFFFFu;
+
+struct TilePlan {
+    unsigned T;        // tiles per level
+    unsigned NT;       // tiles per head = L * T
+    unsigned nblk;     // K1 blocks per head = ceil(Q / kIPB)
+    unsigned chunks;   // 16-sample chunks per item = ceil(LP / 16)
+    unsigned eblk;     // entry slots per K1 block = kIPB * chunks * 64
+    unsigned rows;     // LDS rows per tile (upper bound: ceil(S / T))
+};
+
+// block-granular head-major placement: virtual block id for (XCD = bid & 7, index = bid >> 3)
+__device__ __forceinline__ bool xcd_chunk_block(unsigned nvirt, unsigned per, unsigned &vb)
+{
+    const unsigned xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    vb = xcd * per + idx;
+    return idx < per && vb < nvirt;
+}
+
+// pixels per tile of a level with hw pixels: ceil(hw / T)
+__device__ __forceinline__ unsigned tile_span(unsigned hw, FastDiv T)
+{
+    return fast_div(hw + T.d - 1, T);
+}
+
+template <int CQR>
+__global__ __launch_bounds__(kK1Threads, 8) void msda_bwd_items(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+    const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv,
+    unsigned LP, float invP, unsigned Q, FastDiv nblkdiv, unsigned nvirt, unsigned per_xcd,
+    FastDiv Tdiv, TilePlan plan, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
+    unsigned *__restrict__ desc, uint2 *__restrict__ region)
+{
+    constexpr unsigned D = 16 * CQR, CQ = 4 * CQR;
+    extern __shared__ unsigned lds_k1[];
+    unsigned *hist = lds_k1;                    // [NT]   counts, later exclusive offsets
+    unsigned *stag = lds_k1 + plan.NT;          // [eblk][3] key, weight, (tile << 16 | rank)
+    unsigned *sorted = stag + plan.eblk * 3;    // [eblk][2] key, weight in tile order
+
+    unsigned vblk;
+    if (!xcd_chunk_block(nvirt, per_xcd, vblk)) return;  // block-uniform
+    const unsigned M = Mdiv.d;
+    const unsigned g = fast_div(vblk, nblkdiv), blk = vblk - g * nblkdiv.d;
+    const unsigned b = fast_div(g, Mdiv), m = g - b * M;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const float *vb = value + (size_t)b * S * M * D;
+
+    for (unsigned i = threadIdx.x; i < plan.NT; i += kK1Threads) hist[i] = 0;
+    __syncthreads();
+
+    for (unsigned it = 0; it < kItemsPerWave; ++it) {
+        const unsigned item_local = it * kK1Waves + wave;
+        const unsigned q = blk * kIPB + item_local;
+        unsigned *st_i = stag + (size_t)(item_local * plan.chunks) * 64 * 3;
+        if (q >= Q) {  // wave-uniform: no such query, mark the slots empty
+            for (unsigned ch = 0; ch < plan.chunks; ++ch) st_i[(ch * 64 + lane) * 3 + 2] = kInvalidEntry;
+            continue;
+        }
+        const unsigned item = (b * Q + q) * M + m;
+        const float *loc_i = loc + (size_t)item * LP * 2;
+        const float *att_i = attn + (size_t)item * LP;
+        const float *g_i = grad_out + (size_t)item * D;
+        float *gl_i = grad_loc + (size_t)item * LP * 2;
+        float *ga_i = grad_attn + (size_t)item * LP;
+        const float4 g4 = *reinterpret_cast<const float4 *>(g_i + (lane % CQ) * 4);
+        for (unsigned ch = 0; ch < plan.chunks; ++ch) {
+            const unsigned s = ch * 16 + (lane >> 2);
+            const Entry k = entry_setup<true>(shapes, start, loc_i, att_i, s, lane & 3, LP, invP,
+                                              M, D, m);
+            const float d = chunk_dots<CQ>(vb, k, g4, lane);
+            store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
+
+            unsigned tr = kInvalidEntry, key = 0;
+            if (k.inb && k.w != 0.f) {
+                const unsigned span = tile_span(k.hw, Tdiv);
+                // t = pix / span: float estimate, then exact fix-up
+                unsigned t = (unsigned)(((float)k.pix + 0.5f) * __builtin_amdgcn_rcpf((float)span));
+                if (t * span > k.pix) --t;
+                else if ((t + 1) * span <= k.pix) ++t;
+                const unsigned tile = k.lvl * plan.T + t;
+                const unsigned rank = atomicAdd(&hist[tile], 1u);
+                key = (item_local << 16) | (k.pix - t * span);
+                tr = (tile << 16) | rank;
+            }
+            unsigned *e = st_i + (ch * 64 + lane) * 3;
+            e[0] = key;
+            e[1] = __float_as_uint(k.w);
+            e[2] = tr;
+        }
+    }
+    __syncthreads();
+
+    // exclusive scan of the tile histogram (NT <= kK1Threads): per-wave inclusive scan with
+    // DPP-free shuffles (runs once per block), wave totals through LDS
+    __shared__ unsigned wave_tot[kK1Waves];
+    const unsigned n_mine = threadIdx.x < plan.NT ? hist[threadIdx.x] : 0u;
+    unsigned incl = n_mine;
+#pragma unroll
+    for (unsigned dlt = 1; dlt < 64; dlt <<= 1) {
+        const unsigned o = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0, total = 0;
+#pragma unroll
+    for (unsigned w = 0; w < kK1Waves; ++w) {
+        const unsigned tot = wave_tot[w];
+        if (w < wave) wbase += tot;
+        total += tot;
+    }
+    const unsigned excl = wbase + incl - n_mine;
+    if (threadIdx.x < plan.NT) {
+        hist[threadIdx.x] = excl;
+        desc[((size_t)g * plan.NT + threadIdx.x) * plan.nblk + blk] = (excl << 16) | n_mine;
+    }
+    __syncthreads();
+
+    for (unsigned i = threadIdx.x; i < plan.eblk; i += kK1Threads) {
+        const unsigned tr = stag[i * 3 + 2];
+        if (tr != kInvalidEntry) {
+            const unsigned dst = hist[tr >> 16] + (tr & 0xffffu);
+            sorted[dst * 2] = stag[i * 3];
+            sorted[dst * 2 + 1] = stag[i * 3 + 1];
+        }
+    }
+    __syncthreads();
+    uint2 *out = region + (size_t)vblk * plan.eblk;
+    const uint2 *src = reinterpret_cast<const uint2 *>(sorted);
+    for (unsigned i = threadIdx.x; i < total; i += kK1Threads) out[i] = src[i];
+}
+
+// ---- K2 helpers -------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x)
+{
+    return __builtin_amdgcn_update_dpp(0u, x, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float4 dpp_f4(float4 v)
+{
+    float4 r;
+    r.x = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v.x)));
+    r.y = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v.y)));
+    r.z = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v.z)));
+    r.w = __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v.w)));
+    return r;
+}
+__device__ __forceinline__ void add4(float4 &a, const float4 &b)
+{
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+
+// exclusive prefix sum of one value per thread over the block (kK2Threads threads);
+// returns the block total through `total`.  `scratch` holds kK2Threads/64 words.
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *scratch,
+                                                         unsigned &total)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();  // scratch may still be read from a previous scan
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    total = 0;
+#pragma unroll
+    for (unsigned w = 0; w < kK2Threads / 64; ++w) {
+        const unsigned t = scratch[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    return base + incl - v;
+}
+
+// K2: one block per grad_value tile (head (b, m), level l, pixel range).  The tile's entries
+// (runs written by K1, one per K1 block) are pulled into LDS in batches of `cap`, counting-
+// sorted by tile row, and every wave reduces the rows it owns (a fixed contiguous row range)
+// in registers: one wave instruction fetches the grad_out rows of NSLOT = 256/D entries
+// (D*4 contiguous bytes each, 16 B per lane), a segmented DPP scan folds neighbouring entries
+// of the same row, and each finished row is stored once with plain 16-byte stores.  No atomics
+// on grad_value anywhere; rows without entries are stored as zeros; rows whose entries span
+// several batches are read-modify-written by their owning wave only.
+template <int D>
+__global__ __launch_bounds__(kK2Threads) void msda_bwd_tiles(
+    const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
+    unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, TilePlan plan, unsigned cap,
+    const unsigned *__restrict__ desc, const uint2 *__restrict__ region,
+    float *__restrict__ grad_value)
+{
+    constexpr unsigned NSLOT = 256 / D;  // entries per wave instruction
+    constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
+    extern __shared__ unsigned lds_k2[];
+    const unsigned R = plan.rows;
+    unsigned *rowcnt = lds_k2;               // [R]
+    unsigned *rowbase = rowcnt + R;          // [R + 1]
+    unsigned *pre = rowbase + R + 1;         // [nblk + 1] exclusive prefix of the run lengths
+    unsigned *scratch = pre + plan.nblk + 1; // [8]
+    unsigned *ents = scratch + 8;            // [cap][3]  (q << 12 | row), weight, rank in row
+    unsigned *sorted = ents + cap * 3;       // [cap][2]  (q << 12 | row), weight -- row order
+
+    unsigned vb2;
+    if (!xcd_chunk_block(nvirt, per_xcd, vb2)) return;
+    const unsigned M = Mdiv.d;
+    const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
+    const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
+    const unsigned b = fast_div(g, Mdiv), m = g - b * M;
+    const unsigned hw = (unsigned)shapes[2 * l] * (unsigned)shapes[2 * l + 1];
+    const unsigned st = (unsigned)start[l];
+    const unsigned span = tile_span(hw, Tdiv);
+    const unsigned p0 = t * span;
+    if (p0 >= hw) return;  // block-uniform: tile past the end of a small level
+    const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
+
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned slot = lane % NSLOT, cq = lane / NSLOT;
+    const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
+    float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
+    const size_t row_stride = (size_t)M * D;
+
+    // run-length prefix over the K1 blocks of this head
+    const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
+    unsigned N = 0;
+    for (unsigned c0 = 0; c0 < plan.nblk; c0 += kK2Threads) {
+        const unsigned i = c0 + threadIdx.x;
+        const unsigned n = i < plan.nblk ? (dsc[i] & 0xffffu) : 0u;
+        unsigned tot;
+        const unsigned ex = block_exclusive_scan(n, scratch, tot);
+        if (i < plan.nblk) pre[i] = N + ex;
+        N += tot;
+    }
+    if (threadIdx.x == 0) pre[plan.nblk] = N;
+
+    // rows owned by this wave (same split in every batch)
+    const unsigned r0 = rows * wave / (kK2Threads / 64), r1 = rows * (wave + 1) / (kK2Threads / 64);
+
+    for (unsigned e_lo = 0; e_lo == 0 || e_lo < N; e_lo += cap) {
+        const bool first = e_lo == 0;
+        const unsigned nb = (N - e_lo < cap) ? N - e_lo : cap;
+        for (unsigned i = threadIdx.x; i < rows; i += kK2Threads) rowcnt[i] = 0;
+        __syncthreads();  // also orders `pre` before its first use
+        for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
+            const unsigned e = e_lo + i;
+            unsigned lo = 0, hi = plan.nblk;  // largest blk with pre[blk] <= e
+            while (hi - lo > 1) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (pre[mid] <= e) lo = mid; else hi = mid;
+            }
+            const uint2 en = region[(size_t)(g * plan.nblk + lo) * plan.eblk + (dsc[lo] >> 16) + (e - pre[lo])];
+            const unsigned row = en.x & 0xffffu;
+            const unsigned q = lo * kIPB + (en.x >> 16);
+            ents[i * 3] = (q << 12) | row;
+            ents[i * 3 + 1] = en.y;
+            ents[i * 3 + 2] = atomicAdd(&rowcnt[row], 1u);
+        }
+        __syncthreads();
+        {
+            unsigned tot;
+            const unsigned c = threadIdx.x < rows ? rowcnt[threadIdx.x] : 0u;
+            const unsigned ex = block_exclusive_scan(c, scratch, tot);
+            if (threadIdx.x < rows) rowbase[threadIdx.x] = ex;
+            if (threadIdx.x == 0) rowbase[rows] = tot;
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
+            const unsigned key = ents[i * 3];
+            const unsigned dst = rowbase[key & 0xfffu] + ents[i * 3 + 2];
+            sorted[dst * 2] = key;
+            sorted[dst * 2 + 1] = ents[i * 3 + 1];
+        }
+        __syncthreads();
+
+        // ---- per-wave row sums -------------------------------------------------------------
+        if (first) {  // rows nobody contributes to (in this batch) start as zeros
+            for (unsigned r = r0 + slot; r < r1; r += NSLOT)
+                if (rowcnt[r] == 0)
+                    *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const unsigned e0 = rowbase[r0], e1 = rowbase[r1];
+        unsigned carry_row = kInvalidRow;
+        float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (unsigned base = e0; base < e1; base += NSLOT) {
+            const unsigned e = base + slot;
+            const bool valid = e < e1;
+            unsigned row = kInvalidRow;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                const unsigned key = sorted[e * 2];
+                const float w = __uint_as_float(sorted[e * 2 + 1]);
+                row = key & 0xfffu;
+                const float4 gq = *reinterpret_cast<const float4 *>(g_bm + (size_t)(key >> 12) * row_stride);
+                val = make_float4(w * gq.x, w * gq.y, w * gq.z, w * gq.w);
+            }
+            if (carry_row != kInvalidRow) {  // wave-uniform
+                const unsigned row_first = __builtin_amdgcn_readfirstlane(row);
+                if (row_first == carry_row) {
+                    if (slot == 0) add4(val, carry);
+                } else if (slot == 0) {
+                    float *p = gv_t + carry_row * row_stride;
+                    if (!first) add4(carry, *reinterpret_cast<const float4 *>(p));
+                    *reinterpret_cast<float4 *>(p) = carry;
+                }
+            }
+            // segmented inclusive scan over the NSLOT adjacent lanes (entries are row-sorted)
+            {
+                const unsigned nr = dpp_u32<0x111>(row);  // row_shr:1
+                const float4 nv = dpp_f4<0x111>(val);
+                if (slot >= 1 && nr == row) add4(val, nv);
+            }
+            if (NSLOT > 2) {
+                const unsigned nr = dpp_u32<0x112>(row);
+                const float4 nv = dpp_f4<0x112>(val);
+                if (slot >= 2 && nr == row) add4(val, nv);
+            }
+            if (NSLOT > 4) {
+                const unsigned nr = dpp_u32<0x114>(row);
+                const float4 nv = dpp_f4<0x114>(val);
+                if (slot >= 4 && nr == row) add4(val, nv);
+            }
+            if (NSLOT > 8) {
+                const unsigned nr = dpp_u32<0x118>(row);
+                const float4 nv = dpp_f4<0x118>(val);
+                if (slot >= 8 && nr == row) add4(val, nv);
+            }
+            const unsigned last = ((e1 - base < NSLOT) ? e1 - base : NSLOT) - 1;  // uniform
+            const unsigned next_row = dpp_u32<0x101>(row);  // row_shl:1
+            const bool tail = valid && slot != last && (slot == NSLOT - 1 || next_row != row);
+            if (tail) {
+                float *p = gv_t + row * row_stride;
+                if (!first) add4(val, *reinterpret_cast<const float4 *>(p));
+                *reinterpret_cast<float4 *>(p) = val;
+            }
+            // the last entry's running sum travels to the next batch of entries
+            carry_row = __builtin_amdgcn_readlane(row, last);
+            const int src = (int)((cq * NSLOT + last) * 4);
+            carry.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.x)));
+            carry.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.y)));
+            carry.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.z)));
+            carry.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.w)));
+        }
+        if (carry_row != kInvalidRow && slot == 0) {
+            float *p = gv_t + carry_row * row_stride;
+            if (!first) add4(carry, *reinterpret_cast<const float4 *>(p));
+            *reinterpret_cast<float4 *>(p) = carry;
+        }
+        __syncthreads();  // LDS is reused by the next batch
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -641,6 +1130,20 @@ int launch_fwd_lean(const float *value, const int64_t *shapes, const int64_t *st
     return (int)hipGetLastError();
 }
 
+template <int CQR>
+int launch_bwd_lean_atomic(const float *grad_out, const float *value, const int64_t *shapes,
+                           const int64_t *start, const float *loc, const float *attn, int B, int S,
+                           int M, int L, int Q, int P, float *gv, float *gl, float *ga,
+                           hipStream_t st)
+{
+    const unsigned nitems = (unsigned)B * Q * M;
+    hipLaunchKernelGGL(msda_bwd_lean_atomic<CQR>, dim3(head_major_grid(nitems)), dim3(kBlock), 0,
+                       st, grad_out, value, shapes, start, loc, attn, (unsigned)S,
+                       make_fast_div((unsigned)M), (unsigned)(L * P), make_fast_div((unsigned)Q),
+                       1.0f / (float)P, nitems, (nitems + 7) >> 3, gv, gl, ga);
+    return (int)hipGetLastError();
+}
+
 template <int LPR>
 int launch_bwd_rows(const float *grad_out, const float *value, const int64_t *shapes,
                     const int64_t *start, const float *loc, const float *attn, int B, int S, int M,
@@ -650,6 +1153,88 @@ int launch_bwd_rows(const float *grad_out, const float *value, const int64_t *sh
     const int grid = head_major_grid(nitems);
     hipLaunchKernelGGL(msda_bwd_rows_atomic<LPR>, dim3(grid), dim3(kBlock), 0, st, grad_out, value,
                        shapes, start, loc, attn, S, M, L, Q, P, nitems, gv, gl, ga);
+    return (int)hipGetLastError();
+}
+
+// ---- tiled backward: plan, workspace layout, launch ---------------------------------------
+
+inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, TilePlan &p)
+{
+    if (!(D == 16 || D == 32 || D == 64) || !lean_ok(B, S, M, D, L, Q, P)) return false;
+    const unsigned LP = (unsigned)L * P;
+    p.chunks = (LP + 15) / 16;
+    p.eblk = kIPB * p.chunks * 64;
+    if (p.eblk >= 65536) return false;
+    unsigned T = ((unsigned)S + kK2Threads - 1) / kK2Threads;  // <= 512 rows per tile
+    // enough tiles to fill the chip (K2 runs one block per tile, 2 blocks per CU)
+    const unsigned heads = (unsigned)B * M;
+    const unsigned want = (1024 + heads * L - 1) / (heads * L);
+    if (T < want) T = want;
+    if (T > (unsigned)S) T = (unsigned)S;
+    if (T < 1) T = 1;
+    p.T = T;
+    p.NT = (unsigned)L * T;
+    if (p.NT > kK1Threads) return false;
+    p.nblk = ((unsigned)Q + kIPB - 1) / kIPB;
+    p.rows = ((unsigned)S + T - 1) / T;
+    if (p.rows > kK2Threads || Q >= (1 << 20)) return false;  // K2: one row per thread, q:20|row:12
+    if (((size_t)p.NT + (size_t)p.eblk * 5) * 4 > 150 * 1024) return false;  // K1 LDS
+    if ((unsigned long long)heads * p.nblk * p.eblk >= (1ull << 32)) return false;
+    return true;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline size_t tile_desc_bytes(const TilePlan &p, int B, int M)
+{
+    return align256((size_t)B * M * p.NT * p.nblk * sizeof(unsigned));
+}
+
+inline size_t tile_workspace_bytes(const TilePlan &p, int B, int M)
+{
+    return tile_desc_bytes(p, B, M) + (size_t)B * M * p.nblk * p.eblk * sizeof(uint2);
+}
+
+template <int CQR>
+int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *value,
+                     const int64_t *shapes, const int64_t *start, const float *loc,
+                     const float *attn, int B, int S, int M, int L, int Q, int P, float *gv,
+                     float *gl, float *ga, void *ws, hipStream_t st)
+{
+    constexpr int D = 16 * CQR;
+    unsigned *desc = reinterpret_cast<unsigned *>(ws);
+    uint2 *region = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(ws) + tile_desc_bytes(p, B, M));
+    const unsigned heads = (unsigned)B * M;
+    const FastDiv Mdiv = make_fast_div((unsigned)M), Tdiv = make_fast_div(p.T);
+
+    const unsigned nv1 = heads * p.nblk, per1 = (nv1 + 7) >> 3;
+    const size_t lds1 = ((size_t)p.NT + (size_t)p.eblk * 5) * 4;
+    if (lds1 > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS (LP > 16 only)
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_items<CQR>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (ea != hipSuccess) return (int)ea;
+    }
+    hipLaunchKernelGGL(msda_bwd_items<CQR>, dim3(per1 * 8), dim3(kK1Threads), lds1, st, grad_out,
+                       value, shapes, start, loc, attn, (unsigned)S, Mdiv, (unsigned)(L * P),
+                       1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk), nv1, per1, Tdiv, p, gl,
+                       ga, desc, region);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+
+    const unsigned nv2 = heads * p.NT, per2 = (nv2 + 7) >> 3;
+    // LDS batch: ~2x the mean number of entries per tile, between 1K and 4K entries
+    const unsigned long long mean = (unsigned long long)Q * L * P * 4 / p.NT;
+    unsigned cap = 1024;
+    while (cap < 4096 && cap < 2 * mean) cap <<= 1;
+    const size_t lds2 = ((size_t)p.rows * 2 + 1 + p.nblk + 1 + 8 + (size_t)cap * 5) * 4;
+    if (lds2 > 64 * 1024) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiles<D>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (ea != hipSuccess) return (int)ea;
+    }
+    hipLaunchKernelGGL(msda_bwd_tiles<D>, dim3(per2 * 8), dim3(kK2Threads), lds2, st, grad_out,
+                       shapes, start, (unsigned)S, Mdiv, (unsigned)Q, nv2, per2, Tdiv,
+                       make_fast_div(p.NT), p, cap, desc, region, gv);
     return (int)hipGetLastError();
 }
 
@@ -725,6 +1310,11 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
                                   gv, gl, ga, st);
     hipError_t e = hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * S * M * D, st);
     if (e != hipSuccess) return (int)e;
+    if (lean_ok(B, S, M, D, L, Q, P)) {
+        if (D == 16) return launch_bwd_lean_atomic<1>(grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
+        if (D == 32) return launch_bwd_lean_atomic<2>(grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
+        if (D == 64) return launch_bwd_lean_atomic<4>(grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
+    }
 #define ZIRA_BWD_CASE(LPR_)                                                                      \
     case LPR_:                                                                                   \
         return launch_bwd_rows<LPR_>(grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, \
@@ -736,6 +1326,33 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
     }
 #undef ZIRA_BWD_CASE
     return ZIRA_MSDA_EINVAL;
+}
+
+size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P)
+{
+    TilePlan p;
+    if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0) return 0;
+    if (!make_tile_plan(B, S, M, D, L, Q, P, p)) return 0;
+    return tile_workspace_bytes(p, B, M);
+}
+
+int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_t *shapes,
+                         const int64_t *start, const float *loc, const float *attn, int B, int S,
+                         int M, int D, int L, int Q, int P, float *gv, float *gl, float *ga,
+                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv ||
+        !gl || !ga)
+        return ZIRA_MSDA_EINVAL;
+    TilePlan p;
+    if (!workspace || !make_tile_plan(B, S, M, D, L, Q, P, p) ||
+        workspace_bytes < tile_workspace_bytes(p, B, M) || ((uintptr_t)workspace & 15))
+        return zira_msda_bwd_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
+                                 gv, gl, ga, stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 16) return launch_bwd_tiled<1>(p, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, workspace, st);
+    if (D == 32) return launch_bwd_tiled<2>(p, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, workspace, st);
+    return launch_bwd_tiled<4>(p, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, workspace, st);
 }
 
 int zira_msda_fwd_f64(const double *value, const int64_t *shapes, const int64_t *start,
