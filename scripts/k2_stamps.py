@@ -1,0 +1,26 @@
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import NORTH_STAR_SHAPES, make_msda_inputs
+from ziragroundingdino_amd import _C, _lib
+lib = _lib.load()
+dev = torch.device("cuda")
+v, sh, st, loc, attn, go = make_msda_inputs(2, 900, 8, 32, NORTH_STAR_SHAPES, 4, 0, dev)
+for _ in range(3):
+    _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+torch.cuda.synchronize()
+n = 8 * 8192
+buf = (ctypes.c_ulonglong * n)()
+lib.zira_dev_read_k2_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.zira_dev_read_k2_stamps(buf, n) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
+a = a[a[:, 0] > 0]
+a = a[a[:, 7] > 0]
+t0 = a[:, 0].min()
+print("blocks with stamps:", len(a), " kernel span (us):", (a[:, 7].max() - t0) / 100.0)
+names = ["start->descprefix", "->pass1", "->rowscan", "->pass2", "->zerofill", "->rowsums", "->barrier"]
+d = np.diff(a, axis=1) / 100.0
+for i, nme in enumerate(names):
+    print("  %-18s mean %7.2f us  p50 %7.2f  max %7.2f" % (nme, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
+print("  block lifetime     mean %7.2f us  max %7.2f" % (((a[:, 7] - a[:, 0]) / 100.0).mean(), ((a[:, 7] - a[:, 0]) / 100.0).max()))
+print("  block start spread (us): p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile((a[:, 0] - t0) / 100.0, [50, 90, 100])))

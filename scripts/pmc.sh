@@ -22,7 +22,9 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
+        import re
+        mm = re.search(r"(msda_\w+(<\d+>)?|__amd_\w+)", r["Kernel_Name"])
+        k = mm.group(1) if mm else r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fh:
     for k, cs in agg.items():

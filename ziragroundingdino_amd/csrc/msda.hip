@@ -571,17 +571,28 @@ __global__ __launch_bounds__(kBlock, 8) void msda_bwd_lean_atomic(
 // IPB*LP*4 possible entries).  Precondition (as in the reference module,
 // ms_deform_attn.py:284): the levels tile [0, S) exactly.
 // ------------------------------------------------------------------------------------------
-constexpr unsigned kK1Waves = 16, kK1Threads = kK1Waves * 64;
-constexpr unsigned kItemsPerWave = 3, kIPB = kK1Waves * kItemsPerWave;
-constexpr unsigned kK2Threads = 512;
+constexpr unsigned kItemsPerWave = 3;  // K1: items per wave; a block has 4 or 16 waves
+#ifndef ZIRA_K2_THREADS
+#define ZIRA_K2_THREADS 256
+#endif
+#ifndef ZIRA_K2_MINWAVES
+#define ZIRA_K2_MINWAVES 4
+#endif
+constexpr unsigned kK2Threads = ZIRA_K2_THREADS;
+constexpr unsigned kMaxTileRows = 4095;
+#ifndef ZIRA_TILE_ENTRIES
+#define ZIRA_TILE_ENTRIES 2048
+#endif
+constexpr unsigned kTargetTileEntries = ZIRA_TILE_ENTRIES;
 constexpr unsigned kInvalidEntry = 0xFFFFFFFFu;
 
 struct TilePlan {
     unsigned T;        // tiles per level
     unsigned NT;       // tiles per head = L * T
-    unsigned nblk;     // K1 blocks per head = ceil(Q / kIPB)
+    unsigned ipb;      // items (queries) per K1 block = waves * kItemsPerWave
+    unsigned nblk;     // K1 blocks per head = ceil(Q / ipb)
     unsigned chunks;   // 16-sample chunks per item = ceil(LP / 16)
-    unsigned eblk;     // entry slots per K1 block = kIPB * chunks * 64
+    unsigned eblk;     // entry slots per K1 block = ipb * chunks * 64
     unsigned rows;     // LDS rows per tile (upper bound: ceil(S / T))
 };
 
@@ -599,8 +610,8 @@ __device__ __forceinline__ unsigned tile_span(unsigned hw, FastDiv T)
     return fast_div(hw + T.d - 1, T);
 }
 
-template <int CQR>
-__global__ __launch_bounds__(kK1Threads, 8) void msda_bwd_items(
+template <int CQR, unsigned kK1Waves>
+__global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
     const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv,
@@ -609,6 +620,7 @@ __global__ __launch_bounds__(kK1Threads, 8) void msda_bwd_items(
     unsigned *__restrict__ desc, uint2 *__restrict__ region)
 {
     constexpr unsigned D = 16 * CQR, CQ = 4 * CQR;
+    constexpr unsigned kK1Threads = kK1Waves * 64, kIPB = kK1Waves * kItemsPerWave;
     extern __shared__ unsigned lds_k1[];
     unsigned *hist = lds_k1;                    // [NT]   counts, later exclusive offsets
     unsigned *stag = lds_k1 + plan.NT;          // [eblk][3] key, weight, (tile << 16 | rank)
@@ -668,31 +680,36 @@ __global__ __launch_bounds__(kK1Threads, 8) void msda_bwd_items(
     }
     __syncthreads();
 
-    // exclusive scan of the tile histogram (NT <= kK1Threads): per-wave inclusive scan with
-    // DPP-free shuffles (runs once per block), wave totals through LDS
+    // exclusive scan of the tile histogram in chunks of kK1Threads tiles (wave shuffles, wave
+    // totals through LDS); hist[] is overwritten with the offsets, desc gets {offset, count}
     __shared__ unsigned wave_tot[kK1Waves];
-    const unsigned n_mine = threadIdx.x < plan.NT ? hist[threadIdx.x] : 0u;
-    unsigned incl = n_mine;
+    unsigned total = 0;
+    for (unsigned c0 = 0; c0 < plan.NT; c0 += kK1Threads) {
+        const unsigned ti = c0 + threadIdx.x;
+        const unsigned n_mine = ti < plan.NT ? hist[ti] : 0u;
+        unsigned incl = n_mine;
 #pragma unroll
-    for (unsigned dlt = 1; dlt < 64; dlt <<= 1) {
-        const unsigned o = __shfl_up(incl, dlt);
-        if (lane >= dlt) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned wbase = 0, total = 0;
+        for (unsigned dlt = 1; dlt < 64; dlt <<= 1) {
+            const unsigned o = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned wbase = 0, ctot = 0;
 #pragma unroll
-    for (unsigned w = 0; w < kK1Waves; ++w) {
-        const unsigned tot = wave_tot[w];
-        if (w < wave) wbase += tot;
-        total += tot;
+        for (unsigned w = 0; w < kK1Waves; ++w) {
+            const unsigned tot = wave_tot[w];
+            if (w < wave) wbase += tot;
+            ctot += tot;
+        }
+        const unsigned excl = total + wbase + incl - n_mine;
+        if (ti < plan.NT) {
+            hist[ti] = excl;
+            desc[((size_t)g * plan.NT + ti) * plan.nblk + blk] = (excl << 16) | n_mine;
+        }
+        total += ctot;
+        __syncthreads();
     }
-    const unsigned excl = wbase + incl - n_mine;
-    if (threadIdx.x < plan.NT) {
-        hist[threadIdx.x] = excl;
-        desc[((size_t)g * plan.NT + threadIdx.x) * plan.nblk + blk] = (excl << 16) | n_mine;
-    }
-    __syncthreads();
 
     for (unsigned i = threadIdx.x; i < plan.eblk; i += kK1Threads) {
         const unsigned tr = stag[i * 3 + 2];
@@ -755,16 +772,116 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *s
     return base + incl - v;
 }
 
-// K2: one block per grad_value tile (head (b, m), level l, pixel range).  The tile's entries
-// (runs written by K1, one per K1 block) are pulled into LDS in batches of `cap`, counting-
-// sorted by tile row, and every wave reduces the rows it owns (a fixed contiguous row range)
-// in registers: one wave instruction fetches the grad_out rows of NSLOT = 256/D entries
-// (D*4 contiguous bytes each, 16 B per lane), a segmented DPP scan folds neighbouring entries
-// of the same row, and each finished row is stored once with plain 16-byte stores.  No atomics
-// on grad_value anywhere; rows without entries are stored as zeros; rows whose entries span
-// several batches are read-modify-written by their owning wave only.
+// K2: one block per grad_value tile (head (b, m), level l, pixel range).
+//
+// Two earlier versions of this kernel accumulated the tile in LDS: with ds_add_f32 (LDS fp32
+// atomics run at ~2 cycles per LANE on gfx950: 110 of 160 us) and with plain LDS
+// read-modify-writes under a row-ownership scheme (fine per entry, but the 44 KB tile forces
+// 4096 blocks = 5 rounds of a ~12 us dependent-latency chain).  This version keeps no tile at
+// all: the tile's entries (runs written by K1, one per K1 block) are counting-sorted by tile
+// row in LDS, every wave owns a contiguous range of rows, and a row's sum is formed in
+// registers: one wave instruction fetches the grad_out rows of NSLOT = 256/D entries (D*4
+// contiguous bytes each, 16 B per lane), U of them are in flight, a segmented DPP scan folds
+// neighbouring entries of the same row, and each finished row is stored once with plain
+// 16-byte stores.  Rows without entries are stored as zeros.  The dependent memory chain per
+// block is descriptor -> entries -> grad_out rows -> store, and the tile count is chosen so
+// that all blocks are resident at once (one round).
+// When a tile has more than `cap` entries (the LDS batch), later batches read-modify-write
+// the rows they touch; a row is always handled by the same wave, so program order suffices.
+struct RowCarry {
+    unsigned row;
+    float4 val;
+};
+
+template <unsigned NSLOT>
+__device__ __forceinline__ void rowsum_step(unsigned row, float4 val, bool valid, unsigned last,
+                                            unsigned slot, unsigned cq, bool first,
+                                            float *__restrict__ gv_t, size_t row_stride,
+                                            RowCarry &carry)
+{
+    constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
+    if (carry.row != kInvalidRow) {  // wave-uniform
+        const unsigned row_first = __builtin_amdgcn_readfirstlane(row);
+        if (row_first == carry.row) {
+            if (slot == 0) add4(val, carry.val);
+        } else if (slot == 0) {
+            float *p = gv_t + carry.row * row_stride;
+            if (!first) add4(carry.val, *reinterpret_cast<const float4 *>(p));
+            *reinterpret_cast<float4 *>(p) = carry.val;
+        }
+    }
+    // segmented inclusive scan over the NSLOT adjacent lanes (entries are row-sorted)
+    {
+        const unsigned nr = dpp_u32<0x111>(row);  // row_shr:1
+        const float4 nv = dpp_f4<0x111>(val);
+        if (slot >= 1 && nr == row) add4(val, nv);
+    }
+    if (NSLOT > 2) {
+        const unsigned nr = dpp_u32<0x112>(row);
+        const float4 nv = dpp_f4<0x112>(val);
+        if (slot >= 2 && nr == row) add4(val, nv);
+    }
+    if (NSLOT > 4) {
+        const unsigned nr = dpp_u32<0x114>(row);
+        const float4 nv = dpp_f4<0x114>(val);
+        if (slot >= 4 && nr == row) add4(val, nv);
+    }
+    if (NSLOT > 8) {
+        const unsigned nr = dpp_u32<0x118>(row);
+        const float4 nv = dpp_f4<0x118>(val);
+        if (slot >= 8 && nr == row) add4(val, nv);
+    }
+    const unsigned next_row = dpp_u32<0x101>(row);  // row_shl:1
+    const bool tail = valid && slot != last && (slot == NSLOT - 1 || next_row != row);
+    if (tail) {
+        float *p = gv_t + row * row_stride;
+        if (!first) add4(val, *reinterpret_cast<const float4 *>(p));
+        *reinterpret_cast<float4 *>(p) = val;
+    }
+    // The last entry's running sum travels on to the next NSLOT entries.  Only slot 0 ever
+    // consumes it, and lane (cq, 0) sits NSLOT-1 lanes below lane (cq, NSLOT-1) in the same
+    // DPP row, so a full step hands it over with row_shl:(NSLOT-1).  A partial step is the
+    // last one of the wave's range: its tail is stored right away by the lanes that hold it.
+    if (last == NSLOT - 1) {
+        carry.row = __builtin_amdgcn_readlane(row, NSLOT - 1);
+        carry.val = dpp_f4<0x100 + (NSLOT - 1)>(val);
+    } else {
+        carry.row = kInvalidRow;
+        if (slot == last) {
+            float *p = gv_t + row * row_stride;
+            if (!first) add4(val, *reinterpret_cast<const float4 *>(p));
+            *reinterpret_cast<float4 *>(p) = val;
+        }
+    }
+}
+
+// entry e of the tile -> (K1 block, entry) through the run prefix kept in LDS
+__device__ __forceinline__ uint2 fetch_tile_entry(const uint2 *__restrict__ reg_g,
+                                                  const unsigned *pre, const unsigned *runoff,
+                                                  unsigned nblk, unsigned eblk, unsigned e,
+                                                  unsigned &blk)
+{
+    unsigned lo = 0, hi = nblk;  // largest blk with pre[blk] <= e
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (pre[mid] <= e) lo = mid; else hi = mid;
+    }
+    blk = lo;
+    return reg_g[(size_t)lo * eblk + runoff[lo] + (e - pre[lo])];
+}
+
+#if ZIRA_ABLATE == 9  // developer build: per-phase wall-clock stamps of K2 (100 MHz counter)
+__device__ unsigned long long zira_k2_stamps[8 * 8192];
+#define K2_STAMP(i)                                                                         \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) zira_k2_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define K2_STAMP(i)
+#endif
+
 template <int D>
-__global__ __launch_bounds__(kK2Threads) void msda_bwd_tiles(
+__global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
     const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
     unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, TilePlan plan, unsigned cap,
@@ -772,16 +889,20 @@ __global__ __launch_bounds__(kK2Threads) void msda_bwd_tiles(
     float *__restrict__ grad_value)
 {
     constexpr unsigned NSLOT = 256 / D;  // entries per wave instruction
+    constexpr unsigned U = 4;            // wave instructions in flight
+    constexpr unsigned EPT = 4;          // entries a thread keeps in registers between passes
     constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
     extern __shared__ unsigned lds_k2[];
     const unsigned R = plan.rows;
-    unsigned *rowcnt = lds_k2;               // [R]
-    unsigned *rowbase = rowcnt + R;          // [R + 1]
-    unsigned *pre = rowbase + R + 1;         // [nblk + 1] exclusive prefix of the run lengths
-    unsigned *scratch = pre + plan.nblk + 1; // [8]
-    unsigned *ents = scratch + 8;            // [cap][3]  (q << 12 | row), weight, rank in row
-    unsigned *sorted = ents + cap * 3;       // [cap][2]  (q << 12 | row), weight -- row order
+    unsigned *rowcnt = lds_k2;                // [R]      entries per row (this batch)
+    unsigned *rowbase = rowcnt + R;           // [R + 1]  exclusive prefix of rowcnt
+    unsigned *pre = rowbase + R + 1;          // [nblk + 1] exclusive prefix of the run lengths
+    unsigned *runoff = pre + plan.nblk + 1;   // [nblk]   offset of the run inside its K1 slice
+    unsigned *scratch = runoff + plan.nblk;   // [8]
+    uint2 *sorted = reinterpret_cast<uint2 *>(scratch + 8 + ((2 * R + 1 + 2 * plan.nblk + 1) & 1));
+    // sorted[cap]: (q << 12 | row), weight -- in row order
 
+    K2_STAMP(0);
     unsigned vb2;
     if (!xcd_chunk_block(nvirt, per_xcd, vb2)) return;
     const unsigned M = Mdiv.d;
@@ -802,18 +923,20 @@ __global__ __launch_bounds__(kK2Threads) void msda_bwd_tiles(
     float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
     const size_t row_stride = (size_t)M * D;
 
-    // run-length prefix over the K1 blocks of this head
+    // run-length prefix over the K1 blocks of this head (descriptor = offset << 16 | count)
     const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
+    const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
     unsigned N = 0;
     for (unsigned c0 = 0; c0 < plan.nblk; c0 += kK2Threads) {
         const unsigned i = c0 + threadIdx.x;
-        const unsigned n = i < plan.nblk ? (dsc[i] & 0xffffu) : 0u;
+        const unsigned dd = i < plan.nblk ? dsc[i] : 0u;
         unsigned tot;
-        const unsigned ex = block_exclusive_scan(n, scratch, tot);
-        if (i < plan.nblk) pre[i] = N + ex;
+        const unsigned ex = block_exclusive_scan(dd & 0xffffu, scratch, tot);
+        if (i < plan.nblk) { pre[i] = N + ex; runoff[i] = dd >> 16; }
         N += tot;
     }
     if (threadIdx.x == 0) pre[plan.nblk] = N;
+    K2_STAMP(1);
 
     // rows owned by this wave (same split in every batch)
     const unsigned r0 = rows * wave / (kK2Threads / 64), r1 = rows * (wave + 1) / (kK2Threads / 64);
@@ -821,113 +944,119 @@ __global__ __launch_bounds__(kK2Threads) void msda_bwd_tiles(
     for (unsigned e_lo = 0; e_lo == 0 || e_lo < N; e_lo += cap) {
         const bool first = e_lo == 0;
         const unsigned nb = (N - e_lo < cap) ? N - e_lo : cap;
+        const bool in_regs = nb <= EPT * kK2Threads;  // block-uniform
         for (unsigned i = threadIdx.x; i < rows; i += kK2Threads) rowcnt[i] = 0;
-        __syncthreads();  // also orders `pre` before its first use
-        for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
-            const unsigned e = e_lo + i;
-            unsigned lo = 0, hi = plan.nblk;  // largest blk with pre[blk] <= e
-            while (hi - lo > 1) {
-                const unsigned mid = (lo + hi) >> 1;
-                if (pre[mid] <= e) lo = mid; else hi = mid;
+        __syncthreads();  // also orders pre / runoff before their first use
+
+        // pass 1: count entries per row; small batches keep {entry, rank} in registers
+        unsigned keyr[EPT], wr[EPT], rankr[EPT];
+        if (in_regs) {
+#pragma unroll
+            for (unsigned u = 0; u < EPT; ++u) {
+                const unsigned i = threadIdx.x + u * kK2Threads;
+                keyr[u] = kInvalidRow;
+                if (i < nb) {
+                    unsigned blk;
+                    const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                    const unsigned row = en.x & 0xffffu;
+                    keyr[u] = ((blk * plan.ipb + (en.x >> 16)) << 12) | row;
+                    wr[u] = en.y;
+                    rankr[u] = atomicAdd(&rowcnt[row], 1u);
+                }
             }
-            const uint2 en = region[(size_t)(g * plan.nblk + lo) * plan.eblk + (dsc[lo] >> 16) + (e - pre[lo])];
-            const unsigned row = en.x & 0xffffu;
-            const unsigned q = lo * kIPB + (en.x >> 16);
-            ents[i * 3] = (q << 12) | row;
-            ents[i * 3 + 1] = en.y;
-            ents[i * 3 + 2] = atomicAdd(&rowcnt[row], 1u);
+        } else {
+            for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
+                unsigned blk;
+                const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                atomicAdd(&rowcnt[en.x & 0xffffu], 1u);
+            }
         }
         __syncthreads();
-        {
+        K2_STAMP(2);
+        {   // exclusive prefix over the rows: each thread owns `rpt` consecutive rows
+            const unsigned rpt = (rows + kK2Threads - 1) / kK2Threads;
+            const unsigned ra = threadIdx.x * rpt;
+            const unsigned rb = (ra + rpt < rows) ? ra + rpt : rows;
+            unsigned c = 0;
+            for (unsigned r = ra; r < rb; ++r) c += rowcnt[r];
             unsigned tot;
-            const unsigned c = threadIdx.x < rows ? rowcnt[threadIdx.x] : 0u;
-            const unsigned ex = block_exclusive_scan(c, scratch, tot);
-            if (threadIdx.x < rows) rowbase[threadIdx.x] = ex;
+            unsigned ex = block_exclusive_scan(c, scratch, tot);
+            for (unsigned r = ra; r < rb; ++r) {
+                const unsigned n = rowcnt[r];
+                rowbase[r] = ex;
+                if (!in_regs) rowcnt[r] = ex | (n ? 0x80000000u : 0u);  // cursor + "has entries"
+                ex += n;
+            }
             if (threadIdx.x == 0) rowbase[rows] = tot;
         }
         __syncthreads();
-        for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
-            const unsigned key = ents[i * 3];
-            const unsigned dst = rowbase[key & 0xfffu] + ents[i * 3 + 2];
-            sorted[dst * 2] = key;
-            sorted[dst * 2 + 1] = ents[i * 3 + 1];
+        K2_STAMP(3);
+        // pass 2: place entries in row order
+        if (in_regs) {
+#pragma unroll
+            for (unsigned u = 0; u < EPT; ++u)
+                if (keyr[u] != kInvalidRow)
+                    sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
+        } else {
+            for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
+                unsigned blk;
+                const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                const unsigned row = en.x & 0xffffu;
+                const unsigned dst = atomicAdd(&rowcnt[row], 1u) & 0x7fffffffu;
+                sorted[dst] = make_uint2(((blk * plan.ipb + (en.x >> 16)) << 12) | row, en.y);
+            }
         }
         __syncthreads();
+        K2_STAMP(4);
 
         // ---- per-wave row sums -------------------------------------------------------------
         if (first) {  // rows nobody contributes to (in this batch) start as zeros
             for (unsigned r = r0 + slot; r < r1; r += NSLOT)
-                if (rowcnt[r] == 0)
+                if (rowbase[r + 1] == rowbase[r])
                     *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        K2_STAMP(5);
         const unsigned e0 = rowbase[r0], e1 = rowbase[r1];
-        unsigned carry_row = kInvalidRow;
-        float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (unsigned base = e0; base < e1; base += NSLOT) {
-            const unsigned e = base + slot;
-            const bool valid = e < e1;
-            unsigned row = kInvalidRow;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) {
-                const unsigned key = sorted[e * 2];
-                const float w = __uint_as_float(sorted[e * 2 + 1]);
-                row = key & 0xfffu;
-                const float4 gq = *reinterpret_cast<const float4 *>(g_bm + (size_t)(key >> 12) * row_stride);
-                val = make_float4(w * gq.x, w * gq.y, w * gq.z, w * gq.w);
-            }
-            if (carry_row != kInvalidRow) {  // wave-uniform
-                const unsigned row_first = __builtin_amdgcn_readfirstlane(row);
-                if (row_first == carry_row) {
-                    if (slot == 0) add4(val, carry);
-                } else if (slot == 0) {
-                    float *p = gv_t + carry_row * row_stride;
-                    if (!first) add4(carry, *reinterpret_cast<const float4 *>(p));
-                    *reinterpret_cast<float4 *>(p) = carry;
+        RowCarry carry;
+        carry.row = kInvalidRow;
+        carry.val = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (unsigned base = e0; base < e1; base += U * NSLOT) {
+            unsigned rowu[U];
+            float4 valu[U];
+            float wu[U];
+#pragma unroll
+            for (unsigned u = 0; u < U; ++u) {  // issue all loads first
+                const unsigned e = base + u * NSLOT + slot;
+                rowu[u] = kInvalidRow;
+                wu[u] = 0.f;
+                valu[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < e1) {
+                    const uint2 en = sorted[e];
+                    rowu[u] = en.x & 0xfffu;
+                    wu[u] = __uint_as_float(en.y);
+                    valu[u] = *reinterpret_cast<const float4 *>(g_bm + (size_t)(en.x >> 12) * row_stride);
                 }
             }
-            // segmented inclusive scan over the NSLOT adjacent lanes (entries are row-sorted)
-            {
-                const unsigned nr = dpp_u32<0x111>(row);  // row_shr:1
-                const float4 nv = dpp_f4<0x111>(val);
-                if (slot >= 1 && nr == row) add4(val, nv);
+#pragma unroll
+            for (unsigned u = 0; u < U; ++u) {
+                const unsigned b0 = base + u * NSLOT;
+                if (b0 < e1) {  // wave-uniform
+                    const unsigned last = ((e1 - b0 < NSLOT) ? e1 - b0 : NSLOT) - 1;
+                    const float4 v = make_float4(wu[u] * valu[u].x, wu[u] * valu[u].y,
+                                                 wu[u] * valu[u].z, wu[u] * valu[u].w);
+                    rowsum_step<NSLOT>(rowu[u], v, rowu[u] != kInvalidRow, last, slot, cq, first,
+                                       gv_t, row_stride, carry);
+                }
             }
-            if (NSLOT > 2) {
-                const unsigned nr = dpp_u32<0x112>(row);
-                const float4 nv = dpp_f4<0x112>(val);
-                if (slot >= 2 && nr == row) add4(val, nv);
-            }
-            if (NSLOT > 4) {
-                const unsigned nr = dpp_u32<0x114>(row);
-                const float4 nv = dpp_f4<0x114>(val);
-                if (slot >= 4 && nr == row) add4(val, nv);
-            }
-            if (NSLOT > 8) {
-                const unsigned nr = dpp_u32<0x118>(row);
-                const float4 nv = dpp_f4<0x118>(val);
-                if (slot >= 8 && nr == row) add4(val, nv);
-            }
-            const unsigned last = ((e1 - base < NSLOT) ? e1 - base : NSLOT) - 1;  // uniform
-            const unsigned next_row = dpp_u32<0x101>(row);  // row_shl:1
-            const bool tail = valid && slot != last && (slot == NSLOT - 1 || next_row != row);
-            if (tail) {
-                float *p = gv_t + row * row_stride;
-                if (!first) add4(val, *reinterpret_cast<const float4 *>(p));
-                *reinterpret_cast<float4 *>(p) = val;
-            }
-            // the last entry's running sum travels to the next batch of entries
-            carry_row = __builtin_amdgcn_readlane(row, last);
-            const int src = (int)((cq * NSLOT + last) * 4);
-            carry.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.x)));
-            carry.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.y)));
-            carry.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.z)));
-            carry.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(val.w)));
         }
-        if (carry_row != kInvalidRow && slot == 0) {
-            float *p = gv_t + carry_row * row_stride;
-            if (!first) add4(carry, *reinterpret_cast<const float4 *>(p));
-            *reinterpret_cast<float4 *>(p) = carry;
+        if (carry.row != kInvalidRow && slot == 0) {
+            float *p = gv_t + carry.row * row_stride;
+            if (!first) add4(carry.val, *reinterpret_cast<const float4 *>(p));
+            *reinterpret_cast<float4 *>(p) = carry.val;
         }
+        K2_STAMP(6);
         __syncthreads();  // LDS is reused by the next batch
+        K2_STAMP(7);
     }
 }
 
@@ -1163,21 +1292,32 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     if (!(D == 16 || D == 32 || D == 64) || !lean_ok(B, S, M, D, L, Q, P)) return false;
     const unsigned LP = (unsigned)L * P;
     p.chunks = (LP + 15) / 16;
-    p.eblk = kIPB * p.chunks * 64;
-    if (p.eblk >= 65536) return false;
-    unsigned T = ((unsigned)S + kK2Threads - 1) / kK2Threads;  // <= 512 rows per tile
-    // enough tiles to fill the chip (K2 runs one block per tile, 2 blocks per CU)
+    // sparse calls (decoder: a few hundred queries) use small K1 blocks for balance across the
+    // chip; dense calls use 16-wave blocks so that the (tile x block) run table stays small
     const unsigned heads = (unsigned)B * M;
+    const bool dense = (unsigned long long)heads * Q >= 16 * 4096;
+    p.ipb = (dense ? 16u : 4u) * kItemsPerWave;
+    p.eblk = p.ipb * p.chunks * 64;
+    if (p.eblk >= 65536) return false;
+    // K2 runs one block per tile, 4 blocks per CU: aim for one full round of the chip (the
+    // per-tile critical path is a chain of dependent memory round trips, so rounds cost), with
+    // at most kMaxTileRows rows per tile (12-bit row field of the sorted entries)
+    unsigned T = ((unsigned)S + kMaxTileRows - 1) / kMaxTileRows;
     const unsigned want = (1024 + heads * L - 1) / (heads * L);
     if (T < want) T = want;
+    // dense calls (encoder: every pixel is a query): keep ~kTargetTileEntries entries per tile so
+    // that one LDS batch holds a tile and the per-tile sort stays cheap
+    const unsigned long long per_level = (unsigned long long)Q * P * 4;
+    const unsigned t_dense = (unsigned)((per_level + kTargetTileEntries - 1) / kTargetTileEntries);
+    if (T < t_dense) T = t_dense;
     if (T > (unsigned)S) T = (unsigned)S;
     if (T < 1) T = 1;
     p.T = T;
     p.NT = (unsigned)L * T;
-    if (p.NT > kK1Threads) return false;
-    p.nblk = ((unsigned)Q + kIPB - 1) / kIPB;
+    if (p.NT > 4096) return false;
+    p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
     p.rows = ((unsigned)S + T - 1) / T;
-    if (p.rows > kK2Threads || Q >= (1 << 20)) return false;  // K2: one row per thread, q:20|row:12
+    if (p.rows > kMaxTileRows || Q >= (1 << 20)) return false;  // sorted entry = q:20 | row:12
     if (((size_t)p.NT + (size_t)p.eblk * 5) * 4 > 150 * 1024) return false;  // K1 LDS
     if ((unsigned long long)heads * p.nblk * p.eblk >= (1ull << 32)) return false;
     return true;
@@ -1209,15 +1349,23 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
 
     const unsigned nv1 = heads * p.nblk, per1 = (nv1 + 7) >> 3;
     const size_t lds1 = ((size_t)p.NT + (size_t)p.eblk * 5) * 4;
+    const void *k1 = p.ipb == 16 * kItemsPerWave
+                         ? reinterpret_cast<const void *>(&msda_bwd_items<CQR, 16>)
+                         : reinterpret_cast<const void *>(&msda_bwd_items<CQR, 4>);
     if (lds1 > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS (LP > 16 only)
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_items<CQR>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipError_t ea = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (ea != hipSuccess) return (int)ea;
     }
-    hipLaunchKernelGGL(msda_bwd_items<CQR>, dim3(per1 * 8), dim3(kK1Threads), lds1, st, grad_out,
-                       value, shapes, start, loc, attn, (unsigned)S, Mdiv, (unsigned)(L * P),
-                       1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk), nv1, per1, Tdiv, p, gl,
-                       ga, desc, region);
+    if (p.ipb == 16 * kItemsPerWave)
+        hipLaunchKernelGGL((msda_bwd_items<CQR, 16>), dim3(per1 * 8), dim3(16 * 64), lds1, st,
+                           grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
+                           (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
+                           nv1, per1, Tdiv, p, gl, ga, desc, region);
+    else
+        hipLaunchKernelGGL((msda_bwd_items<CQR, 4>), dim3(per1 * 8), dim3(4 * 64), lds1, st,
+                           grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
+                           (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
+                           nv1, per1, Tdiv, p, gl, ga, desc, region);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
 
@@ -1225,8 +1373,8 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     // LDS batch: ~2x the mean number of entries per tile, between 1K and 4K entries
     const unsigned long long mean = (unsigned long long)Q * L * P * 4 / p.NT;
     unsigned cap = 1024;
-    while (cap < 4096 && cap < 2 * mean) cap <<= 1;
-    const size_t lds2 = ((size_t)p.rows * 2 + 1 + p.nblk + 1 + 8 + (size_t)cap * 5) * 4;
+    while (cap < 8192 && cap < 2 * mean) cap <<= 1;
+    const size_t lds2 = ((size_t)p.rows * 2 + 1 + 2 * p.nblk + 1 + 8 + 1 + (size_t)cap * 2) * 4;
     if (lds2 > 64 * 1024) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiles<D>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1376,6 +1524,13 @@ int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t
     return bwd_generic<double>(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P, gv,
                                gl, ga, (hipStream_t)stream);
 }
+
+#if ZIRA_ABLATE == 9
+int zira_dev_read_k2_stamps(unsigned long long *host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(zira_k2_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 const char *zira_msda_version(void) { return "zira_msda 0.1 gfx950"; }
 
