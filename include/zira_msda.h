@@ -93,6 +93,27 @@ int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t
                       double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                       void *stream);
 
+/* ---- ZiRa reparameterizable side branch (RSB): fused epilogue ---------------------------
+ * Replaces the elementwise / reduction tail of RepZeroConv2d.forward and
+ * RepZeroLinear.forward in training mode (reference
+ * groundingdino_dual_zero_rep_branch.py:87-96 and :119-128):
+ *     out  = scaling * y_branch + y_twin
+ *     loss = mean(smooth_l1(scaling * y_branch, 0)) + mean(smooth_l1(out, 0))     (beta = 1)
+ * y_branch = F(x; W, b) and y_twin = F(x; W_f, b_f) are produced by the caller's GEMM /
+ * convolution library.  All pointers are device pointers to n contiguous floats (16-byte
+ * aligned), `scaling` / `loss` / `g_scaling` / `grad_loss` point to one float on the device,
+ * `workspace` to zira_rsb_workspace_floats(n) floats of scratch (no initialisation needed).
+ * The backward returns d/dy_branch, d/dy_twin and d/dscaling given grad_out (d/dout, may be
+ * NULL = zeros) and grad_loss (d/dloss, may be NULL = 0).  Deterministic reductions. */
+size_t zira_rsb_workspace_floats(size_t n);
+
+int zira_rsb_fwd_f32(const float *y_branch, const float *y_twin, const float *scaling, size_t n,
+                     float *out, float *loss, float *workspace, void *stream);
+
+int zira_rsb_bwd_f32(const float *y_branch, const float *y_twin, const float *scaling,
+                     const float *grad_out, const float *grad_loss, size_t n, float *g_branch,
+                     float *g_twin, float *g_scaling, float *workspace, void *stream);
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

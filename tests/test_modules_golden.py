@@ -1,0 +1,302 @@
+"""Modules around the MSDA op against golden vectors produced by the reference itself
+(tests/golden/gen_modules_golden.py -> mod_*.pt).
+
+Every case runs twice: on the CPU (host logic; the native MSDA entry points are replaced by the
+CPU oracle through a test-only monkeypatch of ``ziragroundingdino_amd._C`` -- the product has
+no such path) and, marked ``gpu``, on the MI355X with the real HIP kernels.
+Tolerances: fp32 1e-4 relative to the tensor scale for module outputs / gradients (north_star:
+1e-3); index and mask results (text masks, matcher assignments, two-stage top-k) bit-exact.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from seeded import fill_by_name_  # noqa: E402
+
+import ziragroundingdino_amd as z  # noqa: E402
+from ziragroundingdino_amd import _C, criterion, matcher, rsb, text_masks, transformer, utils  # noqa: E402
+
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+TOL = 1e-4
+
+
+def load(name):
+    return torch.load(os.path.join(GOLDEN, "mod_%s.pt" % name), weights_only=False)
+
+
+def to(obj, dev):
+    if torch.is_tensor(obj):
+        return obj.to(dev)
+    if isinstance(obj, dict):
+        return {k: to(v, dev) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to(v, dev) for v in obj)
+    return obj
+
+
+def close(got, want, tol=TOL, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got), fin), what + ": inf/nan pattern differs"
+    assert torch.equal(got[~fin], want[~fin]), what
+    scale = max(1.0, float(want[fin].abs().max())) if fin.any() else 1.0
+    err = float((got[fin] - want[fin]).abs().max()) / scale if fin.any() else 0.0
+    assert err <= tol, "%s: max err %.3e (scaled) > %.1e" % (what, err, tol)
+
+
+@pytest.fixture
+def msda_backend(request, monkeypatch, oracle):
+    """device string; on 'cpu' the two native entry points are served by the oracle."""
+    dev = request.param
+    if dev == "cpu":
+        def fwd(value, shapes, start, loc, attn, step):
+            out = oracle.msda_forward(value.detach().numpy(), shapes.numpy(), start.numpy(),
+                                      loc.detach().numpy(), attn.detach().numpy())
+            return torch.from_numpy(out)
+
+        def bwd(value, shapes, start, loc, attn, go, step):
+            g = oracle.msda_backward(go.detach().numpy(), value.detach().numpy(), shapes.numpy(),
+                                     start.numpy(), loc.detach().numpy(), attn.detach().numpy())
+            return [torch.from_numpy(x) for x in g]
+
+        monkeypatch.setattr(_C, "ms_deform_attn_forward", fwd)
+        monkeypatch.setattr(_C, "ms_deform_attn_backward", bwd)
+    return dev
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
+@pytest.mark.parametrize("refdim", [2, 4])
+def test_msda_module(msda_backend, refdim):
+    dev = msda_backend
+    g = to(load("msda_module_ref%d" % refdim), dev)
+    mod = z.MultiScaleDeformableAttention(embed_dim=64, num_heads=4, num_levels=3, num_points=2,
+                                          batch_first=True)
+    # deterministic part of init_weights(): offsets grid, zero attention weights/bias
+    for k in ("sampling_offsets.weight", "sampling_offsets.bias", "attention_weights.weight",
+              "attention_weights.bias", "value_proj.bias", "output_proj.bias"):
+        close(mod.state_dict()[k], g["init_state"][k], 1e-6, "init " + k)
+    mod.load_state_dict(g["state"])
+    mod.to(dev)
+    q = g["query"].clone().requires_grad_(True)
+    v = g["value"].clone().requires_grad_(True)
+    out = mod(query=q, value=v, query_pos=g["query_pos"], key_padding_mask=g["key_padding_mask"],
+              reference_points=g["reference_points"], spatial_shapes=g["spatial_shapes"],
+              level_start_index=g["level_start_index"])
+    close(out, g["out"], TOL, "out")
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(out, [q, v] + list(params.values()), g["grad_out"])
+    close(grads[0], g["grad_query"], TOL, "grad_query")
+    close(grads[1], g["grad_value"], TOL, "grad_value")
+    for (k, _), gr in zip(params.items(), grads[2:]):
+        close(gr, g["grad_params"][k], TOL, "grad " + k)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_rep_zero_linear(dev):
+    g = to(load("rep_zero_linear"), dev)
+    lin = rsb.RepZeroLinear(24, 16)
+    # constructor contract: weight 1e-8, scaling 0.1, zero twin; branch bias keeps nn.Linear init
+    assert torch.all(lin.weight == 1e-8) and float(lin.scaling) == pytest.approx(0.1)
+    assert not lin.freeze_linear.weight.any() and not lin.freeze_linear.bias.any()
+    assert set(lin.state_dict()) == set(g["init_state"])
+    lin.load_state_dict(g["state"])
+    lin.to(dev).train()
+    x = g["x"].clone().requires_grad_(True)
+    out, zl = lin(x)
+    close(out, g["out"], TOL, "out")
+    close(zl, g["zl"], TOL, "zero-interference loss")
+    assert zl.dim() == 0
+    params = dict(lin.named_parameters())
+    grads = torch.autograd.grad((out * g["grad_out"]).sum() + g["zl_weight"] * zl, [x] + list(params.values()))
+    close(grads[0], g["grad_x"], TOL, "grad_x")
+    for k, gr in zip(params, grads[1:]):
+        close(gr, g["grad_params"][k], TOL, "grad " + k)
+    lin.eval()
+    out_e, zl_e = lin(x)
+    close(out_e, g["out_eval"], TOL, "eval out")
+    assert zl_e.shape == (1,) and float(zl_e) == 0.0
+    lin.__rep__()
+    for k, v in lin.state_dict().items():
+        close(v, g["state_after_rep"][k], 1e-6, "after __rep__ " + k)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+@pytest.mark.parametrize("name", ["1x1", "3x3s2"])
+def test_rep_zero_conv(dev, name):
+    g = to(load("rep_zero_conv_" + name), dev)
+    conv = rsb.RepZeroConv2d(12, 16, **g["kwargs"])
+    assert torch.all(conv.weight == 1e-8) and torch.all(conv.bias == 1e-8)
+    assert float(conv.scaling) == pytest.approx(0.1)
+    assert set(conv.state_dict()) == set(g["init_state"])
+    conv.load_state_dict(g["state"])
+    conv.to(dev).train()
+    x = g["x"].clone().requires_grad_(True)
+    out, zl = conv(x)
+    close(out, g["out"], TOL, "out")
+    close(zl, g["zl"], TOL, "zero-interference loss")
+    params = dict(conv.named_parameters())
+    grads = torch.autograd.grad((out * g["grad_out"]).sum() + g["zl_weight"] * zl, [x] + list(params.values()))
+    close(grads[0], g["grad_x"], TOL, "grad_x")
+    for k, gr in zip(params, grads[1:]):
+        close(gr, g["grad_params"][k], TOL, "grad " + k)
+    conv.eval()
+    out_e, zl_e = conv(x)
+    close(out_e, g["out_eval"], TOL, "eval out")
+    assert float(zl_e) == 0.0
+    conv.__rep__()
+    for k, v in conv.state_dict().items():
+        close(v, g["state_after_rep"][k], 1e-6, "after __rep__ " + k)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_text_masks_bit_exact(dev):
+    g = to(load("text_masks"), dev)
+    for suffix in ("", "2", "3"):
+        am, pid, c2t = text_masks.generate_masks_with_special_tokens_and_transfer_map(
+            {"input_ids": g["input_ids" + suffix]}, g["special"], None)
+        assert am.dtype == torch.bool and pid.dtype == torch.long
+        assert torch.equal(am, g["attention_mask" + suffix])
+        assert torch.equal(pid, g["position_ids" + suffix])
+        assert len(c2t) == len(g["cate_to_token" + suffix])
+        for a, b in zip(c2t, g["cate_to_token" + suffix]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_contrastive_embed_and_category_logits(dev):
+    g = to(load("contrastive_logits"), dev)
+    hs = g["hs"].clone().requires_grad_(True)
+    text = g["text"].clone().requires_grad_(True)
+    ce = utils.ContrastiveEmbed(max_text_len=g["max_text_len"])
+    logits = ce(hs, {"encoded_text": text, "text_token_mask": g["text_token_mask"]})
+    close(logits, g["token_logits"], TOL, "token logits")
+    cls = utils.recover_to_cls_logits(logits, g["cate_to_token"], for_fill=-100.0)
+    close(cls, g["cls_logits"], TOL, "category logits")
+    ghs, gtext = torch.autograd.grad(cls, [hs, text], g["grad_out"])
+    close(ghs, g["grad_hs"], TOL, "grad hs")
+    close(gtext, g["grad_text"], TOL, "grad text")
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_utils_misc(dev):
+    g = to(load("utils_misc"), dev)
+    close(utils.gen_sineembed_for_position(g["pos4"]), g["sine4"], 1e-5, "sine4")
+    close(utils.gen_sineembed_for_position(g["pos4"][..., :2]), g["sine2"], 1e-5, "sine2")
+    close(utils.get_sine_pos_embed(g["pos1"], num_pos_feats=16, exchange_xy=False), g["sine1"], 1e-5, "sine1")
+    om, op = utils.gen_encoder_output_proposals(g["memory"], g["padding_mask"], g["shapes"])
+    close(om, g["out_memory"], 1e-6, "proposal memory")
+    close(op, g["out_proposals"], 1e-5, "proposals")
+    om2, op2 = utils.gen_encoder_output_proposals(g["memory"], g["padding_mask"],
+                                                  torch.tensor(g["shapes"], device=dev))
+    assert torch.equal(op, op2) and torch.equal(om, om2)
+    close(utils.inverse_sigmoid(g["inv_sig_in"]), g["inv_sig_out"], 1e-6, "inverse_sigmoid")
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_criterion_and_matcher(dev):
+    from types import SimpleNamespace
+
+    g = to(load("criterion"), dev)
+    crit = criterion.build_criterion(SimpleNamespace(**g["args"]))
+    assert dict(crit.weight_dict) == g["weight_dict"]
+    out = g["outputs"]
+    out["pred_logits"] = out["pred_logits"].clone().requires_grad_(True)
+    out["pred_boxes"] = out["pred_boxes"].clone().requires_grad_(True)
+    losses, idx = crit(out, g["targets"], return_indices=True)
+    assert set(losses) == set(g["losses"])
+    for k in losses:
+        close(losses[k], g["losses"][k], TOL, k)
+
+    def same(a, b):  # matcher assignments: bit-exact
+        assert len(a) == len(b)
+        for (i1, j1), (i2, j2) in zip(a, b):
+            assert torch.equal(i1.cpu(), i2.cpu()) and torch.equal(j1.cpu(), j2.cpu())
+
+    same(idx["indices"], g["indices"]["indices"])
+    for a, b in zip(idx["aux_outputs"], g["indices"]["aux_outputs"]):
+        same(a, b)
+    same(idx["enc_outputs"][0], g["indices"]["enc_outputs"][0])
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses)
+    close(total, g["total"], TOL, "weighted total")
+    gl, gb = torch.autograd.grad(total, [out["pred_logits"], out["pred_boxes"]])
+    close(gl, g["grad_pred_logits"], TOL, "grad logits")
+    close(gb, g["grad_pred_boxes"], TOL, "grad boxes")
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_bi_attention_block(dev):
+    g = to(load("bi_attention_block"), dev)
+    blk = transformer.BiAttentionBlock(v_dim=32, l_dim=32, embed_dim=64, num_heads=4, dropout=0.0, drop_path=0.1)
+    blk.load_state_dict(g["state"])
+    blk.to(dev).eval()
+    v = g["v"].clone().requires_grad_(True)
+    l = g["l"].clone().requires_grad_(True)
+    ov, ol = blk(v, l, attention_mask_v=g["mask_v"], attention_mask_l=g["mask_l"])
+    close(ov, g["out_v"], TOL, "out_v")
+    close(ol, g["out_l"], TOL, "out_l")
+    gv, gl = torch.autograd.grad((ov * g["grad_out_v"]).sum() + (ol * g["grad_out_l"]).sum(), [v, l])
+    close(gv, g["grad_v"], TOL, "grad_v")
+    close(gl, g["grad_l"], TOL, "grad_l")
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_text_enhancer_layer(dev):
+    g = to(load("text_enhancer_layer"), dev)
+    lay = transformer.TransformerEncoderLayer(d_model=32, nhead=4, dim_feedforward=48, dropout=0.0)
+    lay.load_state_dict(g["state"])
+    lay.to(dev).eval()
+    src = g["src"].clone().requires_grad_(True)
+    out = lay(src, src_mask=~g["may_attend"], src_key_padding_mask=None, pos=g["pos"])
+    close(out, g["out"], TOL, "out")
+    gs, = torch.autograd.grad(out, [src], g["grad_out"])
+    close(gs, g["grad_src"], TOL, "grad_src")
+
+
+@pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
+def test_tiny_transformer(msda_backend):
+    """Encoder (fusion + text enhancer + deformable layer) -> two-stage top-k -> decoder with
+    iterative box refinement, weights rebuilt from names (tests/golden/seeded.py)."""
+    dev = msda_backend
+    g = load("tiny_transformer")
+    kw = g["kwargs"]
+    d = kw["d_model"]
+    tr = transformer.Transformer(**kw)
+    bbox = utils.MLP(d, d, 4, 3)
+    cls = utils.ContrastiveEmbed(max_text_len=16)
+    tr.decoder.bbox_embed = torch.nn.ModuleList([bbox for _ in range(2)])
+    tr.decoder.class_embed = torch.nn.ModuleList([cls for _ in range(2)])
+    tr.enc_out_bbox_embed = utils.MLP(d, d, 4, 3)
+    tr.enc_out_class_embed = cls
+    assert [n for n, _ in tr.named_parameters()] == g["param_names"]   # state-dict contract
+    fill_by_name_(tr, g["salt"], g["scale"], g["scales"])
+    tr.to(dev).eval()
+    g = to(g, dev)
+    srcs = [s.clone().requires_grad_(True) for s in g["srcs"]]
+    text = g["text"].clone().requires_grad_(True)
+    text_dict = {"encoded_text": text, "text_token_mask": g["text_token_mask"],
+                 "position_ids": g["position_ids"],
+                 "text_self_attention_masks": g["text_self_attention_masks"]}
+    hs, refs, hs_enc, ref_enc, init_box, _ = tr(srcs, g["masks"], None, g["poss"], None, None, text_dict)
+    assert torch.equal(tr.last_topk_proposals, g["topk_proposals"])     # indices: bit-exact
+    close(text_dict["encoded_text"], g["memory_text"], TOL, "memory_text")
+    for i, (a, b) in enumerate(zip(hs, g["hs"])):
+        close(a, b, TOL, "hs[%d]" % i)
+    for i, (a, b) in enumerate(zip(refs, g["references"])):
+        close(a, b, TOL, "references[%d]" % i)
+    close(hs_enc, g["hs_enc"], TOL, "hs_enc")
+    close(ref_enc, g["ref_enc"], TOL, "ref_enc")
+    close(init_box, g["init_box_proposal"], TOL, "init_box_proposal")
+    total = sum((h * go).sum() for h, go in zip(hs, g["grad_hs"])) + (refs[-1] ** 2).sum() + (hs_enc ** 2).sum() * 0.1
+    close(total, g["total"], TOL, "total")
+    grads = torch.autograd.grad(total, srcs + [text])
+    for i in range(3):
+        close(grads[i], g["grad_srcs"][i], 2e-4, "grad srcs[%d]" % i)
+    close(grads[3], g["grad_text"], 2e-4, "grad text")

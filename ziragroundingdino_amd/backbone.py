@@ -1,0 +1,262 @@
+"""Frozen image backbone: Swin Transformer + sine position encoding.
+
+Out of kernel scope: the backbone is frozen and has no backward in
+ZiRa, its cost is dense GEMMs / window attention that stock PyTorch-ROCm already sends to MFMA
+(hipBLASLt, fused SDPA).  It exists here because the end-to-end training step the bench times
+starts at the pixels.  Architecture, feature shapes and parameter names follow the reference
+(groundingdino/models/GroundingDINO/backbone/swin_transformer.py, position_encoding.py:78-134,
+backbone.py:146-221) so that its checkpoints load: ``patch_embed.proj``, ``layers.N.blocks.K.
+{norm1, attn.{relative_position_bias_table, qkv, proj}, norm2, mlp.{fc1, fc2}}``,
+``layers.N.downsample.{reduction, norm}``, ``norm{1,2,3}``.
+"""
+import math
+from typing import List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .transformer import DropPath
+from .utils import NestedTensor
+
+SWIN_VARIANTS = {  # reference swin_transformer.py:772-788
+    "swin_T_224_1k": dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7),
+    "swin_B_224_22k": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7),
+    "swin_B_384_22k": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=12),
+    "swin_L_224_22k": dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7),
+    "swin_L_384_22k": dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=12),
+}
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+def window_partition(x, ws):
+    B, H, W, C = x.shape
+    x = x.view(B, H // ws, ws, W // ws, ws, C)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+
+
+def window_reverse(windows, ws, H, W):
+    B = windows.shape[0] // ((H // ws) * (W // ws))
+    x = windows.view(B, H // ws, W // ws, ws, ws, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads):
+        super().__init__()
+        self.dim, self.ws, self.num_heads = dim, window_size, num_heads
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros((2 * window_size - 1) * (2 * window_size - 1), num_heads))
+        coords = torch.stack(torch.meshgrid(torch.arange(window_size), torch.arange(window_size), indexing="ij"))
+        coords = coords.flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += window_size - 1
+        rel[:, :, 1] += window_size - 1
+        rel[:, :, 0] *= 2 * window_size - 1
+        self.register_buffer("relative_position_index", rel.sum(-1))
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+    def forward(self, x, mask=None):
+        Bw, N, C = x.shape
+        qkv = self.qkv(x).reshape(Bw, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)]
+        bias = bias.view(N, N, -1).permute(2, 0, 1).unsqueeze(0)                # 1, heads, N, N
+        if mask is not None:                                                    # nW, N, N
+            nW = mask.shape[0]
+            bias = (bias + mask.unsqueeze(1)).repeat(Bw // nW, 1, 1, 1)         # Bw, heads, N, N
+        x = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=bias.to(x.dtype))
+        return self.proj(x.transpose(1, 2).reshape(Bw, N, C))
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, drop_path):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, shift_size
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, window_size, num_heads)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, H, W, mask_matrix):
+        B, L, C = x.shape
+        ws = self.window_size
+        shortcut = x
+        x = self.norm1(x).view(B, H, W, C)
+        pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+        x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        Hp, Wp = H + pad_b, W + pad_r
+        if self.shift_size > 0:
+            x = torch.roll(x, shifts=(-self.shift_size, -self.shift_size), dims=(1, 2))
+            attn_mask = mask_matrix
+        else:
+            attn_mask = None
+        w = self.attn(window_partition(x, ws), mask=attn_mask)
+        x = window_reverse(w, ws, Hp, Wp)
+        if self.shift_size > 0:
+            x = torch.roll(x, shifts=(self.shift_size, self.shift_size), dims=(1, 2))
+        x = x[:, :H, :W, :].reshape(B, H * W, C)
+        x = shortcut + self.drop_path(x)
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x, H, W):
+        B, L, C = x.shape
+        x = x.view(B, H, W, C)
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))  # odd sizes are padded (reference :326-328)
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x.view(B, -1, 4 * C)))
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, drop_path, downsample):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, window_size // 2
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2,
+                                 mlp_ratio, drop_path[i]) for i in range(depth)])
+        self.downsample = PatchMerging(dim) if downsample else None
+
+    def forward(self, x, H, W):
+        ws, ss = self.window_size, self.shift_size
+        Hp, Wp = int(math.ceil(H / ws)) * ws, int(math.ceil(W / ws)) * ws
+        img_mask = torch.zeros((1, Hp, Wp, 1), device=x.device)
+        cnt = 0
+        for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+            for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+                img_mask[:, h, w, :] = cnt
+                cnt += 1
+        mw = window_partition(img_mask, ws).view(-1, ws * ws)
+        attn_mask = mw.unsqueeze(1) - mw.unsqueeze(2)
+        attn_mask = attn_mask.masked_fill(attn_mask != 0, -100.0).masked_fill(attn_mask == 0, 0.0)
+        for blk in self.blocks:
+            x = blk(x, H, W, attn_mask)
+        if self.downsample is not None:
+            return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
+        return x, H, W, x, H, W
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96):
+        super().__init__()
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        _, _, H, W = x.shape
+        p = self.patch_size
+        x = F.pad(x, (0, (p - W % p) % p, 0, (p - H % p) % p))  # 1333 -> 1336 (reference :482-489)
+        x = self.proj(x)
+        Wh, Ww = x.shape[2], x.shape[3]
+        x = self.norm(x.flatten(2).transpose(1, 2))
+        return x, Wh, Ww
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7,
+                 mlp_ratio=4.0, drop_path_rate=0.2, out_indices=(1, 2, 3), **_unused):
+        super().__init__()
+        self.out_indices = tuple(out_indices)
+        self.num_layers = len(depths)
+        self.patch_embed = PatchEmbed(4, 3, embed_dim)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        self.layers = nn.ModuleList([
+            BasicLayer(self.num_features[i], depths[i], num_heads[i], window_size, mlp_ratio,
+                       dpr[sum(depths[:i]):sum(depths[:i + 1])], downsample=i < self.num_layers - 1)
+            for i in range(self.num_layers)])
+        for i in self.out_indices:
+            self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
+
+    def forward(self, tensor_list: NestedTensor):
+        x, Wh, Ww = self.patch_embed(tensor_list.tensors)
+        outs = {}
+        for i, layer in enumerate(self.layers):
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
+            if i in self.out_indices:
+                x_out = getattr(self, f"norm{i}")(x_out)
+                out = x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
+                m = tensor_list.mask
+                mask = F.interpolate(m[None].float(), size=out.shape[-2:]).to(torch.bool)[0]
+                outs[len(outs)] = NestedTensor(out, mask)
+        return outs
+
+
+class PositionEmbeddingSineHW(nn.Module):
+    """Sine position encoding with separate H/W temperatures (reference position_encoding.py:78-134)."""
+
+    def __init__(self, num_pos_feats=64, temperatureH=10000, temperatureW=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats = num_pos_feats
+        self.temperatureH, self.temperatureW = temperatureH, temperatureW
+        self.normalize = normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, tensor_list: NestedTensor):
+        mask = tensor_list.mask
+        not_mask = ~mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            eps = 1e-6
+            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+        i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
+        expo = 2 * torch.div(i, 2, rounding_mode="floor") / self.num_pos_feats
+        pos_x = x_embed[:, :, :, None] / (self.temperatureW ** expo)
+        pos_y = y_embed[:, :, :, None] / (self.temperatureH ** expo)
+        pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
+        pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+class Joiner(nn.Sequential):
+    """(backbone, position_embedding) -> (list of NestedTensor features, list of pos) -- reference
+    backbone.py:146-160; ``self[1]`` is also used on its own for the extra 4th level."""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+
+    def forward(self, tensor_list: NestedTensor):
+        xs = self[0](tensor_list)
+        out: List[NestedTensor] = []
+        pos = []
+        for _, x in xs.items():
+            out.append(x)
+            pos.append(self[1](x).to(x.tensors.dtype))
+        return out, pos
+
+
+def build_backbone(args):
+    """Swin variants of reference backbone.py:163-221 (ResNet is not on the ZiRa path)."""
+    if args.backbone not in SWIN_VARIANTS:
+        raise NotImplementedError("Unknown backbone {}".format(args.backbone))
+    pos = PositionEmbeddingSineHW(args.hidden_dim // 2, temperatureH=args.pe_temperatureH,
+                                  temperatureW=args.pe_temperatureW, normalize=True)
+    idx = list(args.return_interm_indices)
+    assert idx in [[0, 1, 2, 3], [1, 2, 3], [3]]
+    swin = SwinTransformer(out_indices=tuple(idx), **SWIN_VARIANTS[args.backbone])
+    model = Joiner(swin, pos)
+    model.num_channels = swin.num_features[4 - len(idx):]
+    return model

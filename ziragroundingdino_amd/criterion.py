@@ -1,0 +1,154 @@
+"""Set-prediction loss of GroundingDINO / ZiRa (reference
+groundingdino/models/GroundingDINO/criterion/criterion.py:62-262 ``SetCriterion``,
+two_stage_criterion.py:20-100 ``TwoStageCriterion``, criterion/__init__.py:22-40 weights).
+
+Loss-dict keys are the reference's: ``loss_class / loss_bbox / loss_giou`` plus the suffixes
+``_0.._{dec_layers-2}`` (auxiliary decoder layers) and ``_enc`` (two-stage encoder output).
+"""
+import copy
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .box_ops import box_cxcywh_to_xyxy, generalized_box_iou
+from .matcher import build_matcher
+
+
+def is_dist_avail_and_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: float = 2):
+    """RetinaNet focal loss, mean over queries then sum, / num_boxes (reference criterion.py:31-59)."""
+    prob = inputs.sigmoid()
+    ce_loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce_loss * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, num_classes, matcher, weight_dict, losses: List[str] = ["class", "boxes"],
+                 eos_coef: float = 0.1, loss_class_type: str = "focal_loss", alpha: float = 0.25,
+                 gamma: float = 2.0):
+        super().__init__()
+        assert loss_class_type in ["ce_loss", "focal_loss"]
+        self.num_classes = num_classes
+        self.matcher = matcher
+        self.weight_dict = weight_dict
+        self.losses = losses
+        self.alpha = alpha
+        self.gamma = gamma
+        self.eos_coef = eos_coef
+        self.loss_class_type = loss_class_type
+        if loss_class_type == "ce_loss":
+            empty_weight = torch.ones(self.num_classes + 1)
+            empty_weight[-1] = eos_coef
+            self.register_buffer("empty_weight", empty_weight)
+
+    @staticmethod
+    def _get_src_permutation_idx(indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        src_idx = torch.cat([src for (src, _) in indices])
+        return batch_idx, src_idx
+
+    def loss_labels(self, outputs, targets, indices, num_boxes):
+        src_logits = outputs["pred_logits"]
+        idx = self._get_src_permutation_idx(indices)
+        target_classes_o = torch.cat([t["labels"][J] for t, (_, J) in zip(targets, indices)])
+        target_classes = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64,
+                                    device=src_logits.device)
+        target_classes[idx] = target_classes_o
+        if self.loss_class_type == "ce_loss":
+            loss_class = F.cross_entropy(src_logits.transpose(1, 2), target_classes, self.empty_weight)
+        else:
+            onehot = torch.zeros([src_logits.shape[0], src_logits.shape[1], src_logits.shape[2] + 1],
+                                 dtype=src_logits.dtype, device=src_logits.device)
+            onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+            loss_class = sigmoid_focal_loss(src_logits, onehot[:, :, :-1], num_boxes=num_boxes,
+                                            alpha=self.alpha, gamma=self.gamma) * src_logits.shape[1]
+        return {"loss_class": loss_class}
+
+    def loss_boxes(self, outputs, targets, indices, num_boxes):
+        idx = self._get_src_permutation_idx(indices)
+        src_boxes = outputs["pred_boxes"][idx]
+        target_boxes = torch.cat([t["boxes"][i] for t, (_, i) in zip(targets, indices)], dim=0)
+        loss_bbox = F.l1_loss(src_boxes, target_boxes, reduction="none")
+        loss_giou = 1 - torch.diag(generalized_box_iou(box_cxcywh_to_xyxy(src_boxes),
+                                                       box_cxcywh_to_xyxy(target_boxes)))
+        return {"loss_bbox": loss_bbox.sum() / num_boxes, "loss_giou": loss_giou.sum() / num_boxes}
+
+    def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
+        loss_map = {"class": self.loss_labels, "boxes": self.loss_boxes}
+        assert loss in loss_map, f"do you really want to compute {loss} loss?"
+        return loss_map[loss](outputs, targets, indices, num_boxes, **kwargs)
+
+    def _num_boxes(self, outputs, targets):
+        num_boxes = sum(len(t["labels"]) for t in targets)
+        num_boxes = torch.as_tensor([num_boxes], dtype=torch.float,
+                                    device=next(iter(outputs.values())).device)
+        if is_dist_avail_and_initialized():
+            dist.all_reduce(num_boxes)
+        return torch.clamp(num_boxes / get_world_size(), min=1).item()
+
+
+class TwoStageCriterion(SetCriterion):
+    def __init__(self, num_classes, matcher, weight_dict, losses=["class", "boxes"], eos_coef=None,
+                 loss_class_type="focal_loss", alpha: float = 0.25, gamma: float = 2,
+                 two_stage_binary_cls=False):
+        super().__init__(num_classes, matcher, weight_dict, losses, eos_coef, loss_class_type,
+                         alpha, gamma)
+        self.two_stage_binary_cls = two_stage_binary_cls
+
+    def forward(self, outputs, targets, return_indices=False):
+        outputs_without_aux = {k: v for k, v in outputs.items()
+                               if k not in ("aux_outputs", "enc_outputs", "cate_to_token_mask_list")}
+        indices_list = {"indices": None, "aux_outputs": [], "enc_outputs": []}
+        indices = self.matcher(outputs_without_aux, targets)
+        indices_list["indices"] = indices
+        num_boxes = self._num_boxes(outputs_without_aux, targets)
+
+        losses = {}
+        for loss in self.losses:
+            losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
+        for i, aux_outputs in enumerate(outputs.get("aux_outputs", [])):
+            indices = self.matcher(aux_outputs, targets)
+            indices_list["aux_outputs"].append(indices)
+            for loss in self.losses:
+                l_dict = self.get_loss(loss, aux_outputs, targets, indices, num_boxes)
+                losses.update({k + f"_{i}": v for k, v in l_dict.items()})
+        if "enc_outputs" in outputs:
+            enc_outputs = outputs["enc_outputs"]
+            if self.two_stage_binary_cls:
+                for bt in targets:
+                    bt["labels"] = torch.zeros_like(bt["labels"])
+            indices = self.matcher(enc_outputs, targets)
+            indices_list["enc_outputs"].append(indices)
+            for loss in self.losses:
+                l_dict = self.get_loss(loss, enc_outputs, targets, indices, num_boxes)
+                losses.update({k + "_enc": v for k, v in l_dict.items()})
+        if return_indices:
+            return losses, indices_list
+        return losses
+
+
+def build_criterion(args):
+    """class 1, bbox 5, giou 2, replicated for ``_enc`` and ``_0..`` (reference criterion/__init__.py:22-40)."""
+    weight_dict = {"loss_class": 1, "loss_bbox": 5.0, "loss_giou": 2.0}
+    base = copy.deepcopy(weight_dict)
+    if args.aux_loss:
+        aux = {k + "_enc": v for k, v in base.items()}
+        for i in range(args.dec_layers - 1):
+            aux.update({k + f"_{i}": v for k, v in base.items()})
+        weight_dict.update(aux)
+    return TwoStageCriterion(num_classes=args.max_text_len, matcher=build_matcher(args),
+                             weight_dict=weight_dict)

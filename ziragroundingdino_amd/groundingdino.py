@@ -1,0 +1,467 @@
+"""ZiRa GroundingDINO model -- drop-in for the reference's
+``groundingdino/models/GroundingDINO/groundingdino_dual_zero_rep_branch.py`` (class
+``GroundingDINO`` :137-745, builder :748-827, registry name ``dualzerorepbranchgroundingdino``).
+
+Same surface: ``model(batched_inputs)`` with ``[{"image": uint8/float [3,H,W], "captions":
+"cat . dog .", "instances": Instances}]`` returns the weighted loss dict in training mode
+(``loss_class/_bbox/_giou`` + ``_0.._4`` + ``_enc``, ``loss_conv_adapter``,
+``loss_linear_adapter``) and ``[{"instances": Instances}]`` in eval mode; the hooks
+``before_train`` / ``after_train`` / ``add_cls_prompt`` / ``load_state_dict`` and the
+parameter names (``input_proj_conv_adapter.N.*``, ``rep_linear_adapter.*``, ``feat_map``,
+``input_proj``, ``bbox_embed``, ``transformer.*``, ``backbone.0.*``, ``bert.*``) are the
+reference's, so its checkpoints and its training driver work unchanged.
+
+What runs where: both side branches go through the fused RSB epilogue kernels (rsb.py), all
+12 deformable-attention calls through the gfx950 MSDA kernels (ms_deform_attn.py); the frozen
+backbone and text encoder are stock PyTorch-ROCm and are evaluated without building an
+autograd graph (nothing upstream of the side branches needs gradients).
+"""
+import copy
+import random
+from typing import List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .backbone import build_backbone
+from .bert import BertConfig, BertModel, SimpleTokenizer
+from .box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh
+from .criterion import build_criterion
+from .rsb import RepZeroConv2d, RepZeroLinear
+from .structures import Boxes, ImageList, Instances
+from .text_masks import generate_masks_with_special_tokens_and_transfer_map
+from .transformer import build_transformer
+from .utils import (MLP, ContrastiveEmbed, NestedTensor, inverse_sigmoid,
+                    nested_tensor_from_tensor_list, recover_to_cls_logits)
+
+
+class _Registry:
+    """name -> builder, as groundingdino/models/registry.py ``MODULE_BUILD_FUNCS``."""
+
+    def __init__(self):
+        self._funcs = {}
+
+    def registe_with_name(self, module_name=None, force=False):
+        def deco(fn):
+            name = module_name or fn.__name__
+            if name in self._funcs and not force:
+                raise KeyError("%s is already registered" % name)
+            self._funcs[name] = fn
+            return fn
+        return deco
+
+    def get(self, name):
+        return self._funcs[name]
+
+    def __contains__(self, name):
+        return name in self._funcs
+
+
+MODULE_BUILD_FUNCS = _Registry()
+
+
+class GroundingDINO(nn.Module):
+    def __init__(self, backbone, transformer, num_queries, aux_loss=False, iter_update=False,
+                 query_dim=2, num_feature_levels=1, nheads=8, two_stage_type="no",
+                 dec_pred_bbox_embed_share=True, two_stage_class_embed_share=True,
+                 two_stage_bbox_embed_share=True, num_patterns=0, dn_number=100,
+                 dn_box_noise_scale=0.4, dn_label_noise_ratio=0.5, dn_labelbook_size=100,
+                 text_encoder_type="bert-base-uncased", sub_sentence_present=True, max_text_len=256,
+                 criterion=None, pixel_mean: List[float] = [123.675, 116.280, 103.530],
+                 pixel_std: List[float] = [123.675, 116.280, 103.530], device="cuda",
+                 select_box_nums_for_evaluation=200, freeze_all=False, loss_adapter_weight=0.1,
+                 use_cet=False, use_prompt_memory=False, num_select_prompt=200,
+                 use_zero_inter_loss=True, use_add_names=False, use_bert_tuning=False,
+                 use_cls_linear=False, use_prompt_tuning=False, use_prompt_memory_output=True,
+                 use_project_tuning=False, use_project_adapter=True,
+                 use_zero_inter_loss_for_conv=True, use_learned_names=False,
+                 bert=None, tokenizer=None, **_unused):
+        super().__init__()
+        assert query_dim == 4 and iter_update, "GroundingDINO uses 4-d queries with iterative update"
+        assert not use_cls_linear, "use_cls_linear (linear probing ablation) is outside the ZiRa path"
+        assert two_stage_type in ["no", "standard"]
+        self.num_queries = num_queries
+        self.transformer = transformer
+        self.hidden_dim = hidden_dim = transformer.d_model
+        self.num_feature_levels = num_feature_levels
+        self.nheads = nheads
+        self.max_text_len = max_text_len
+        self.sub_sentence_present = sub_sentence_present
+        self.query_dim = query_dim
+        self.num_patterns = num_patterns
+        self.dn_number, self.dn_box_noise_scale = dn_number, dn_box_noise_scale
+        self.dn_label_noise_ratio, self.dn_labelbook_size = dn_label_noise_ratio, dn_labelbook_size
+
+        # text encoder (frozen); tokenizer / pretrained weights can be injected by the caller
+        self.tokenizer = tokenizer if tokenizer is not None else SimpleTokenizer()
+        self.bert = bert if bert is not None else BertModel(BertConfig())
+        self.bert.pooler.dense.weight.requires_grad_(False)
+        self.bert.pooler.dense.bias.requires_grad_(False)
+        self.feat_map = nn.Linear(self.bert.config.hidden_size, hidden_dim, bias=True)
+        nn.init.constant_(self.feat_map.bias.data, 0)
+        nn.init.xavier_uniform_(self.feat_map.weight.data)
+
+        self.learned_classes = []
+        self.use_cet = use_cet
+        self.use_prompt_memory = use_prompt_memory
+        self.use_zero_inter_loss = use_zero_inter_loss
+        self.prompt_memory_pool = nn.ParameterDict()
+        self.num_select_prompt = num_select_prompt
+        self.use_prompt_tuning = use_prompt_tuning
+        self.use_learned_names = use_learned_names
+        self.use_prompt_memory_output = use_prompt_memory_output
+        if use_cet:  # RSB #1: language side branch beside feat_map
+            self.rep_linear_adapter = RepZeroLinear(self.bert.config.hidden_size, hidden_dim)
+        self.specical_tokens = self.tokenizer.convert_tokens_to_ids(["[CLS]", "[SEP]", ".", "?"])
+
+        # input projections (frozen) and RSB #2: one zero-initialised conv branch beside each
+        chans = list(backbone.num_channels)
+        proj, adapters = [], []
+        in_channels = chans[-1]
+        if num_feature_levels > 1:
+            for c in chans:
+                proj.append(nn.Sequential(nn.Conv2d(c, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
+                adapters.append(RepZeroConv2d(c, hidden_dim, kernel_size=1))
+            for _ in range(num_feature_levels - len(chans)):
+                proj.append(nn.Sequential(nn.Conv2d(in_channels, hidden_dim, kernel_size=3, stride=2, padding=1),
+                                          nn.GroupNorm(32, hidden_dim)))
+                adapters.append(RepZeroConv2d(in_channels, hidden_dim, kernel_size=3, stride=2, padding=1))
+                in_channels = hidden_dim
+        else:
+            assert two_stage_type == "no"
+            proj.append(nn.Sequential(nn.Conv2d(chans[-1], hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
+            adapters.append(RepZeroConv2d(chans[-1], hidden_dim, kernel_size=1))
+        self.input_proj = nn.ModuleList(proj)
+        self.use_project_adapter = use_project_adapter
+        self.use_zero_inter_loss_for_conv = use_zero_inter_loss_for_conv
+        if use_project_adapter:
+            self.input_proj_conv_adapter = nn.ModuleList(adapters)
+
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.box_pred_damping = None
+        self.iter_update = iter_update
+
+        # prediction heads, shared across decoder layers
+        self.dec_pred_bbox_embed_share = dec_pred_bbox_embed_share
+        _class_embed = ContrastiveEmbed(max_text_len=max_text_len)
+        _bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        nn.init.constant_(_bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(_bbox_embed.layers[-1].bias.data, 0)
+        n_dec = transformer.num_decoder_layers
+        boxes = [_bbox_embed if dec_pred_bbox_embed_share else copy.deepcopy(_bbox_embed) for _ in range(n_dec)]
+        self.bbox_embed = nn.ModuleList(boxes)
+        self.class_embed = nn.ModuleList([_class_embed for _ in range(n_dec)])
+        self.transformer.decoder.bbox_embed = self.bbox_embed
+        self.transformer.decoder.class_embed = self.class_embed
+        self.two_stage_type = two_stage_type
+        if two_stage_type != "no":
+            if two_stage_bbox_embed_share:
+                assert dec_pred_bbox_embed_share
+                self.transformer.enc_out_bbox_embed = _bbox_embed
+            else:
+                self.transformer.enc_out_bbox_embed = copy.deepcopy(_bbox_embed)
+            if two_stage_class_embed_share:
+                assert dec_pred_bbox_embed_share
+                self.transformer.enc_out_class_embed = _class_embed
+            else:
+                self.transformer.enc_out_class_embed = copy.deepcopy(_class_embed)
+            self.refpoint_embed = None
+
+        self.criterion = criterion
+        self.pixel_mean, self.pixel_std = pixel_mean, pixel_std
+        self.device = device
+        self._reset_parameters()
+        self.use_add_names = use_add_names
+        self.select_box_nums_for_evaluation = select_box_nums_for_evaluation
+        self.loss_adapter_weight = loss_adapter_weight
+        self.freeze_all = freeze_all
+        self.use_bert_tuning = use_bert_tuning
+        self.use_cls_linear = use_cls_linear
+        self.use_project_tuning = use_project_tuning
+
+    def _reset_parameters(self):
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+
+    def init_ref_points(self, use_num_queries):
+        self.refpoint_embed = nn.Embedding(use_num_queries, self.query_dim)
+
+    # ---- pieces of forward ----------------------------------------------------------------
+    @staticmethod
+    def _frozen(module):
+        return not any(p.requires_grad for p in module.parameters())
+
+    def _project_level(self, l, feat):
+        """GroupNorm(input_proj conv + side branch); returns (src, zero-interference loss | None)."""
+        if not self.use_project_adapter:
+            return self.input_proj[l](feat), None
+        branch, zero_loss = self.input_proj_conv_adapter[l](feat)
+        return self.input_proj[l][1](self.input_proj[l][0](feat) + branch), zero_loss
+
+    def encode_text(self, captions, device):
+        tokenized = self.tokenizer(captions, padding="longest", return_tensors="pt").to(device)
+        masks, position_ids, cate_to_token_mask_list = generate_masks_with_special_tokens_and_transfer_map(
+            tokenized, self.specical_tokens, self.tokenizer)
+        L = self.max_text_len
+        if masks.shape[1] > L:
+            masks = masks[:, :L, :L]
+            position_ids = position_ids[:, :L]
+            for k in ("input_ids", "attention_mask", "token_type_ids"):
+                tokenized[k] = tokenized[k][:, :L]
+        if self.sub_sentence_present:
+            enc_in = {k: v for k, v in tokenized.items() if k != "attention_mask"}
+            enc_in["attention_mask"] = masks
+            enc_in["position_ids"] = position_ids
+        else:
+            enc_in = tokenized
+        with torch.set_grad_enabled(not self._frozen(self.bert)):
+            hidden = self.bert(**enc_in)["last_hidden_state"]
+        text_dict, loss_linear_adapter = self.project_text(
+            hidden, tokenized["attention_mask"].bool(), position_ids, masks)
+        return text_dict, cate_to_token_mask_list, loss_linear_adapter
+
+    def project_text(self, bert_hidden, text_token_mask, position_ids, text_self_attention_masks):
+        """feat_map + language side branch (reference :459-476): BERT states -> text_dict."""
+        L = self.max_text_len
+        encoded_text = self.feat_map(bert_hidden)
+        loss_linear_adapter = None
+        if self.use_cet:
+            rep_out, loss_linear_adapter = self.rep_linear_adapter(bert_hidden)
+            encoded_text = rep_out + encoded_text
+        if encoded_text.shape[1] > L:
+            encoded_text, text_token_mask = encoded_text[:, :L, :], text_token_mask[:, :L]
+            position_ids = position_ids[:, :L]
+            text_self_attention_masks = text_self_attention_masks[:, :L, :L]
+        text_dict = {"encoded_text": encoded_text, "text_token_mask": text_token_mask,
+                     "position_ids": position_ids,
+                     "text_self_attention_masks": text_self_attention_masks}
+        return text_dict, loss_linear_adapter
+
+    def forward(self, batched_inputs, **kw):
+        images = self.preprocess_image(batched_inputs)
+        samples = nested_tensor_from_tensor_list(images)
+
+        captions = [x["captions"] for x in batched_inputs]
+        names_list = [x["captions"][:-1].split(".") for x in batched_inputs]
+        if (self.use_add_names and not self.training) or (self.use_learned_names and self.training):
+            extra = [c for c in self.learned_classes if c not in names_list[0]]
+            if self.training and len(extra) >= self.num_select_prompt:
+                extra = random.sample(extra, self.num_select_prompt)
+            for i, (caption, names) in enumerate(zip(captions, names_list)):
+                names_list[i] = names + extra
+                captions[i] = caption + ".".join(extra)
+                if not captions[i].endswith("."):
+                    captions[i] += "."
+
+        text_dict, cate_to_token_mask_list, loss_linear_adapter = self.encode_text(captions, samples.device)
+
+        targets = None
+        if self.training:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            targets = self.prepare_targets(gt_instances, cate_to_token_mask_list, names_list)
+
+        with torch.set_grad_enabled(not self._frozen(self.backbone)):
+            features, poss = self.backbone(samples)
+
+        out_or_loss = self.forward_features(features, poss, samples.mask, text_dict,
+                                            cate_to_token_mask_list, loss_linear_adapter, targets)
+        if self.training:
+            return out_or_loss
+        out = out_or_loss
+        results = self.dt_inference(out["pred_logits"], out["pred_boxes"], images.image_sizes)
+        processed = []
+        for r, inp, image_size in zip(results, batched_inputs, images.image_sizes):
+            height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
+            r.pred_boxes.scale(width / image_size[1], height / image_size[0])  # detector_postprocess
+            r.image_size = (height, width)
+            processed.append({"instances": r})
+        return processed
+
+    def forward_features(self, features, poss, samples_mask, text_dict, cate_to_token_mask_list,
+                         loss_linear_adapter=None, targets=None):
+        """Everything downstream of the frozen backbone / text encoder: input projections with
+        the vision side branches, transformer, heads, and in training mode the criterion
+        (reference :483-587).  ``features``: list of NestedTensor, ``poss``: their position
+        encodings, ``samples_mask``: [B,H,W] padding mask of the input images."""
+        poss = list(poss)
+        srcs, masks, loss_conv_adapter = [], [], None
+
+        def add_zero_loss(z):
+            nonlocal loss_conv_adapter
+            if z is not None:
+                loss_conv_adapter = z if loss_conv_adapter is None else loss_conv_adapter + z
+
+        for l, feat in enumerate(features):
+            src, mask = feat.decompose()
+            src, z = self._project_level(l, src)
+            add_zero_loss(z)
+            srcs.append(src)
+            masks.append(mask)
+        for l in range(len(srcs), self.num_feature_levels):
+            inp = features[-1].tensors if l == len(features) else srcs[-1]
+            src, z = self._project_level(l, inp)
+            add_zero_loss(z)
+            mask = F.interpolate(samples_mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+            if len(poss) <= l:  # (callers that start at feature level may pass it themselves)
+                poss.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+            srcs.append(src)
+            masks.append(mask)
+
+        hs, reference, hs_enc, ref_enc, init_box_proposal, _ = self.transformer(
+            srcs, masks, None, poss, None, None, text_dict)
+
+        outputs_coord_list = []
+        for layer_ref_sig, layer_bbox_embed, layer_hs in zip(reference[:-1], self.bbox_embed, hs):
+            unsig = layer_bbox_embed(layer_hs) + inverse_sigmoid(layer_ref_sig)
+            outputs_coord_list.append(unsig.sigmoid())
+        outputs_coord_list = torch.stack(outputs_coord_list)
+        outputs_class = torch.stack([
+            recover_to_cls_logits(layer_cls_embed(layer_hs, text_dict), cate_to_token_mask_list, for_fill=-100.0)
+            for layer_cls_embed, layer_hs in zip(self.class_embed, hs)])
+        out = {"pred_logits": outputs_class[-1], "pred_boxes": outputs_coord_list[-1],
+               "cate_to_token_mask_list": cate_to_token_mask_list}
+
+        if self.training:
+            if self.aux_loss:
+                out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b}
+                                      for a, b in zip(outputs_class[:-1], outputs_coord_list[:-1])]
+            if hs_enc is not None:
+                interm_class = self.transformer.enc_out_class_embed(hs_enc[-1], text_dict)
+                interm_class = recover_to_cls_logits(interm_class, cate_to_token_mask_list, for_fill=-100.0)
+                out["enc_outputs"] = {"pred_logits": interm_class, "pred_boxes": ref_enc[-1]}
+            assert targets is not None and self.criterion is not None
+            loss_dict = self.criterion(out, targets)
+            weight_dict = self.criterion.weight_dict
+            for k in loss_dict.keys():
+                if k in weight_dict:
+                    loss_dict[k] = loss_dict[k] * weight_dict[k]
+            if self.use_project_adapter and self.use_zero_inter_loss_for_conv:
+                loss_dict["loss_conv_adapter"] = loss_conv_adapter * self.loss_adapter_weight
+            if self.use_cet and self.use_zero_inter_loss:
+                loss_dict["loss_linear_adapter"] = loss_linear_adapter * self.loss_adapter_weight
+            return loss_dict
+        return out
+
+    # ---- helpers with the reference's names ---------------------------------------------------
+    def prepare_targets(self, targets, cate_to_token_mask_list, names_list):
+        new_targets = []
+        for t in targets:
+            h, w = t.image_size
+            scale = torch.as_tensor([w, h, w, h], dtype=torch.float, device=self.device)
+            new_targets.append({"labels": t.gt_classes,
+                                "boxes": box_xyxy_to_cxcywh(t.gt_boxes.tensor / scale)})
+        return new_targets
+
+    def preprocess_image(self, batched_inputs):
+        images = [self.normalizer(x["image"].to(self.device)) for x in batched_inputs]
+        return ImageList.from_tensors(images)
+
+    def normalizer(self, x):
+        mean = torch.tensor(self.pixel_mean, device=x.device).view(3, 1, 1)
+        std = torch.tensor(self.pixel_std, device=x.device).view(3, 1, 1)
+        return (x - mean) / std
+
+    def dt_inference(self, box_cls, box_pred, image_sizes):
+        """sigmoid -> top-k over (query x class) -> boxes in absolute xyxy (reference :634-675)."""
+        assert len(box_cls) == len(image_sizes)
+        prob = box_cls.sigmoid()
+        scores, topk_indexes = torch.topk(prob.view(box_cls.shape[0], -1),
+                                          self.select_box_nums_for_evaluation, dim=1)
+        topk_boxes = torch.div(topk_indexes, box_cls.shape[2], rounding_mode="floor")
+        labels = topk_indexes % box_cls.shape[2]
+        boxes = torch.gather(box_pred, 1, topk_boxes.unsqueeze(-1).repeat(1, 1, 4))
+        results = []
+        for s, lab, b, image_size in zip(scores, labels, boxes, image_sizes):
+            r = Instances(image_size)
+            r.pred_boxes = Boxes(box_cxcywh_to_xyxy(b))
+            r.pred_boxes.scale(scale_x=image_size[1], scale_y=image_size[0])
+            r.scores = s
+            r.pred_classes = lab
+            results.append(r)
+        return results
+
+    def unfreeze_module_(self, pat_names, verbose=False):
+        for name, param in self.named_parameters():
+            if any(p in name for p in pat_names):
+                param.requires_grad = True
+                if verbose:
+                    print("unfreeze:", name)
+
+    def load_state_dict(self, state_dict, strict=True):
+        for k, v in state_dict.items():
+            if "prompt_memory_pool" in k:
+                class_name = k.split(".")[-1]
+                if class_name == "prompt_memory_pool":
+                    continue
+                self.prompt_memory_pool[class_name] = nn.Parameter(v)
+                self.learned_classes.append(class_name[1:-1])
+        return super().load_state_dict(state_dict=state_dict, strict=strict)
+
+    def add_cls_prompt(self, class_names, device="cpu", fixed_name=False):
+        for class_name in class_names:
+            self.learned_classes.append(class_name)
+            if not fixed_name:
+                class_name = "-{}-".format(class_name)
+            if class_name not in self.prompt_memory_pool:
+                self.prompt_memory_pool[class_name] = nn.Parameter(torch.randn(self.hidden_dim).to(device))
+
+    def before_train(self):
+        """Freeze everything, then unfreeze what the method trains: every parameter whose name
+        contains "adapter" -- the two side branches and their twins (reference :722-734)."""
+        if self.freeze_all:
+            for param in self.parameters():
+                param.requires_grad = False
+        if self.use_bert_tuning:
+            self.unfreeze_module_(["bert", "feat_map"])
+        if self.use_prompt_tuning:
+            self.unfreeze_module_(["prompt_memory_pool"])
+        if self.use_project_tuning:
+            self.unfreeze_module_(["input_proj"])
+        self.unfreeze_module_(["adapter"])
+
+    def after_train(self):
+        """End of a task: merge every side branch into its twin (reference :739-745)."""
+        for module in self.modules():
+            if hasattr(module, "__rep__"):
+                module.__rep__()
+
+    def side_branch_parameters(self):
+        """The only tensors that ever receive gradients in ZiRa (4 622 853 values for Swin-T)."""
+        return [p for n, p in self.named_parameters() if "adapter" in n]
+
+
+@MODULE_BUILD_FUNCS.registe_with_name(module_name="dualzerorepbranchgroundingdino")
+def build_dual_zero_rep_branch_groundingdino(args, bert=None, tokenizer=None):
+    backbone = build_backbone(args)
+    transformer = build_transformer(args)
+    criterion = build_criterion(args)
+    return GroundingDINO(
+        backbone, transformer, num_queries=args.num_queries, aux_loss=True, iter_update=True,
+        query_dim=4, num_feature_levels=args.num_feature_levels, nheads=args.nheads,
+        dec_pred_bbox_embed_share=args.dec_pred_bbox_embed_share, two_stage_type=args.two_stage_type,
+        two_stage_bbox_embed_share=args.two_stage_bbox_embed_share,
+        two_stage_class_embed_share=args.two_stage_class_embed_share, num_patterns=args.num_patterns,
+        dn_number=0, dn_box_noise_scale=args.dn_box_noise_scale,
+        dn_label_noise_ratio=args.dn_label_noise_ratio, dn_labelbook_size=args.dn_labelbook_size,
+        text_encoder_type=args.text_encoder_type, sub_sentence_present=args.sub_sentence_present,
+        max_text_len=args.max_text_len, criterion=criterion, freeze_all=args.freeze_all,
+        select_box_nums_for_evaluation=args.select_box_nums_for_evaluation,
+        loss_adapter_weight=args.loss_adapter_weight, use_cet=args.use_cet,
+        use_prompt_memory=args.use_prompt_memory, use_zero_inter_loss=args.use_zero_inter_loss,
+        use_add_names=args.use_add_names, use_bert_tuning=args.use_bert_tuning,
+        use_cls_linear=args.use_cls_linear, use_prompt_tuning=args.use_prompt_tuning,
+        use_prompt_memory_output=args.use_prompt_memory_output,
+        use_project_tuning=getattr(args, "use_project_tuning", False),
+        use_project_adapter=args.use_project_adapter,
+        use_zero_inter_loss_for_conv=args.use_zero_inter_loss_for_conv,
+        use_learned_names=args.use_learned_names, device=getattr(args, "device", "cuda"),
+        bert=bert, tokenizer=tokenizer)
+
+
+def build_model(args, **kw):
+    """groundingdino/models/__init__.py:11-18: dispatch on ``args.modelname``."""
+    assert args.modelname in MODULE_BUILD_FUNCS, "unknown model %s" % args.modelname
+    return MODULE_BUILD_FUNCS.get(args.modelname)(args, **kw)

@@ -1,0 +1,60 @@
+"""Hungarian matching of predictions to ground truth (reference
+groundingdino/models/GroundingDINO/matcher/matcher.py:27-151; ``build_matcher`` uses the
+defaults, i.e. weights 1/1/1, matcher/__init__.py:20-21).
+
+The assignment itself is scipy's ``linear_sum_assignment`` (rectangular Jonker-Volgenant), as
+in the reference, on a single device->host copy of the whole batch's cost matrix; the index
+results are therefore bit-identical whenever the cost matrix is.
+"""
+import torch
+import torch.nn as nn
+from scipy.optimize import linear_sum_assignment
+
+from .box_ops import box_cxcywh_to_xyxy, generalized_box_iou
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1,
+                 cost_class_type: str = "focal_loss_cost", alpha: float = 0.25, gamma: float = 2.0):
+        super().__init__()
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        assert cost_class_type in {"ce_cost", "focal_loss_cost"}
+        self.cost_class = cost_class
+        self.cost_bbox = cost_bbox
+        self.cost_giou = cost_giou
+        self.cost_class_type = cost_class_type
+        self.alpha = alpha
+        self.gamma = gamma
+
+    @torch.no_grad()
+    def cost_matrix(self, outputs, targets):
+        """[bs, num_queries, total_targets] matching cost (device tensor)."""
+        bs, num_queries = outputs["pred_logits"].shape[:2]
+        logits = outputs["pred_logits"].flatten(0, 1)
+        out_bbox = outputs["pred_boxes"].flatten(0, 1)
+        tgt_ids = torch.cat([v["labels"] for v in targets])
+        tgt_bbox = torch.cat([v["boxes"] for v in targets])
+        if self.cost_class_type == "ce_cost":
+            cost_class = -logits.softmax(-1)[:, tgt_ids]
+        else:
+            p = logits.sigmoid()
+            neg = (1 - self.alpha) * (p ** self.gamma) * (-(1 - p + 1e-8).log())
+            pos = self.alpha * ((1 - p) ** self.gamma) * (-(p + 1e-8).log())
+            cost_class = pos[:, tgt_ids] - neg[:, tgt_ids]
+        cost_bbox = torch.cdist(out_bbox, tgt_bbox, p=1)
+        cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(out_bbox), box_cxcywh_to_xyxy(tgt_bbox))
+        C = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
+        return C.view(bs, num_queries, -1)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        """-> list (per image) of (query_idx, target_idx) int64 CPU tensors."""
+        C = self.cost_matrix(outputs, targets).cpu()
+        sizes = [len(v["boxes"]) for v in targets]
+        indices = [linear_sum_assignment(c[i]) for i, c in enumerate(C.split(sizes, -1))]
+        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64))
+                for i, j in indices]
+
+
+def build_matcher(args=None):
+    return HungarianMatcher()

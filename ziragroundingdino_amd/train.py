@@ -1,0 +1,97 @@
+"""Training-step harness: the part of the reference's driver that touches the hot path
+(train_multidatasets.py ``Trainer.run_step`` :150-200, ``before_train/after_train`` :221-246,
+optimizer / DDP set-up in ``do_train`` :392-409, task config
+test_odinw13_softfreeze/for_train/test_aquarium.py:13-25).
+
+    forward -> sum(loss_dict) -> backward -> [all-reduce] -> clip_grad_norm_(0.1, L2) -> AdamW
+
+Data parallelism, MI355X-first: one process per GPU; only the ZiRa side branches ever receive
+gradients (4.6 M values, 18.5 MB fp32), so their ``.grad`` tensors are views of ONE flat buffer
+that is all-reduced over RCCL/xGMI in a single call right after backward (the side branches are
+the earliest layers, so their gradients are the last thing backward produces -- there is
+nothing left to overlap with) and clipped from the same buffer.  The reference wraps the whole
+170 M-parameter model in DDP before freezing it (``find_unused_parameters=True``) and
+all-reduces every bucket, ~690 MB per step, for the same result.
+"""
+import math
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+from .structures import Boxes, Instances
+
+
+def lr_factor(name: str) -> float:
+    """``optimizer.params.lr_factor_func`` of the task configs: twins learn at 0.2x."""
+    return 0.2 if "freeze" in name else 1.0
+
+
+class ZiraTrainer:
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), clip_max_norm=0.1,
+                 clip_norm_type=2.0, process_group=None):
+        self.model = model
+        model.before_train()  # freeze everything but the side branches
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        # one flat gradient bucket; .grad of every trainable tensor is a view into it
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        groups = [{"params": [p], "lr": lr * lr_factor(n), "weight_decay": weight_decay}
+                  for n, p in named]
+        self.optimizer = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay)
+        self.clip_max_norm, self.clip_norm_type = clip_max_norm, clip_norm_type
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.iter = 0
+
+    def run_step(self, data) -> Dict[str, torch.Tensor]:
+        """One optimisation step on one minibatch; returns the (detached) weighted loss dict."""
+        assert self.model.training, "[ZiraTrainer] model was changed to eval mode!"
+        loss_dict = self.model(data)
+        losses = sum(loss_dict.values())
+        losses.backward()
+        if self.world > 1:  # single RCCL all-reduce of the side-branch gradients
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.div_(self.world)
+        if self.clip_max_norm is not None:
+            # clip_grad_norm_ over the side-branch tensors == one norm of the flat bucket
+            total_norm = torch.linalg.vector_norm(self.flat_grad, self.clip_norm_type)
+            self.flat_grad.mul_(torch.clamp(self.clip_max_norm / (total_norm + 1e-6), max=1.0))
+        self.optimizer.step()
+        self.flat_grad.zero_()  # keeps the views alive (no set_to_none)
+        self.iter += 1
+        return {k: v.detach() for k, v in loss_dict.items()}
+
+    def after_train(self, class_names: List[str] = ()):
+        """End of a task (reference Trainer.after_train :221-237)."""
+        self.model.add_cls_prompt(list(class_names))
+        self.model.after_train()
+
+
+def synthetic_batch(batch_size, height=800, width=1333, n_categories=7, boxes_per_image=5, seed=0,
+                    device="cpu"):
+    """Synthetic minibatch in the reference's input format: uint8-valued
+    images, one caption listing all categories, ``boxes_per_image`` xyxy boxes with side
+    5-40 % of the image."""
+    g = torch.Generator().manual_seed(seed)
+    words = ["fish", "jellyfish", "penguin", "puffin", "shark", "starfish", "stingray", "crab",
+             "turtle", "seal", "whale", "coral", "eel"]
+    names = [words[i % len(words)] + ("" if i < len(words) else str(i)) for i in range(n_categories)]
+    caption = " . ".join(names) + " ."
+    batch = []
+    for _ in range(batch_size):
+        img = torch.randint(0, 256, (3, height, width), generator=g, dtype=torch.uint8).float()
+        wh = (0.05 + 0.35 * torch.rand(boxes_per_image, 2, generator=g))
+        c = wh / 2 + (1 - wh) * torch.rand(boxes_per_image, 2, generator=g)
+        xyxy = torch.cat([c - wh / 2, c + wh / 2], -1) * torch.tensor([width, height, width, height])
+        inst = Instances((height, width), gt_boxes=Boxes(xyxy),
+                         gt_classes=torch.randint(0, n_categories, (boxes_per_image,), generator=g))
+        batch.append({"image": img.to(device), "captions": caption, "instances": inst.to(device),
+                      "height": height, "width": width})
+    return batch

@@ -1,0 +1,613 @@
+"""Cross-modal deformable transformer of GroundingDINO (the one every reference model variant
+uses: groundingdino/models/GroundingDINO/transformer_for_adapter.py), plus its two encoder
+neighbours (fuse_modules.py ``BiAttentionBlock``, transformer_vanilla.py
+``TransformerEncoderLayer``).
+
+Module / parameter names follow the reference so that its checkpoints load unchanged
+(SURVEY.md appendix A): ``encoder.layers.N.self_attn.*``, ``encoder.text_layers.N.*``,
+``encoder.fusion_layers.N.*``, ``decoder.layers.N.{cross_attn,ca_text,self_attn,...}``,
+``decoder.ref_point_head``, ``level_embed``, ``tgt_embed``, ``enc_output``, ``enc_output_norm``.
+The ablation-only ``use_adapter`` (Adapter / MoE) branch is not part of the ZiRa path
+(``use_adapter = False`` in config/GroundingDINO_SwinT_OGC_rep.py:56) and is not built.
+
+Every multi-scale deformable attention call (6 encoder layers with Q = S, 6 decoder layers
+with Q = 900) runs the gfx950 kernels through ``MultiScaleDeformableAttention``.
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
+from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
+                    gen_sineembed_for_position, get_sine_pos_embed, inverse_sigmoid)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath semantics)."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask.div_(keep)
+
+
+class BiMultiHeadAttention(nn.Module):
+    """Image <-> text attention sharing one score matrix (reference fuse_modules.py:99-248)."""
+
+    def __init__(self, v_dim, l_dim, embed_dim, num_heads, dropout=0.1, cfg=None):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == embed_dim
+        self.v_dim, self.l_dim = v_dim, l_dim
+        self.scale = self.head_dim ** (-0.5)
+        self.dropout = dropout
+        self.v_proj = nn.Linear(v_dim, embed_dim)
+        self.l_proj = nn.Linear(l_dim, embed_dim)
+        self.values_v_proj = nn.Linear(v_dim, embed_dim)
+        self.values_l_proj = nn.Linear(l_dim, embed_dim)
+        self.out_v_proj = nn.Linear(embed_dim, v_dim)
+        self.out_l_proj = nn.Linear(embed_dim, l_dim)
+        self.stable_softmax_2d = True
+        self.clamp_min_for_underflow = True
+        self.clamp_max_for_overflow = True
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for lin in (self.v_proj, self.l_proj, self.values_v_proj, self.values_l_proj,
+                    self.out_v_proj, self.out_l_proj):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.fill_(0)
+
+    def _heads(self, t: Tensor, bsz: int):
+        return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).reshape(
+            bsz * self.num_heads, -1, self.head_dim)
+
+    def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
+        bsz, tgt_len, _ = v.size()
+        q = self._heads(self.v_proj(v) * self.scale, bsz)
+        k = self._heads(self.l_proj(l), bsz)
+        value_v = self._heads(self.values_v_proj(v), bsz)
+        value_l = self._heads(self.values_l_proj(l), bsz)
+        src_len = k.size(1)
+
+        attn = torch.bmm(q, k.transpose(1, 2))  # [bs*heads, n_img, n_text]
+        if self.stable_softmax_2d:
+            attn = attn - attn.max()
+        if self.clamp_min_for_underflow:
+            attn = torch.clamp(attn, min=-50000)
+        if self.clamp_max_for_overflow:
+            attn = torch.clamp(attn, max=50000)
+
+        attn_T = attn.transpose(1, 2)
+        attn_l = attn_T - torch.max(attn_T, dim=-1, keepdim=True)[0]
+        if self.clamp_min_for_underflow:
+            attn_l = torch.clamp(attn_l, min=-50000)
+        if self.clamp_max_for_overflow:
+            attn_l = torch.clamp(attn_l, max=50000)
+        if attention_mask_v is not None:
+            mv = attention_mask_v[:, None, None, :].repeat(1, self.num_heads, 1, 1).flatten(0, 1)
+            attn_l = attn_l.masked_fill(mv, float("-inf"))
+        attn_l = attn_l.softmax(dim=-1)
+
+        if attention_mask_l is not None:
+            ml = attention_mask_l[:, None, None, :].repeat(1, self.num_heads, 1, 1).flatten(0, 1)
+            attn = attn.masked_fill(ml, float("-inf"))
+        attn_v = attn.softmax(dim=-1)
+
+        probs_v = F.dropout(attn_v, p=self.dropout, training=self.training)
+        probs_l = F.dropout(attn_l, p=self.dropout, training=self.training)
+        out_v = torch.bmm(probs_v, value_l)
+        out_l = torch.bmm(probs_l, value_v)
+        out_v = out_v.view(bsz, self.num_heads, tgt_len, self.head_dim).transpose(1, 2).reshape(
+            bsz, tgt_len, self.embed_dim)
+        out_l = out_l.view(bsz, self.num_heads, src_len, self.head_dim).transpose(1, 2).reshape(
+            bsz, src_len, self.embed_dim)
+        return self.out_v_proj(out_v), self.out_l_proj(out_l)
+
+
+class BiAttentionBlock(nn.Module):
+    """Pre-LN bi-directional fusion with layer-scale gammas (reference fuse_modules.py:252-305)."""
+
+    def __init__(self, v_dim, l_dim, embed_dim, num_heads, dropout=0.1, drop_path=0.0,
+                 init_values=1e-4, cfg=None):
+        super().__init__()
+        self.layer_norm_v = nn.LayerNorm(v_dim)
+        self.layer_norm_l = nn.LayerNorm(l_dim)
+        self.attn = BiMultiHeadAttention(v_dim=v_dim, l_dim=l_dim, embed_dim=embed_dim,
+                                         num_heads=num_heads, dropout=dropout)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.gamma_v = nn.Parameter(init_values * torch.ones((v_dim)), requires_grad=True)
+        self.gamma_l = nn.Parameter(init_values * torch.ones((l_dim)), requires_grad=True)
+
+    def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
+        v = self.layer_norm_v(v)
+        l = self.layer_norm_l(l)
+        delta_v, delta_l = self.attn(v, l, attention_mask_v=attention_mask_v,
+                                     attention_mask_l=attention_mask_l)
+        v = v + self.drop_path(self.gamma_v * delta_v)
+        l = l + self.drop_path(self.gamma_l * delta_l)
+        return v, l
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Text-enhancer layer (reference transformer_vanilla.py:72-123): post-LN self-attention
+    over the tokens with the block-diagonal sub-sentence mask, then FFN."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 normalize_before=False):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.activation = _get_activation_fn(activation)
+        self.normalize_before = normalize_before
+        self.nhead = nhead
+
+    @staticmethod
+    def with_pos_embed(tensor, pos: Optional[Tensor]):
+        return tensor if pos is None else tensor + pos
+
+    def forward(self, src, src_mask: Optional[Tensor] = None,
+                src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None):
+        # [bs, T, T] -> [nhead*bs, T, T] by tiling, exactly as the reference does (:109-112).
+        # nn.MultiheadAttention indexes that dimension as b*nhead + h, so with bs > 1 the
+        # masks of different images are interleaved over heads; kept for output parity.
+        if src_mask.dim() == 3 and src_mask.shape[0] == src.shape[1]:
+            src_mask = src_mask.repeat(self.nhead, 1, 1)
+        q = k = self.with_pos_embed(src, pos)
+        src2 = self.self_attn(q, k, value=src, attn_mask=src_mask)[0]
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout2(src2))
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    """MSDA self-attention over all pixels of all levels (Q = S) + FFN, post-LN
+    (reference transformer_for_adapter.py:809-907)."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4,
+                 n_heads=8, n_points=4, use_adapter=False, **_unused):
+        super().__init__()
+        if use_adapter:
+            raise NotImplementedError("use_adapter (Adapter/MoE ablation) is outside the ZiRa path")
+        self.self_attn = MSDeformAttn(embed_dim=d_model, num_levels=n_levels, num_heads=n_heads,
+                                      num_points=n_points, batch_first=True)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation, d_model=d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.use_adapter = False
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, src):
+        src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(src2)), torch.zeros(1).to(src)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
+                key_padding_mask=None):
+        src2 = self.self_attn(query=self.with_pos_embed(src, pos), reference_points=reference_points,
+                              value=src, spatial_shapes=spatial_shapes,
+                              level_start_index=level_start_index, key_padding_mask=key_padding_mask)
+        src = self.norm1(src + self.dropout1(src2))
+        return self.forward_ffn(src)
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    """self-attn -> text cross-attn -> MSDA cross-attn -> FFN, post-LN
+    (reference transformer_for_adapter.py:910-1073)."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4,
+                 n_heads=8, n_points=4, use_text_feat_guide=False, use_text_cross_attention=False,
+                 use_adapter=False, **_unused):
+        super().__init__()
+        if use_adapter:
+            raise NotImplementedError("use_adapter (Adapter/MoE ablation) is outside the ZiRa path")
+        assert not use_text_feat_guide
+        ident_or_drop = lambda: nn.Dropout(dropout) if dropout > 0 else nn.Identity()
+        self.cross_attn = MSDeformAttn(embed_dim=d_model, num_levels=n_levels, num_heads=n_heads,
+                                       num_points=n_points, batch_first=True)
+        self.dropout1 = ident_or_drop()
+        self.norm1 = nn.LayerNorm(d_model)
+        if use_text_cross_attention:
+            self.ca_text = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+            self.catext_dropout = ident_or_drop()
+            self.catext_norm = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = ident_or_drop()
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation, d_model=d_ffn, batch_dim=1)
+        self.dropout3 = ident_or_drop()
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = ident_or_drop()
+        self.norm3 = nn.LayerNorm(d_model)
+        self.key_aware_proj = None
+        self.use_text_feat_guide = use_text_feat_guide
+        self.use_text_cross_attention = use_text_cross_attention
+        self.use_adapter = False
+
+    def rm_self_attn_modules(self):
+        self.self_attn = None
+        self.dropout2 = None
+        self.norm2 = None
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, tgt):
+        with torch.amp.autocast("cuda", enabled=False):  # reference :1004 keeps the FFN in fp32
+            tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(tgt2)), torch.zeros(1).to(tgt)
+
+    def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None, tgt_key_padding_mask=None,
+                tgt_reference_points=None, memory_text=None, text_attention_mask=None, memory=None,
+                memory_key_padding_mask=None, memory_level_start_index=None,
+                memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
+                cross_attn_mask=None):
+        assert cross_attn_mask is None
+        if self.self_attn is not None:
+            q = k = self.with_pos_embed(tgt, tgt_query_pos)
+            tgt2 = self.self_attn(q, k, tgt, attn_mask=self_attn_mask)[0]
+            tgt = self.norm2(tgt + self.dropout2(tgt2))
+        if self.use_text_cross_attention:
+            tgt2 = self.ca_text(self.with_pos_embed(tgt, tgt_query_pos), memory_text.transpose(0, 1),
+                                memory_text.transpose(0, 1), key_padding_mask=text_attention_mask)[0]
+            tgt = self.catext_norm(tgt + self.catext_dropout(tgt2))
+        tgt2 = self.cross_attn(
+            query=self.with_pos_embed(tgt, tgt_query_pos).transpose(0, 1),
+            reference_points=tgt_reference_points.transpose(0, 1).contiguous(),
+            value=memory.transpose(0, 1), spatial_shapes=memory_spatial_shapes,
+            level_start_index=memory_level_start_index, key_padding_mask=memory_key_padding_mask,
+        ).transpose(0, 1)
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        return self.forward_ffn(tgt)
+
+
+class TransformerEncoder(nn.Module):
+    """Per layer: BiAttention fusion -> text enhancer -> deformable image layer
+    (reference transformer_for_adapter.py:423-662)."""
+
+    def __init__(self, encoder_layer, num_layers, d_model=256, num_queries=300,
+                 enc_layer_share=False, text_enhance_layer=None, feature_fusion_layer=None,
+                 use_checkpoint=False, use_transformer_ckpt=False):
+        super().__init__()
+        self.layers, self.text_layers, self.fusion_layers = [], [], []
+        if num_layers > 0:
+            self.layers = _get_clones(encoder_layer, num_layers, layer_share=enc_layer_share)
+            if text_enhance_layer is not None:
+                self.text_layers = _get_clones(text_enhance_layer, num_layers, layer_share=enc_layer_share)
+            if feature_fusion_layer is not None:
+                self.fusion_layers = _get_clones(feature_fusion_layer, num_layers, layer_share=enc_layer_share)
+        self.query_scale = None
+        self.num_queries = num_queries
+        self.num_layers = num_layers
+        self.d_model = d_model
+        self.use_checkpoint = use_checkpoint
+        self.use_transformer_ckpt = use_transformer_ckpt
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel centres of every level, normalised by the valid extent and replicated over the
+        levels: [bs, S, L, 2] (reference :482-497).  ``spatial_shapes``: list of (H, W) or tensor."""
+        shapes = spatial_shapes.tolist() if torch.is_tensor(spatial_shapes) else spatial_shapes
+        refs = []
+        for lvl, (H_, W_) in enumerate(shapes):
+            H_, W_ = int(H_), int(W_)
+            ref_y, ref_x = torch.meshgrid(
+                torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device),
+                torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device), indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H_)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W_)
+            refs.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(refs, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src: Tensor, pos: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                valid_ratios: Tensor, key_padding_mask: Tensor, memory_text: Tensor = None,
+                text_attention_mask: Tensor = None, pos_text: Tensor = None,
+                text_self_attention_masks: Tensor = None, position_ids: Tensor = None,
+                spatial_shapes_list=None):
+        output = src
+        if self.num_layers > 0:
+            reference_points = self.get_reference_points(
+                spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes,
+                valid_ratios, device=src.device)
+        if self.text_layers:
+            bs, n_text, _ = memory_text.shape
+            if pos_text is None and position_ids is None:
+                pos_text = (torch.arange(n_text, device=memory_text.device).float()
+                            .unsqueeze(0).unsqueeze(-1).repeat(bs, 1, 1))
+                pos_text = get_sine_pos_embed(pos_text, num_pos_feats=256, exchange_xy=False)
+            if position_ids is not None:
+                pos_text = get_sine_pos_embed(position_ids[..., None], num_pos_feats=256, exchange_xy=False)
+
+        adapter_loss = torch.zeros(1).to(src)
+        for layer_id, layer in enumerate(self.layers):
+            if self.fusion_layers:
+                output, memory_text = self.fusion_layers[layer_id](
+                    v=output, l=memory_text, attention_mask_v=key_padding_mask,
+                    attention_mask_l=text_attention_mask)
+            if self.text_layers:
+                memory_text = self.text_layers[layer_id](
+                    src=memory_text.transpose(0, 1),
+                    src_mask=~text_self_attention_masks,  # True = do not attend
+                    src_key_padding_mask=text_attention_mask,
+                    pos=(pos_text.transpose(0, 1) if pos_text is not None else None),
+                ).transpose(0, 1)
+            output, adapter_loss_ = layer(src=output, pos=pos, reference_points=reference_points,
+                                          spatial_shapes=spatial_shapes,
+                                          level_start_index=level_start_index,
+                                          key_padding_mask=key_padding_mask)
+            adapter_loss = adapter_loss + adapter_loss_
+        return output, memory_text, adapter_loss
+
+
+class TransformerDecoder(nn.Module):
+    """Six layers with iterative box refinement (reference transformer_for_adapter.py:665-806)."""
+
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False, d_model=256,
+                 query_dim=4, num_feature_levels=1):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers) if num_layers > 0 else []
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+        assert return_intermediate, "support return_intermediate only"
+        assert query_dim in [2, 4]
+        self.query_dim = query_dim
+        self.num_feature_levels = num_feature_levels
+        self.ref_point_head = MLP(query_dim // 2 * d_model, d_model, d_model, 2)
+        self.query_pos_sine_scale = None
+        self.query_scale = None
+        self.bbox_embed = None
+        self.class_embed = None
+        self.d_model = d_model
+        self.ref_anchor_head = None
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, refpoints_unsigmoid=None,
+                level_start_index=None, spatial_shapes=None, valid_ratios=None, memory_text=None,
+                text_attention_mask=None):
+        output = tgt
+        intermediate = []
+        reference_points = refpoints_unsigmoid.sigmoid()
+        ref_points = [reference_points]
+        adapter_loss = torch.zeros(1).to(tgt)
+        for layer_id, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                reference_points_input = (reference_points[:, :, None]
+                                          * torch.cat([valid_ratios, valid_ratios], -1)[None, :])
+            else:
+                reference_points_input = reference_points[:, :, None] * valid_ratios[None, :]
+            query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :])
+            raw_query_pos = self.ref_point_head(query_sine_embed)
+            pos_scale = self.query_scale(output) if self.query_scale is not None else 1
+            query_pos = pos_scale * raw_query_pos
+
+            output, adapter_loss_ = layer(
+                tgt=output, tgt_query_pos=query_pos, tgt_query_sine_embed=query_sine_embed,
+                tgt_key_padding_mask=tgt_key_padding_mask,
+                tgt_reference_points=reference_points_input, memory_text=memory_text,
+                text_attention_mask=text_attention_mask, memory=memory,
+                memory_key_padding_mask=memory_key_padding_mask,
+                memory_level_start_index=level_start_index, memory_spatial_shapes=spatial_shapes,
+                memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask)
+            adapter_loss = adapter_loss + adapter_loss_
+
+            if self.bbox_embed is not None:  # iterative refinement, detached between layers
+                delta_unsig = self.bbox_embed[layer_id](output)
+                new_reference_points = (delta_unsig + inverse_sigmoid(reference_points)).sigmoid()
+                reference_points = new_reference_points.detach()
+                ref_points.append(new_reference_points)
+            intermediate.append(self.norm(output))
+        return [[x.transpose(0, 1) for x in intermediate],
+                [r.transpose(0, 1) for r in ref_points], adapter_loss]
+
+
+class Transformer(nn.Module):
+    """Encoder -> two-stage query selection (top-900 by max token logit) -> decoder
+    (reference transformer_for_adapter.py:41-415)."""
+
+    def __init__(self, d_model=256, nhead=8, num_queries=300, num_encoder_layers=6,
+                 num_unicoder_layers=0, num_decoder_layers=6, dim_feedforward=2048, dropout=0.0,
+                 activation="relu", normalize_before=False, return_intermediate_dec=False,
+                 query_dim=4, num_patterns=0, num_feature_levels=1, enc_n_points=4, dec_n_points=4,
+                 learnable_tgt_init=False, two_stage_type="no", embed_init_tgt=False,
+                 use_text_enhancer=False, use_fusion_layer=False, use_checkpoint=False,
+                 use_transformer_ckpt=False, use_text_cross_attention=False, text_dropout=0.1,
+                 fusion_dropout=0.1, fusion_droppath=0.0, use_adapter=False, **_unused):
+        super().__init__()
+        assert query_dim == 4
+        assert not normalize_before
+        assert learnable_tgt_init, "why not learnable_tgt_init"
+        assert two_stage_type in ["no", "standard"]
+        self.num_feature_levels = num_feature_levels
+        self.num_encoder_layers = num_encoder_layers
+        self.num_unicoder_layers = num_unicoder_layers
+        self.num_decoder_layers = num_decoder_layers
+        self.num_queries = num_queries
+
+        encoder_layer = DeformableTransformerEncoderLayer(
+            d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, enc_n_points,
+            use_adapter=use_adapter)
+        text_enhance_layer = TransformerEncoderLayer(
+            d_model=d_model, nhead=nhead // 2, dim_feedforward=dim_feedforward // 2,
+            dropout=text_dropout) if use_text_enhancer else None
+        feature_fusion_layer = BiAttentionBlock(
+            v_dim=d_model, l_dim=d_model, embed_dim=dim_feedforward // 2, num_heads=nhead // 2,
+            dropout=fusion_dropout, drop_path=fusion_droppath) if use_fusion_layer else None
+        self.encoder = TransformerEncoder(
+            encoder_layer, num_encoder_layers, d_model=d_model, num_queries=num_queries,
+            text_enhance_layer=text_enhance_layer, feature_fusion_layer=feature_fusion_layer,
+            use_checkpoint=use_checkpoint, use_transformer_ckpt=use_transformer_ckpt)
+
+        decoder_layer = DeformableTransformerDecoderLayer(
+            d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, dec_n_points,
+            use_text_cross_attention=use_text_cross_attention, use_adapter=use_adapter)
+        self.decoder = TransformerDecoder(
+            decoder_layer, num_decoder_layers, nn.LayerNorm(d_model),
+            return_intermediate=return_intermediate_dec, d_model=d_model, query_dim=query_dim,
+            num_feature_levels=num_feature_levels)
+
+        self.d_model = d_model
+        self.nhead = nhead
+        self.dec_layers = num_decoder_layers
+        self.num_patterns = num_patterns if isinstance(num_patterns, int) else 0
+        if num_feature_levels > 1:
+            self.level_embed = (nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+                                if num_encoder_layers > 0 else None)
+        self.learnable_tgt_init = learnable_tgt_init
+        self.embed_init_tgt = embed_init_tgt
+        if (two_stage_type != "no" and embed_init_tgt) or two_stage_type == "no":
+            self.tgt_embed = nn.Embedding(self.num_queries, d_model)
+            nn.init.normal_(self.tgt_embed.weight.data)
+        else:
+            self.tgt_embed = None
+        self.two_stage_type = two_stage_type
+        if two_stage_type == "standard":
+            self.enc_output = nn.Linear(d_model, d_model)
+            self.enc_output_norm = nn.LayerNorm(d_model)
+            self.two_stage_wh_embedding = None
+        if two_stage_type == "no":
+            self.init_ref_points(num_queries)
+        self.enc_out_class_embed = None
+        self.enc_out_bbox_embed = None
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        if self.num_feature_levels > 1 and self.level_embed is not None:
+            nn.init.normal_(self.level_embed)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_H = torch.sum(~mask[:, :, 0], 1)
+        valid_W = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+    def init_ref_points(self, use_num_queries):
+        self.refpoint_embed = nn.Embedding(use_num_queries, 4)
+
+    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None):
+        src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes = [], [], [], []
+        for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
+            bs, c, h, w = src.shape
+            shapes.append((h, w))
+            pos_embed = pos_embed.flatten(2).transpose(1, 2)
+            if self.num_feature_levels > 1 and self.level_embed is not None:
+                pos_embed = pos_embed + self.level_embed[lvl].view(1, 1, -1)
+            lvl_pos_embed_flatten.append(pos_embed)
+            src_flatten.append(src.flatten(2).transpose(1, 2))
+            mask_flatten.append(mask.flatten(1))
+        src_flatten = torch.cat(src_flatten, 1)
+        mask_flatten = torch.cat(mask_flatten, 1)
+        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        # the op wants the level table on the device (int64); the host copy `shapes` is kept for
+        # everything that only needs Python ints, so nothing reads the device tensor back
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flatten.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)),
+                                       spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+
+        memory, memory_text, adapter_loss1 = self.encoder(
+            src_flatten, pos=lvl_pos_embed_flatten, level_start_index=level_start_index,
+            spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, key_padding_mask=mask_flatten,
+            memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"],
+            position_ids=text_dict["position_ids"],
+            text_self_attention_masks=text_dict["text_self_attention_masks"],
+            spatial_shapes_list=shapes)
+        text_dict["encoded_text"] = memory_text
+
+        if self.two_stage_type == "standard":
+            output_memory, output_proposals = gen_encoder_output_proposals(memory, mask_flatten, shapes)
+            output_memory = self.enc_output_norm(self.enc_output(output_memory))
+            enc_outputs_class_unselected = self.enc_out_class_embed(output_memory, text_dict)
+            topk_logits = enc_outputs_class_unselected.max(-1)[0]
+            enc_outputs_coord_unselected = self.enc_out_bbox_embed(output_memory) + output_proposals
+            topk_proposals = torch.topk(topk_logits, self.num_queries, dim=1)[1]  # bs, nq (int64)
+            gather4 = topk_proposals.unsqueeze(-1).repeat(1, 1, 4)
+            refpoint_embed_undetach = torch.gather(enc_outputs_coord_unselected, 1, gather4)
+            refpoint_embed_ = refpoint_embed_undetach.detach()
+            init_box_proposal = torch.gather(output_proposals, 1, gather4).sigmoid()
+            tgt_undetach = torch.gather(output_memory, 1,
+                                        topk_proposals.unsqueeze(-1).repeat(1, 1, self.d_model))
+            if self.embed_init_tgt:
+                tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
+            else:
+                tgt_ = tgt_undetach.detach()
+            if refpoint_embed is not None:
+                refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
+                tgt = torch.cat([tgt, tgt_], dim=1)
+            else:
+                refpoint_embed, tgt = refpoint_embed_, tgt_
+        else:
+            tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
+            refpoint_embed_ = self.refpoint_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
+            if refpoint_embed is not None:
+                refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
+                tgt = torch.cat([tgt, tgt_], dim=1)
+            else:
+                refpoint_embed, tgt = refpoint_embed_, tgt_
+            init_box_proposal = refpoint_embed_.sigmoid()
+            topk_proposals = None
+
+        hs, references, adapter_loss2 = self.decoder(
+            tgt=tgt.transpose(0, 1), memory=memory.transpose(0, 1),
+            memory_key_padding_mask=mask_flatten, pos=lvl_pos_embed_flatten.transpose(0, 1),
+            refpoints_unsigmoid=refpoint_embed.transpose(0, 1), level_start_index=level_start_index,
+            spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, tgt_mask=attn_mask,
+            memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"])
+
+        if self.two_stage_type == "standard":
+            hs_enc = tgt_undetach.unsqueeze(0)
+            ref_enc = refpoint_embed_undetach.sigmoid().unsqueeze(0)
+        else:
+            hs_enc = ref_enc = None
+        self.last_topk_proposals = topk_proposals  # exposed for the bit-exact index parity tests
+        return hs, references, hs_enc, ref_enc, init_box_proposal, adapter_loss1 + adapter_loss2
+
+
+def build_transformer(args):
+    return Transformer(
+        d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads,
+        num_queries=args.num_queries, dim_feedforward=args.dim_feedforward,
+        num_encoder_layers=args.enc_layers, num_decoder_layers=args.dec_layers,
+        normalize_before=args.pre_norm, return_intermediate_dec=True, query_dim=args.query_dim,
+        activation=args.transformer_activation, num_patterns=args.num_patterns,
+        num_feature_levels=args.num_feature_levels, enc_n_points=args.enc_n_points,
+        dec_n_points=args.dec_n_points, learnable_tgt_init=True, two_stage_type=args.two_stage_type,
+        embed_init_tgt=args.embed_init_tgt, use_text_enhancer=args.use_text_enhancer,
+        use_fusion_layer=args.use_fusion_layer, use_checkpoint=args.use_checkpoint,
+        use_transformer_ckpt=args.use_transformer_ckpt,
+        use_text_cross_attention=args.use_text_cross_attention, text_dropout=args.text_dropout,
+        fusion_dropout=args.fusion_dropout, fusion_droppath=args.fusion_droppath,
+        use_adapter=getattr(args, "use_adapter", False))

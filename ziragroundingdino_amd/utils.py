@@ -1,0 +1,205 @@
+"""Small building blocks of the cross-modal transformer, with the reference's names.
+
+Mirrors groundingdino/models/GroundingDINO/utils.py and util/misc.py (only what the hot path
+uses): ``MLP`` (:171), ``ContrastiveEmbed`` (:234-269), ``recover_to_cls_logits`` (:312-320),
+``gen_sineembed_for_position`` (:204-231), ``get_sine_pos_embed`` (:24-53),
+``gen_encoder_output_proposals`` (:56-116), ``inverse_sigmoid`` (util/misc.py:704-708),
+``NestedTensor`` / ``nested_tensor_from_tensor_list`` (util/misc.py:440-499).
+
+Differences that do not change results: ``recover_to_cls_logits`` is one masked max per image
+instead of a Python loop over categories (the reference loops B x n_cat with boolean indexing,
+each iteration a device sync).
+"""
+import copy
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+
+def _get_clones(module, N, layer_share=False):
+    if layer_share:
+        return nn.ModuleList([module for _ in range(N)])
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def _get_activation_fn(activation, d_model=256, batch_dim=0):
+    table = {"relu": F.relu, "gelu": F.gelu, "glu": F.glu, "selu": F.selu}
+    if activation in table:
+        return table[activation]
+    if activation == "prelu":
+        return nn.PReLU()
+    raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+
+
+def inverse_sigmoid(x, eps=1e-3):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+class MLP(nn.Module):
+    """num_layers Linear layers with ReLU in between (state-dict keys ``layers.{i}.*``)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+def _interleaved_sincos(arg: Tensor) -> Tensor:
+    """[..., n] -> [..., n] with sin on even and cos on odd channels (pairs share a frequency)."""
+    return torch.stack((arg[..., 0::2].sin(), arg[..., 1::2].cos()), dim=-1).flatten(-2)
+
+
+def _dim_t(n: int, temperature: float, device) -> Tensor:
+    i = torch.arange(n, dtype=torch.float32, device=device)
+    return temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / n)
+
+
+def get_sine_pos_embed(pos_tensor: Tensor, num_pos_feats: int = 128, temperature: int = 10000,
+                       exchange_xy: bool = True) -> Tensor:
+    """[..., n] positions -> [..., n*num_pos_feats] sine embedding (reference utils.py:24-53)."""
+    dim_t = _dim_t(num_pos_feats, temperature, pos_tensor.device)
+    parts = [_interleaved_sincos(x * (2 * math.pi) / dim_t)
+             for x in pos_tensor.split([1] * pos_tensor.shape[-1], dim=-1)]
+    if exchange_xy:
+        parts[0], parts[1] = parts[1], parts[0]
+    return torch.cat(parts, dim=-1)
+
+
+def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
+    """[nq, bs, 2|4] (x, y[, w, h]) in [0,1] -> [nq, bs, 256|512], ordered (y, x[, w, h]);
+    128 features each, temperature 10000 (reference utils.py:204-231)."""
+    dim_t = _dim_t(128, 10000, pos_tensor.device)
+    emb = [_interleaved_sincos(pos_tensor[:, :, i, None] * (2 * math.pi) / dim_t)
+           for i in range(pos_tensor.size(-1))]
+    if pos_tensor.size(-1) == 2:
+        return torch.cat((emb[1], emb[0]), dim=2)
+    if pos_tensor.size(-1) == 4:
+        return torch.cat((emb[1], emb[0], emb[2], emb[3]), dim=2)
+    raise ValueError("Unknown pos_tensor shape(-1):{}".format(pos_tensor.size(-1)))
+
+
+def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor, spatial_shapes,
+                                 learnedwh=None):
+    """Two-stage proposals: one box per pixel, centre = pixel centre / valid size, side
+    0.05 * 2^level; returned un-sigmoided, +inf where padded or outside (0.01, 0.99)
+    (reference utils.py:56-116).  ``spatial_shapes`` may be a tensor or a list of (H, W)."""
+    N, S, C = memory.shape
+    shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist() if torch.is_tensor(spatial_shapes)
+                                            else spatial_shapes)]
+    proposals = []
+    cur = 0
+    for lvl, (H, W) in enumerate(shapes):
+        m = memory_padding_mask[:, cur:cur + H * W].view(N, H, W)
+        valid_H = (~m[:, :, 0]).sum(1)
+        valid_W = (~m[:, 0, :]).sum(1)
+        gy, gx = torch.meshgrid(
+            torch.linspace(0, H - 1, H, dtype=torch.float32, device=memory.device),
+            torch.linspace(0, W - 1, W, dtype=torch.float32, device=memory.device), indexing="ij")
+        grid = torch.stack([gx, gy], -1)                                   # H, W, 2 (x, y)
+        scale = torch.stack([valid_W, valid_H], 1).view(N, 1, 1, 2)
+        grid = (grid.unsqueeze(0).expand(N, -1, -1, -1) + 0.5) / scale
+        if learnedwh is not None:
+            wh = torch.ones_like(grid) * learnedwh.sigmoid() * (2.0 ** lvl)
+        else:
+            wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        proposals.append(torch.cat((grid, wh), -1).view(N, -1, 4))
+        cur += H * W
+    output_proposals = torch.cat(proposals, 1)
+    valid = ((output_proposals > 0.01) & (output_proposals < 0.99)).all(-1, keepdim=True)
+    output_proposals = torch.log(output_proposals / (1 - output_proposals))
+    output_proposals = output_proposals.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf"))
+    output_proposals = output_proposals.masked_fill(~valid, float("inf"))
+    output_memory = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0)
+    output_memory = output_memory.masked_fill(~valid, 0.0)
+    return output_memory, output_proposals
+
+
+class ContrastiveEmbed(nn.Module):
+    """Parameter-free classifier: logits[b, q, t] = <x[b, q], text[b, t]>, -inf on padded
+    tokens and padded out to ``max_text_len`` columns (reference utils.py:234-269)."""
+
+    def __init__(self, max_text_len=256):
+        super().__init__()
+        self.max_text_len = max_text_len
+
+    def forward(self, x, text_dict):
+        assert isinstance(text_dict, dict)
+        y = text_dict["encoded_text"]
+        text_token_mask = text_dict["text_token_mask"]
+        res = x @ y.transpose(-1, -2)
+        res = res.masked_fill(~text_token_mask[:, None, :], float("-inf"))
+        pad = self.max_text_len - res.shape[-1]
+        if pad > 0:
+            res = F.pad(res, (0, pad), value=float("-inf"))
+        return res
+
+
+def recover_to_cls_logits(logits: Tensor, cate_to_token_mask_list: List[Tensor],
+                          for_fill=float("-inf")) -> Tensor:
+    """token logits -> category logits: new[b, q, c] = max over the tokens of category c,
+    ``for_fill`` elsewhere; same shape as ``logits`` (reference utils.py:312-320)."""
+    assert logits.shape[0] == len(cate_to_token_mask_list)
+    new_logits = torch.full(logits.shape, for_fill, device=logits.device, dtype=logits.dtype)
+    for bid, mask in enumerate(cate_to_token_mask_list):          # mask: [n_cat, n_token] bool
+        n_cat, n_tok = mask.shape
+        if n_cat == 0:
+            continue
+        tok = logits[bid, :, :n_tok]                                # [Q, n_tok]
+        per_cat = tok[:, None, :].masked_fill(~mask[None], float("-inf")).max(dim=-1)[0]
+        new_logits[bid, :, :n_cat] = per_cat
+    return new_logits
+
+
+class NestedTensor(object):
+    """(tensors [B,C,H,W], mask [B,H,W] True = padding) pair (reference util/misc.py:440-470)."""
+
+    def __init__(self, tensors, mask: Optional[Tensor]):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, device):
+        mask = self.mask.to(device) if self.mask is not None else None
+        return NestedTensor(self.tensors.to(device), mask)
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    @property
+    def device(self):
+        return self.tensors.device
+
+
+def nested_tensor_from_tensor_list(tensor_list) -> NestedTensor:
+    """Pad a list of [C,Hi,Wi] images to the common max size (reference util/misc.py:474-499)."""
+    if hasattr(tensor_list, "tensor") and hasattr(tensor_list, "image_sizes"):  # ImageList-like
+        sizes = tensor_list.image_sizes
+        batch = tensor_list.tensor
+        mask = torch.ones(batch.shape[0], batch.shape[2], batch.shape[3], dtype=torch.bool,
+                          device=batch.device)
+        for m, (h, w) in zip(mask, sizes):
+            m[:h, :w] = False
+        return NestedTensor(batch, mask)
+    if tensor_list[0].ndim != 3:
+        raise ValueError("not supported")
+    c = tensor_list[0].shape[0]
+    h = max(img.shape[1] for img in tensor_list)
+    w = max(img.shape[2] for img in tensor_list)
+    tensor = torch.zeros((len(tensor_list), c, h, w), dtype=tensor_list[0].dtype,
+                         device=tensor_list[0].device)
+    mask = torch.ones((len(tensor_list), h, w), dtype=torch.bool, device=tensor_list[0].device)
+    for img, pad_img, m in zip(tensor_list, tensor, mask):
+        pad_img[:, :img.shape[1], :img.shape[2]].copy_(img)
+        m[:img.shape[1], :img.shape[2]] = False
+    return NestedTensor(tensor, mask)
