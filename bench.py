@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the hot path on N MI355X GPUs of one node.
+"""bench.py -- images/s of the ZiRa training step (GroundingDINO-T, 800x1333) on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One JSON line on rank 0 (contract in the task statement).  A "step" is one forward + backward
-pass of the hot path over one synthetic batch of `--batch` (default 2) 800x1333 images per GPU.
+One JSON line on rank 0.  A "step" is one pass of the hot path over one synthetic minibatch of
+`--batch` (default 2) uint8 800x1333 images per GPU, i.e. BASELINE.json configs[1] per rank:
+frozen Swin-T + BERT-base front end (random init -- no checkpoint offline), both ZiRa side
+branches (fused RSB epilogue kernels), 6 encoder + 6 decoder layers with 12 MSDA forward and
+12 backward calls on the gfx950 kernels, Hungarian matching + losses, backward, all-reduce of
+the 4.6 M side-branch gradients (RCCL, N > 1), clip 0.1, AdamW -- nothing skipped.
 
-Workloads (``--workload``):
-  msda_decoder   the MSDA op at the north-star shape B=2,Q=900,M=8,D=32,L=4,P=4,S=22223
-                 (SURVEY.md section 8d): 1 fwd + 1 bwd per step, x `--calls` per step
-                 (default 6 = the six decoder layers' cross-attention calls of one model step).
-
-`roofline` is measured live: HIP events (on the stream the kernels are launched on -- torch's
-current stream, which is what `_C` hands to the C ABI) around back-to-back launches of the
-forward and of the backward entry point; the dominant one (backward) is reported.
-`cpu_baseline` times the CPU oracle (oracle/msda_oracle.c, OpenMP over all host cores) on a
-bounded number of repetitions of the same workload, rank 0 at N=1 only.
+`roofline`: every MSDA call of the timed steps is bracketed by HIP events on its launch stream
+(`_C.TIMING`); calls are grouped into decoder shape (Q = 900, the north-star shape) and
+encoder shape (Q = S), forward / backward, and priced with the algorithmic bytes of SURVEY.md
+section 8(d).  The top-level object is the north-star kernel pair ("ms_deform_attn fwd+bwd at B=2,
+Q=900, L=4, M=8, P=4"); `kernels` lists all four groups, `dominant` names the one with the
+largest share of the step.
+`cpu_baseline` (rank 0, N = 1): the same training step on the host cores -- this package's
+model on CPU tensors with the two native MSDA entry points served by the CPU oracle (kind
+"port"; the reference's own Python cannot travel to the GPU box) -- on a bounded sample.
 """
 import argparse
 import json
@@ -25,7 +28,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -44,9 +46,7 @@ def msda_algorithmic_bytes(B, S, M, D, L, Q, P, esize=4):
     O = B * Q * M * D * esize
     G = B * Q * M * L * P * 4 * D * esize
     Vt = min(V, G)
-    fwd = Vt + Lc + A + O
-    bwd = O + Vt + 2 * Lc + 2 * A + V
-    return fwd, bwd
+    return Vt + Lc + A + O, O + Vt + 2 * Lc + 2 * A + V
 
 
 def make_msda_inputs(B, Q, M, D, shapes, P, seed, device):
@@ -62,50 +62,93 @@ def make_msda_inputs(B, Q, M, D, shapes, P, seed, device):
     return [t.to(device) for t in (value, sh, start, loc, attn, grad_out)]
 
 
-def time_events(fn, iters, warmup=5):
-    """Average device time of fn() over `iters` back-to-back launches on the current stream."""
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3  # seconds
-
-
-def cpu_baseline_msda(B, Q, M, D, shapes, P, budget_s=12.0):
-    """Oracle (kind 'port') on the host cores: fwd+bwd of the same workload, bounded sample."""
+def cpu_baseline_step(height=800, width=1333, sample_div=2, threads=None):
+    """The same training step on the host cores, bounded: ONE step at batch 1 on an image whose
+    sides are 1/`sample_div` of the benchmark's (1/4 of the pixels by default; a full-size step
+    takes several minutes of CPU time), torch CPU ops for everything dense and the CPU oracle
+    for the MSDA op.  Returns (equivalent full-size images, seconds, threads, description): the
+    cost of the step is close to linear in the pixel count (Swin, the encoder's S tokens, the
+    fusion S x T scores; only the 900-query decoder and BERT are fixed), so the sample counts
+    as 1/sample_div^2 of a full-size image -- which flatters the CPU.
+    """
     from oracle import msda_oracle
+    from ziragroundingdino_amd import _C
+    from ziragroundingdino_amd.config import zira_swint_config
+    from ziragroundingdino_amd.groundingdino import build_model
+    from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
 
     msda_oracle.build()
-    value, sh, start, loc, attn, go = [t.cpu().numpy() for t in
-                                       make_msda_inputs(B, Q, M, D, shapes, P, 0, "cpu")]
     cores = os.cpu_count() or 1
-    msda_oracle.set_num_threads(cores)
-    msda_oracle.msda_forward(value, sh, start, loc, attn)  # warm
-    n, t0 = 0, time.perf_counter()
-    while True:
-        msda_oracle.msda_forward(value, sh, start, loc, attn)
-        msda_oracle.msda_backward(go, value, sh, start, loc, attn)
-        n += 1
+    threads = threads or min(cores, 32)  # torch CPU ops stop scaling (and thrash) far below 256 threads
+    torch.set_num_threads(threads)
+    msda_oracle.set_num_threads(threads)
+    saved = _C.ms_deform_attn_forward, _C.ms_deform_attn_backward
+    # cpu_baseline leg only: the checker stands in for the kernels on CPU tensors
+    _C.ms_deform_attn_forward = lambda v, s, st, l, a, step: torch.from_numpy(msda_oracle.msda_forward(
+        v.detach().numpy(), s.numpy(), st.numpy(), l.detach().numpy(), a.detach().numpy()))
+    _C.ms_deform_attn_backward = lambda v, s, st, l, a, go, step: [torch.from_numpy(x) for x in msda_oracle.msda_backward(
+        go.detach().numpy(), v.detach().numpy(), s.numpy(), st.numpy(), l.detach().numpy(), a.detach().numpy())]
+    try:
+        torch.manual_seed(0)
+        model = build_model(zira_swint_config(device="cpu")).train()
+        trainer = ZiraTrainer(model)
+        h, w = height // sample_div, width // sample_div
+        data = synthetic_batch(1, h, w, device="cpu")
+        t0 = time.perf_counter()
+        trainer.run_step(data)
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 500:
-            break
-    return n, el, msda_oracle.num_threads()
+        desc = ("1 full training step at batch 1 on a %dx%d image (1/%d of the %dx%d pixels; counted as "
+                "that fraction of an image) on the host: this package's model on CPU tensors (torch CPU "
+                "ops, %d of %d cores) with MSDA served by oracle/msda_oracle.c (OpenMP), %.1f s"
+                % (h, w, sample_div * sample_div, height, width, threads, cores, el))
+        return (h * w) / float(height * width), el, threads, desc
+    finally:
+        _C.ms_deform_attn_forward, _C.ms_deform_attn_backward = saved
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the north-star kernel pair from the committed rocprofv3 PMC summary
+    (profiles/*_msda_pmc_summary.json; FETCH_SIZE doubled as the gfx950 note in
+    MI355X_MICROARCH.md prescribes for 16-B-per-lane loads, WRITE_SIZE as is).  PMC passes cannot
+    run inside bench.py; the file is produced by scripts/collect_profiles.sh on the same shapes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_msda_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        dec = json.load(open(files[-1]))["decoder"]
+        total = sum(k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"] for k in dec.values())
+        return {"traffic": total, "traffic_source": os.path.relpath(files[-1], ROOT) +
+                " (uniform sampling locations at the same shape; sum of msda_fwd_lean, msda_bwd_items, msda_bwd_tiles)"}
+    except Exception:
+        return None
+
+
+def summarize_timing(records, B_expect):
+    """Group the (kind, dims, e0, e1) records of `_C.TIMING` -> {group: (calls, avg seconds, dims)}."""
+    groups = {}
+    for kind, dims, e0, e1 in records:
+        B, S, M, D, L, Q, P = dims
+        shape = "enc" if Q == S else "dec"
+        key = "%s_%s" % (kind, shape)
+        ms = e0.elapsed_time(e1)
+        g = groups.setdefault(key, [0, 0.0, dims])
+        g[0] += 1
+        g[1] += ms * 1e-3
+    return {k: (v[0], v[1] / v[0], v[2]) for k, v in groups.items()}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="msda_decoder")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU per step")
-    ap.add_argument("--calls", type=int, default=6, help="MSDA fwd+bwd pairs per step")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=1,
+                    help="cpu_baseline runs one step on an image with sides divided by this")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,55 +162,65 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ziragroundingdino_amd import _C, _lib
+    from ziragroundingdino_amd.config import zira_swint_config
+    from ziragroundingdino_amd.groundingdino import build_model
+    from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
 
-    _lib.load()
-    B, Q, M, D, P = args.batch, 900, 8, 32, 4
-    shapes = NORTH_STAR_SHAPES
-    L = len(shapes)
-    S = sum(h * w for h, w in shapes)
-    # each rank owns its own minibatch (data parallel, no data-path collective inside MSDA)
-    value, sh, start, loc, attn, go = make_msda_inputs(B, Q, M, D, shapes, P, seed=rank, device=dev)
-
-    def fwd():
-        return _C.ms_deform_attn_forward(value, sh, start, loc, attn, 64)
-
-    def bwd():
-        return _C.ms_deform_attn_backward(value, sh, start, loc, attn, go, 64)
-
-    def step():
-        for _ in range(args.calls):
-            fwd()
-            bwd()
+    _lib.load()  # fail loudly if the HIP extension is missing
+    torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
+    model = build_model(zira_swint_config(device=str(dev))).to(dev).train()
+    trainer = ZiraTrainer(model)
+    data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard
 
     for _ in range(args.warmup):
-        step()
+        trainer.run_step(data)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    _C.TIMING = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        trainer.run_step(data)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    records, _C.TIMING = _C.TIMING, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel, measured live with events on the launch stream ----
-    fwd_bytes, bwd_bytes = msda_algorithmic_bytes(B, S, M, D, L, Q, P)
-    t_fwd = time_events(fwd, 200)
-    t_bwd = time_events(bwd, 200)
-    t_pair = time_events(lambda: (fwd(), bwd()), 200)
-
     if rank == 0:
-        images = args.steps * B * world
+        groups = summarize_timing(records, args.batch)
+        kernels = {}
+        for key, (calls, avg_s, dims) in sorted(groups.items()):
+            fb, bb = msda_algorithmic_bytes(*dims)
+            nbytes = fb if key.startswith("fwd") else bb
+            kernels[key] = {"calls_per_step": calls / args.steps, "avg_us": avg_s * 1e6,
+                            "algorithmic_bytes": nbytes, "achieved": nbytes / avg_s / 1e9,
+                            "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                            "share_of_step": calls * avg_s / elapsed,
+                            "dims_BSMDLQP": list(dims)}
+        dominant = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
+        roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                    "kernels": kernels, "dominant": dominant}
+        pmc = pmc_traffic()
+        if pmc:
+            roofline.update(pmc)
+        if "fwd_dec" in kernels and "bwd_dec" in kernels:
+            f, b = kernels["fwd_dec"], kernels["bwd_dec"]
+            t_pair = (f["avg_us"] + b["avg_us"]) * 1e-6
+            nbytes = f["algorithmic_bytes"] + b["algorithmic_bytes"]
+            roofline.update({"kernel": "ms_deform_attn fwd+bwd, decoder cross-attention shape "
+                                       "B=%d,S=%d,M=%d,D=%d,L=%d,Q=%d,P=%d" % tuple(f["dims_BSMDLQP"]),
+                             "achieved": nbytes / t_pair / 1e9, "frac": nbytes / t_pair / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes": nbytes, "avg_us": t_pair * 1e6})
+        images = args.steps * args.batch * world
         line = {
-            "metric": "images/sec fwd+bwd GroundingDINO-T+ZiRa @800x1333 (hot-path workload: see config)",
+            "metric": "images/sec fwd+bwd GroundingDINO-T+ZiRa @800x1333",
             "value": images / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -180,39 +233,21 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d x (ms_deform_attn fwd+bwd) per step at B=%d,Q=%d,M=%d,D=%d,L=%d,P=%d,S=%d"
-                            % (args.workload, args.calls, B, Q, M, D, L, P, S),
-                "images_per_gpu": B,
+                "workload": "configs[1]: GroundingDINO-T (Swin-T + BERT-base, random init) frozen-backbone "
+                            "ZiRa side-branch fine-tune step, %d x %dx%d images per GPU, 900 queries, "
+                            "full fwd+loss+bwd+clip+AdamW" % (args.batch, args.height, args.width),
+                "images_per_gpu": args.batch,
+                "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world,
-                "kernel_variant": _lib.variant_f32(D),
+                "trainable_values": int(trainer.flat_grad.numel()),
+                "msda_kernel_variant": _lib.variant_f32(32),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "ms_deform_attn backward (memset + msda_bwd kernel)",
-                "achieved": bwd_bytes / t_bwd / 1e9,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": bwd_bytes / t_bwd / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes": bwd_bytes,
-                "avg_us": t_bwd * 1e6,
-                "fwd": {"achieved": fwd_bytes / t_fwd / 1e9, "frac": fwd_bytes / t_fwd / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes": fwd_bytes, "avg_us": t_fwd * 1e6},
-                "fwd_bwd": {"achieved": (fwd_bytes + bwd_bytes) / t_pair / 1e9,
-                            "frac": (fwd_bytes + bwd_bytes) / t_pair / 1e9 / HBM_PEAK_GBS,
-                            "avg_us": t_pair * 1e6},
-            },
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            n, el, cores = cpu_baseline_msda(B, Q, M, D, shapes, P)
-            line["cpu_baseline"] = {
-                "value": n * B / args.calls / el,
-                "unit": "images/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": "%d x (oracle msda fwd+bwd, same shape, OpenMP %d threads) in %.1f s; "
-                          "scaled by %d calls per step" % (n, cores, el, args.calls),
-            }
+            n_img, el, cores, desc = cpu_baseline_step(args.height, args.width, args.cpu_sample_div)
+            line["cpu_baseline"] = {"value": n_img / el, "unit": "images/s", "cores": cores,
+                                    "kind": "port", "sample": desc}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -59,6 +59,27 @@ def _dims(value, spatial_shapes, sampling_loc, im2col_step):
 
 
 USE_TILED_BACKWARD = True  # False forces the atomic backward (tests compare the two)
+# Optional launch timing for bench.py: when TIMING is a list, every call appends
+# (kind, (B, S, M, D, L, Q, P), start_event, end_event) recorded on the launch stream.
+TIMING = None
+
+
+class _Timed:
+    def __init__(self, kind, dims):
+        self.kind, self.dims = kind, dims
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            self.e1.record()
+            TIMING.append((self.kind, self.dims, self.e0, self.e1))
+        return False
 _WS_CACHE = {}
 
 
@@ -85,11 +106,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     B, S, M, D, L, Q, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
     lib = _lib.load()
     out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device):
-        fn = getattr(lib, "zira_msda_fwd_" + _SUFFIX[value.dtype])
-        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Q, P,
-                out.data_ptr(), _stream())
+    fn = getattr(lib, "zira_msda_fwd_" + _SUFFIX[value.dtype])
+    args = (value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Q, P, out.data_ptr())
+    with torch.cuda.device(value.device), _Timed("fwd", (B, S, M, D, L, Q, P)):
+        rc = fn(*args, _stream())
     _raise_on(rc, "ms_deform_attn_forward")
     return out
 
@@ -104,21 +125,20 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if grad_output.dtype != value.dtype:
         raise RuntimeError("expected grad_output to have the dtype of value")
     lib = _lib.load()
-    grad_value = torch.empty_like(value)          # zero-filled by the callee on the stream
+    grad_value = torch.empty_like(value)          # written exactly once by the callee
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
-    with torch.cuda.device(value.device):
-        args = (grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-                B, S, M, D, L, Q, P, grad_value.data_ptr(), grad_loc.data_ptr(),
-                grad_attn.data_ptr())
-        ws_bytes = _workspace_bytes(lib, B, S, M, D, L, Q, P) if value.dtype == torch.float32 else 0
-        if ws_bytes and USE_TILED_BACKWARD:
-            # atomic-free two-kernel backward; scratch comes from torch's caching allocator
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+    args = (grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            B, S, M, D, L, Q, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+    ws_bytes = _workspace_bytes(lib, B, S, M, D, L, Q, P) if value.dtype == torch.float32 else 0
+    tiled = bool(ws_bytes) and USE_TILED_BACKWARD
+    if tiled:  # atomic-free two-kernel backward; scratch comes from torch's caching allocator
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+    with torch.cuda.device(value.device), _Timed("bwd", (B, S, M, D, L, Q, P)):
+        if tiled:
             rc = lib.zira_msda_bwd_f32_ws(*args, ws.data_ptr(), ws_bytes, _stream())
         else:
-            fn = getattr(lib, "zira_msda_bwd_" + _SUFFIX[value.dtype])
-            rc = fn(*args, _stream())
+            rc = getattr(lib, "zira_msda_bwd_" + _SUFFIX[value.dtype])(*args, _stream())
     _raise_on(rc, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_attn]

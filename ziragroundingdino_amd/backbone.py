@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .dense import conv_module_as_gemm
 from .transformer import DropPath
 from .utils import NestedTensor
 
@@ -165,7 +166,7 @@ class PatchEmbed(nn.Module):
         _, _, H, W = x.shape
         p = self.patch_size
         x = F.pad(x, (0, (p - W % p) % p, 0, (p - H % p) % p))  # 1333 -> 1336 (reference :482-489)
-        x = self.proj(x)
+        x = conv_module_as_gemm(self.proj, x)  # 4x4/4 patches: reshape + GEMM
         Wh, Ww = x.shape[2], x.shape[3]
         x = self.norm(x.flatten(2).transpose(1, 2))
         return x, Wh, Ww

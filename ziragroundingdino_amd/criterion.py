@@ -98,7 +98,8 @@ class SetCriterion(nn.Module):
                                     device=next(iter(outputs.values())).device)
         if is_dist_avail_and_initialized():
             dist.all_reduce(num_boxes)
-        return torch.clamp(num_boxes / get_world_size(), min=1).item()
+        # kept on the device (0-dim): the reference's .item() here is one more host sync per step
+        return torch.clamp(num_boxes / get_world_size(), min=1)[0]
 
 
 class TwoStageCriterion(SetCriterion):
@@ -112,29 +113,30 @@ class TwoStageCriterion(SetCriterion):
     def forward(self, outputs, targets, return_indices=False):
         outputs_without_aux = {k: v for k, v in outputs.items()
                                if k not in ("aux_outputs", "enc_outputs", "cate_to_token_mask_list")}
-        indices_list = {"indices": None, "aux_outputs": [], "enc_outputs": []}
-        indices = self.matcher(outputs_without_aux, targets)
-        indices_list["indices"] = indices
+        aux_list = list(outputs.get("aux_outputs", []))
+        enc_outputs = outputs.get("enc_outputs")
+        if enc_outputs is not None and self.two_stage_binary_cls:
+            raise NotImplementedError("two_stage_binary_cls is not used by the ZiRa configs")
+        # all matchings of the step in one go (one device->host copy instead of one per set)
+        sets = [outputs_without_aux] + aux_list + ([enc_outputs] if enc_outputs is not None else [])
+        if hasattr(self.matcher, "forward_many"):
+            all_indices = self.matcher.forward_many(sets, targets)
+        else:
+            all_indices = [self.matcher(o, targets) for o in sets]
+        indices_list = {"indices": all_indices[0], "aux_outputs": all_indices[1:1 + len(aux_list)],
+                        "enc_outputs": all_indices[1 + len(aux_list):]}
         num_boxes = self._num_boxes(outputs_without_aux, targets)
 
         losses = {}
         for loss in self.losses:
-            losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
-        for i, aux_outputs in enumerate(outputs.get("aux_outputs", [])):
-            indices = self.matcher(aux_outputs, targets)
-            indices_list["aux_outputs"].append(indices)
+            losses.update(self.get_loss(loss, outputs, targets, all_indices[0], num_boxes))
+        for i, aux_outputs in enumerate(aux_list):
             for loss in self.losses:
-                l_dict = self.get_loss(loss, aux_outputs, targets, indices, num_boxes)
+                l_dict = self.get_loss(loss, aux_outputs, targets, all_indices[1 + i], num_boxes)
                 losses.update({k + f"_{i}": v for k, v in l_dict.items()})
-        if "enc_outputs" in outputs:
-            enc_outputs = outputs["enc_outputs"]
-            if self.two_stage_binary_cls:
-                for bt in targets:
-                    bt["labels"] = torch.zeros_like(bt["labels"])
-            indices = self.matcher(enc_outputs, targets)
-            indices_list["enc_outputs"].append(indices)
+        if enc_outputs is not None:
             for loss in self.losses:
-                l_dict = self.get_loss(loss, enc_outputs, targets, indices, num_boxes)
+                l_dict = self.get_loss(loss, enc_outputs, targets, all_indices[-1], num_boxes)
                 losses.update({k + "_enc": v for k, v in l_dict.items()})
         if return_indices:
             return losses, indices_list

@@ -1,0 +1,60 @@
+"""Convolutions of the hot path expressed as GEMMs.
+
+On this ROCm build MIOpen has no tuned fp32 solver for the 1x1 / patch / 3x3-stride-2
+convolutions of the input projections and falls back to ``naive_conv_*`` kernels (3-4 ms per
+call, ~25 % of the kernel time of a training step in the first rocprofv3 trace).  Every one of
+them is a plain dense contraction, so they are routed to the GEMM library (hipBLASLt, MFMA)
+instead: 1x1 -> W[O,C] @ x[B,C,HW]; kernel == stride (patch embedding) -> reshape + GEMM;
+anything else -> im2col (F.unfold) + GEMM.  Same results as F.conv2d up to fp32 summation
+order; gradients come from autograd of the matmuls (weight gradients are GEMMs as well).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def conv_columns(x, kernel, stride=1, padding=0):
+    """im2col view of x for a (kh, kw) kernel: ([B, C*kh*kw, Ho*Wo], Ho, Wo); free for 1x1."""
+    kh, kw = kernel
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    B, C, H, W = x.shape
+    if kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0:
+        return x.flatten(2), H, W
+    if kh == sh and kw == sw and ph == 0 and pw == 0 and H % kh == 0 and W % kw == 0:
+        Ho, Wo = H // kh, W // kw                                            # non-overlapping patches
+        cols = x.view(B, C, Ho, kh, Wo, kw).permute(0, 1, 3, 5, 2, 4).reshape(B, C * kh * kw, Ho * Wo)
+        return cols, Ho, Wo
+    Ho = (H + 2 * ph - kh) // sh + 1
+    Wo = (W + 2 * pw - kw) // sw + 1
+    return F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw)), Ho, Wo
+
+
+def conv2d_as_gemm(x, weight, bias=None, stride=1, padding=0):
+    """conv2d (dilation 1, groups 1, zero padding) via GEMM.  x [B,C,H,W], weight [O,C,kh,kw]."""
+    O = weight.shape[0]
+    cols, Ho, Wo = conv_columns(x, weight.shape[2:], stride, padding)
+    y = torch.matmul(weight.view(O, -1), cols)                               # [B, O, Ho*Wo]
+    if bias is not None:
+        y = y + bias.view(1, O, 1)
+    return y.view(x.shape[0], O, Ho, Wo)
+
+
+def conv2d_pair_as_gemm(x, weight_a, bias_a, weight_b, bias_b, stride=1, padding=0):
+    """Two convolutions of the same input with equally shaped kernels as ONE batched GEMM
+    (the activations / im2col columns are read once); returns two contiguous [B,O,Ho,Wo]."""
+    O = weight_a.shape[0]
+    cols, Ho, Wo = conv_columns(x, weight_a.shape[2:], stride, padding)
+    w = torch.stack([weight_a.view(O, -1), weight_b.view(O, -1)])            # [2, O, K]
+    y = torch.matmul(w[:, None], cols[None])                                 # [2, B, O, Ho*Wo]
+    if bias_a is not None:
+        y = y + torch.stack([bias_a, bias_b]).view(2, 1, O, 1)
+    y = y.view(2, x.shape[0], O, Ho, Wo)
+    return y[0], y[1]
+
+
+def conv_module_as_gemm(conv: torch.nn.Conv2d, x):
+    """Apply an nn.Conv2d's parameters through conv2d_as_gemm (falls back to the module itself
+    for dilation / groups / non-zero padding modes, which the hot path does not use)."""
+    if conv.dilation != (1, 1) or conv.groups != 1 or conv.padding_mode != "zeros" or isinstance(conv.padding, str):
+        return conv(x)
+    return conv2d_as_gemm(x, conv.weight, conv.bias, conv.stride, conv.padding)

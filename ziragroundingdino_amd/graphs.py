@@ -1,0 +1,178 @@
+"""hipGraph capture for the launch-bound, gradient-free parts of the step.
+
+The frozen front end of ZiRa (Swin backbone, BERT) is ~2500 small kernels per step whose
+launch cost on the host exceeds their run time on an MI355X; nothing in it depends on the host
+and no gradient flows into it.  ``GraphedNoGrad`` captures such a callable once per input
+signature into a HIP graph (``torch.cuda.CUDAGraph``; random ops such as the backbone's
+stochastic depth keep working through the graph-safe Philox generator) and replays it with one
+launch.  Inputs are copied into static buffers; outputs are static tensors that stay valid until
+the next replay of the same signature.
+"""
+import torch
+
+
+def _flatten(obj, out):
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _flatten(o, out)
+    elif isinstance(obj, dict):
+        for k in obj:
+            _flatten(obj[k], out)
+    return out
+
+
+class GraphedNoGrad:
+    def __init__(self, fn, max_signatures=4, warmup=2):
+        self.fn = fn
+        self.max_signatures = max_signatures
+        self.warmup = warmup
+        self._cache = {}
+
+    def __call__(self, *args):
+        tensors = _flatten(args, [])
+        if not tensors or not tensors[0].is_cuda or torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            with torch.no_grad():
+                return self.fn(*args)
+        key = tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors)
+        entry = self._cache.get(key)
+        if entry is None:
+            if len(self._cache) >= self.max_signatures:  # unbounded shape variety: stay eager
+                with torch.no_grad():
+                    return self.fn(*args)
+            entry = self._capture(args, tensors)
+            self._cache[key] = entry
+        static_in, graph, static_out = entry
+        for s, t in zip(static_in, tensors):
+            s.copy_(t, non_blocking=True)
+        graph.replay()
+        return static_out
+
+    def _capture(self, args, tensors):
+        static_in = [t.clone() for t in tensors]
+        it = iter(static_in)
+
+        def rebuild(obj):
+            if torch.is_tensor(obj):
+                return next(it)
+            if isinstance(obj, (list, tuple)):
+                return type(obj)(rebuild(o) for o in obj)
+            if isinstance(obj, dict):
+                return {k: rebuild(v) for k, v in obj.items()}
+            return obj
+
+        static_args = rebuild(args)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):
+                self.fn(*static_args)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            static_out = self.fn(*static_args)
+        return static_in, graph, static_out
+
+
+class _EncoderLayerPiece(torch.nn.Module):
+    """Text enhancer + deformable image layer of one encoder layer with a tensor-only signature
+    (the fusion block in front of them runs eagerly, see GraphedTransformer).  The level tables
+    are constants of the piece (cached device tensors)."""
+
+    def __init__(self, encoder, layer_id, spatial_shapes, level_start_index):
+        super().__init__()
+        self.encoder, self.layer_id = encoder, layer_id
+        self.spatial_shapes, self.level_start_index = spatial_shapes, level_start_index
+
+    def forward(self, output, memory_text, pos, reference_points, key_padding_mask,
+                text_attention_mask, pos_text, text_self_attention_masks):
+        return self.encoder.forward_layer(
+            self.layer_id, output, memory_text, pos, reference_points, self.spatial_shapes,
+            self.level_start_index, key_padding_mask, text_attention_mask, pos_text,
+            text_self_attention_masks, fuse=False)
+
+
+class _SelectDecodePiece(torch.nn.Module):
+    """Two-stage query selection + the whole decoder with a tensor-only signature."""
+
+    def __init__(self, transformer, shapes, spatial_shapes, level_start_index):
+        super().__init__()
+        self.transformer, self.shapes = transformer, shapes
+        self.spatial_shapes, self.level_start_index = spatial_shapes, level_start_index
+
+    def forward(self, memory, memory_text, mask_flatten, lvl_pos, valid_ratios, text_token_mask):
+        text_dict = {"encoded_text": memory_text, "text_token_mask": text_token_mask}
+        hs, refs, hs_enc, ref_enc, init_box = self.transformer.select_and_decode(
+            memory, mask_flatten, lvl_pos, self.shapes, self.spatial_shapes, self.level_start_index,
+            valid_ratios, text_dict)
+        self.n_hs, self.n_refs = len(hs), len(refs)
+        return (*hs, *refs, hs_enc, ref_enc, init_box)
+
+
+def _graph(mod, args):
+    sample = tuple(x.detach().clone().requires_grad_(x.requires_grad) for x in args)
+    return torch.cuda.make_graphed_callables(mod, sample, num_warmup_iters=3, allow_unused_input=True)
+
+
+class GraphedTransformer:
+    """Forward AND backward of the (frozen-weight) cross-modal transformer replayed from HIP
+    graphs (``torch.cuda.make_graphed_callables``): in eager mode the host needs ~31 ms to
+    enqueue the ~1500 small kernels of the forward alone, longer than the GPU needs to run them.
+
+    The transformer is cut into seven graphed pieces -- text enhancer + deformable layer of each
+    encoder layer, and query selection + decoder -- each with its own pair of graphs and memory
+    pool; the six image<->text fusion blocks between them stay eager.  (On ROCm 7.2 / torch 2.10
+    graphs that contain three or more BiAttention blocks replay once and then take a GPU memory
+    fault; stacks of the other layer types replay indefinitely.  scripts/graph_bisect*.py hold
+    the bisection.)
+    One set of graphs per input signature (image size / caption length); further signatures
+    run eagerly after ``max_signatures``."""
+
+    def __init__(self, transformer, max_signatures=2):
+        self.transformer = transformer
+        self.max_signatures = max_signatures
+        self._cache = {}
+
+    def __call__(self, srcs, masks, poss, text_dict):
+        t = self.transformer
+        key = (tuple((tuple(x.shape), x.requires_grad) for x in srcs),
+               tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad)
+        if key not in self._cache and len(self._cache) >= self.max_signatures:
+            hs, refs, hs_enc, ref_enc, init_box, _ = t(srcs, masks, None, poss, None, None, text_dict)
+            return hs, refs, hs_enc, ref_enc, init_box
+
+        (src, mask_flat, lvl_pos, shapes, spatial_shapes, level_start_index,
+         valid_ratios) = t.prepare_inputs(srcs, masks, poss)
+        enc = t.encoder
+        memory_text = text_dict["encoded_text"]
+        text_attention_mask = ~text_dict["text_token_mask"]
+        reference_points, pos_text = enc.prepare(shapes, valid_ratios, memory_text, None,
+                                                 text_dict["position_ids"], src.device)
+        tsm = text_dict["text_self_attention_masks"]
+
+        entry = self._cache.get(key)
+        if entry is None:
+            entry = self._cache[key] = {"layers": [], "decode": None}
+        output = src
+        for i in range(len(enc.layers)):
+            if enc.fusion_layers:  # eager: graphed BiAttention blocks fault on replay (see class doc)
+                output, memory_text = enc.fusion_layers[i](v=output, l=memory_text, attention_mask_v=mask_flat,
+                                                           attention_mask_l=text_attention_mask)
+            args = (output, memory_text, lvl_pos, reference_points, mask_flat, text_attention_mask,
+                    pos_text, tsm)
+            if len(entry["layers"]) <= i:
+                entry["layers"].append(_graph(_EncoderLayerPiece(enc, i, spatial_shapes, level_start_index), args))
+            output, memory_text = entry["layers"][i](*args)
+        text_dict["encoded_text"] = memory_text
+
+        args = (output, memory_text, mask_flat, lvl_pos, valid_ratios, text_dict["text_token_mask"])
+        if entry["decode"] is None:
+            piece = _SelectDecodePiece(t, shapes, spatial_shapes, level_start_index)
+            entry["decode"] = (_graph(piece, args), piece)
+        graphed, piece = entry["decode"]
+        out = graphed(*args)
+        nh, nr = piece.n_hs, piece.n_refs
+        hs, refs = list(out[:nh]), list(out[nh:nh + nr])
+        hs_enc, ref_enc, init_box = out[nh + nr:nh + nr + 3]
+        return hs, refs, hs_enc, ref_enc, init_box

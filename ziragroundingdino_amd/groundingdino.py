@@ -28,6 +28,8 @@ from .backbone import build_backbone
 from .bert import BertConfig, BertModel, SimpleTokenizer
 from .box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh
 from .criterion import build_criterion
+from .dense import conv_module_as_gemm
+from .graphs import GraphedNoGrad, GraphedTransformer
 from .rsb import RepZeroConv2d, RepZeroLinear
 from .structures import Boxes, ImageList, Instances
 from .text_masks import generate_masks_with_special_tokens_and_transfer_map
@@ -180,6 +182,33 @@ class GroundingDINO(nn.Module):
         self.use_bert_tuning = use_bert_tuning
         self.use_cls_linear = use_cls_linear
         self.use_project_tuning = use_project_tuning
+        # hipGraph replay of the frozen front end (GPU only; see graphs.py)
+        self.use_frontend_graphs = True
+        self._graphed_backbone = GraphedNoGrad(self._backbone_tensors)
+        self._graphed_bert = GraphedNoGrad(self._bert_hidden)
+        # hipGraph replay of transformer forward + backward (opt-in: fixed input sizes, frozen
+        # transformer weights, training mode); see graphs.GraphedTransformer
+        self.use_transformer_graph = False
+        self._graphed_transformer = GraphedTransformer(self.transformer)
+
+    def _backbone_tensors(self, images, mask):
+        """tensor-in / tensor-out view of the backbone for graph capture."""
+        features, poss = self.backbone(NestedTensor(images, mask))
+        return [f.tensors for f in features], [f.mask for f in features], poss
+
+    def _bert_hidden(self, enc_in):
+        return self.bert(**enc_in)["last_hidden_state"]
+
+    def run_backbone(self, samples):
+        """features (list of NestedTensor) and position encodings of the frozen backbone."""
+        if self._frozen(self.backbone):
+            if self.use_frontend_graphs and samples.tensors.is_cuda:
+                ft, fm, poss = self._graphed_backbone(samples.tensors, samples.mask)
+            else:
+                with torch.no_grad():
+                    ft, fm, poss = self._backbone_tensors(samples.tensors, samples.mask)
+            return [NestedTensor(t, m) for t, m in zip(ft, fm)], list(poss)
+        return self.backbone(samples)
 
     def _reset_parameters(self):
         for proj in self.input_proj:
@@ -196,10 +225,11 @@ class GroundingDINO(nn.Module):
 
     def _project_level(self, l, feat):
         """GroupNorm(input_proj conv + side branch); returns (src, zero-interference loss | None)."""
+        main = conv_module_as_gemm(self.input_proj[l][0], feat)  # GEMM library instead of MIOpen
         if not self.use_project_adapter:
-            return self.input_proj[l](feat), None
+            return self.input_proj[l][1](main), None
         branch, zero_loss = self.input_proj_conv_adapter[l](feat)
-        return self.input_proj[l][1](self.input_proj[l][0](feat) + branch), zero_loss
+        return self.input_proj[l][1](main + branch), zero_loss
 
     def encode_text(self, captions, device):
         tokenized = self.tokenizer(captions, padding="longest", return_tensors="pt").to(device)
@@ -217,8 +247,15 @@ class GroundingDINO(nn.Module):
             enc_in["position_ids"] = position_ids
         else:
             enc_in = tokenized
-        with torch.set_grad_enabled(not self._frozen(self.bert)):
-            hidden = self.bert(**enc_in)["last_hidden_state"]
+        enc_in = dict(enc_in)
+        if self._frozen(self.bert):
+            if self.use_frontend_graphs and enc_in["input_ids"].is_cuda:
+                hidden = self._graphed_bert(enc_in)
+            else:
+                with torch.no_grad():
+                    hidden = self._bert_hidden(enc_in)
+        else:
+            hidden = self._bert_hidden(enc_in)
         text_dict, loss_linear_adapter = self.project_text(
             hidden, tokenized["attention_mask"].bool(), position_ids, masks)
         return text_dict, cate_to_token_mask_list, loss_linear_adapter
@@ -263,8 +300,7 @@ class GroundingDINO(nn.Module):
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
             targets = self.prepare_targets(gt_instances, cate_to_token_mask_list, names_list)
 
-        with torch.set_grad_enabled(not self._frozen(self.backbone)):
-            features, poss = self.backbone(samples)
+        features, poss = self.run_backbone(samples)
 
         out_or_loss = self.forward_features(features, poss, samples.mask, text_dict,
                                             cate_to_token_mask_list, loss_linear_adapter, targets)
@@ -310,8 +346,13 @@ class GroundingDINO(nn.Module):
             srcs.append(src)
             masks.append(mask)
 
-        hs, reference, hs_enc, ref_enc, init_box_proposal, _ = self.transformer(
-            srcs, masks, None, poss, None, None, text_dict)
+        if (self.use_transformer_graph and self.training and srcs[0].is_cuda
+                and self._frozen(self.transformer) and torch.is_grad_enabled()):
+            hs, reference, hs_enc, ref_enc, init_box_proposal = self._graphed_transformer(
+                srcs, masks, poss, text_dict)
+        else:
+            hs, reference, hs_enc, ref_enc, init_box_proposal, _ = self.transformer(
+                srcs, masks, None, poss, None, None, text_dict)
 
         outputs_coord_list = []
         for layer_ref_sig, layer_bbox_embed, layer_hs in zip(reference[:-1], self.bbox_embed, hs):

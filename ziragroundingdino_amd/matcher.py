@@ -56,5 +56,21 @@ class HungarianMatcher(nn.Module):
                 for i, j in indices]
 
 
+    @torch.no_grad()
+    def forward_many(self, outputs_list, targets):
+        """Match several prediction sets (final layer, auxiliary layers, encoder proposals)
+        against the same targets with ONE device->host copy: all cost matrices are built on the
+        GPU first, the linear sum assignments then run on the host back to back.  Same
+        assignments as calling ``forward`` once per set (the reference does that: 7 syncs)."""
+        costs = torch.stack([self.cost_matrix(o, targets) for o in outputs_list]).cpu()
+        sizes = [len(v["boxes"]) for v in targets]
+        results = []
+        for C in costs:
+            indices = [linear_sum_assignment(c[i]) for i, c in enumerate(C.split(sizes, -1))]
+            results.append([(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64))
+                            for i, j in indices])
+        return results
+
+
 def build_matcher(args=None):
     return HungarianMatcher()

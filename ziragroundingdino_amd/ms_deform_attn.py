@@ -67,6 +67,22 @@ def sampling_locations_from_reference_points(reference_points, sampling_offsets,
         "Last dim of reference_points must be 2 or 4, but get {} instead.".format(last))
 
 
+_VERIFIED_LEVEL_TABLES = set()
+
+
+def _check_levels_cover_value(spatial_shapes, num_value):
+    """The reference asserts sum(H*W) == num_value on every call (ms_deform_attn.py:284), which
+    reads a device tensor back (a host sync, 12x per step).  Same check here, but a given level
+    table (same storage, same version) is only read back once."""
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, spatial_shapes.device, int(num_value))
+    if key in _VERIFIED_LEVEL_TABLES:
+        return
+    assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
+    if len(_VERIFIED_LEVEL_TABLES) > 256:
+        _VERIFIED_LEVEL_TABLES.clear()
+    _VERIFIED_LEVEL_TABLES.add(key)
+
+
 class MultiScaleDeformableAttention(nn.Module):
     """Multi-scale deformable attention (Deformable-DETR) with the reference's parameter names.
 
@@ -157,7 +173,7 @@ class MultiScaleDeformableAttention(nn.Module):
         if not self.batch_first:
             query = query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
-        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == value.shape[1]
+        _check_levels_cover_value(spatial_shapes, value.shape[1])
 
         value, loc, attn = self.project(query, value, key_padding_mask, reference_points,
                                         spatial_shapes)

@@ -23,6 +23,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib
+from .dense import conv2d_as_gemm, conv2d_pair_as_gemm
 
 zero_value = 1e-8
 lan_scale = 0.1
@@ -106,10 +107,23 @@ class RepZeroConv2d(nn.Conv2d):
         if self.bias is not None:
             nn.init.constant_(self.freeze_conv.bias, val=0.0)
 
+    def _gemm_ok(self):
+        return (self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
+                and not isinstance(self.padding, str))
+
     def forward(self, input: Tensor):
+        if not self._gemm_ok():  # configurations the hot path never uses: plain conv modules
+            if not self.training:
+                return self.freeze_conv(input), input.new_zeros(1)
+            return rsb_epilogue(super().forward(input), self.freeze_conv(input), self.scaling)
+        twin = self.freeze_conv
         if not self.training:
-            return self.freeze_conv(input), torch.zeros(1).to(input)
-        return rsb_epilogue(super().forward(input), self.freeze_conv(input), self.scaling)
+            return conv2d_as_gemm(input, twin.weight, twin.bias, self.stride, self.padding), \
+                input.new_zeros(1)
+        # branch and twin read the same activations: one batched GEMM over both weight sets
+        y_branch, y_twin = conv2d_pair_as_gemm(input, self.weight, self.bias, twin.weight, twin.bias,
+                                               self.stride, self.padding)
+        return rsb_epilogue(y_branch, y_twin, self.scaling)
 
     def __rep__(self):
         with torch.no_grad():
@@ -137,7 +151,7 @@ class RepZeroLinear(nn.Linear):
 
     def forward(self, input: Tensor):
         if not self.training:
-            return self.freeze_linear(input), torch.zeros(1).to(input)
+            return self.freeze_linear(input), input.new_zeros(1)
         return rsb_epilogue(super().forward(input), self.freeze_linear(input), self.scaling)
 
     def __rep__(self):

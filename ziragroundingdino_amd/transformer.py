@@ -39,6 +39,41 @@ class DropPath(nn.Module):
         return x * mask.div_(keep)
 
 
+def _cascade_reduce(x: Tensor, op: str) -> Tensor:
+    """Full max / sum of x as a cascade of short row reductions (<= 256 elements each, one
+    block per output) instead of one multi-block reduction."""
+    v = x.reshape(-1)
+    fill = float("-inf") if op == "max" else 0.0
+    while v.numel() > 256:
+        pad = (-v.numel()) % 256
+        if pad:
+            v = F.pad(v, (0, pad), value=fill)
+        v = v.view(-1, 256)
+        v = v.amax(dim=-1) if op == "max" else v.sum(dim=-1)
+    return v.amax() if op == "max" else v.sum()
+
+
+class _SubtractGlobalMax(torch.autograd.Function):
+    """x - x.max() with the gradient autograd would give it (g - onehot(argmax) * sum(g), ties
+    shared evenly) -- the reference's ``attn_weights - attn_weights.max()`` (fuse_modules.py:169).
+    Written out because PyTorch's full reductions over this 2 M-element tensor (``max()`` in the
+    forward, ``sum()`` in the backward) go through its multi-block reduce with global scratch,
+    which replays once from a hipGraph and then faults on ROCm 7.2; the cascades below are plain
+    row reductions and give the same values (max exactly, the sum up to fp32 association)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        m = _cascade_reduce(x, "max")
+        ctx.save_for_backward(x, m)
+        return x - m
+
+    @staticmethod
+    def backward(ctx, g):
+        x, m = ctx.saved_tensors
+        mask = (x == m).to(g.dtype)
+        return g - mask * (_cascade_reduce(g, "sum") / _cascade_reduce(mask, "sum"))
+
+
 class BiMultiHeadAttention(nn.Module):
     """Image <-> text attention sharing one score matrix (reference fuse_modules.py:99-248)."""
 
@@ -82,7 +117,7 @@ class BiMultiHeadAttention(nn.Module):
 
         attn = torch.bmm(q, k.transpose(1, 2))  # [bs*heads, n_img, n_text]
         if self.stable_softmax_2d:
-            attn = attn - attn.max()
+            attn = _SubtractGlobalMax.apply(attn)
         if self.clamp_min_for_underflow:
             attn = torch.clamp(attn, min=-50000)
         if self.clamp_max_for_overflow:
@@ -170,7 +205,7 @@ class TransformerEncoderLayer(nn.Module):
         if src_mask.dim() == 3 and src_mask.shape[0] == src.shape[1]:
             src_mask = src_mask.repeat(self.nhead, 1, 1)
         q = k = self.with_pos_embed(src, pos)
-        src2 = self.self_attn(q, k, value=src, attn_mask=src_mask)[0]
+        src2 = self.self_attn(q, k, value=src, attn_mask=src_mask, need_weights=False)[0]
         src = self.norm1(src + self.dropout1(src2))
         src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout2(src2))
@@ -203,7 +238,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(src2)), torch.zeros(1).to(src)
+        return self.norm2(src + self.dropout3(src2)), src.new_zeros(1)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
                 key_padding_mask=None):
@@ -260,7 +295,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward_ffn(self, tgt):
         with torch.amp.autocast("cuda", enabled=False):  # reference :1004 keeps the FFN in fp32
             tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(tgt2)), torch.zeros(1).to(tgt)
+        return self.norm3(tgt + self.dropout4(tgt2)), tgt.new_zeros(1)
 
     def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None, tgt_key_padding_mask=None,
                 tgt_reference_points=None, memory_text=None, text_attention_mask=None, memory=None,
@@ -270,11 +305,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
         assert cross_attn_mask is None
         if self.self_attn is not None:
             q = k = self.with_pos_embed(tgt, tgt_query_pos)
-            tgt2 = self.self_attn(q, k, tgt, attn_mask=self_attn_mask)[0]
+            tgt2 = self.self_attn(q, k, tgt, attn_mask=self_attn_mask, need_weights=False)[0]
             tgt = self.norm2(tgt + self.dropout2(tgt2))
         if self.use_text_cross_attention:
             tgt2 = self.ca_text(self.with_pos_embed(tgt, tgt_query_pos), memory_text.transpose(0, 1),
-                                memory_text.transpose(0, 1), key_padding_mask=text_attention_mask)[0]
+                                memory_text.transpose(0, 1), key_padding_mask=text_attention_mask,
+                                need_weights=False)[0]
             tgt = self.catext_norm(tgt + self.catext_dropout(tgt2))
         tgt2 = self.cross_attn(
             query=self.with_pos_embed(tgt, tgt_query_pos).transpose(0, 1),
@@ -330,11 +366,21 @@ class TransformerEncoder(nn.Module):
                 text_attention_mask: Tensor = None, pos_text: Tensor = None,
                 text_self_attention_masks: Tensor = None, position_ids: Tensor = None,
                 spatial_shapes_list=None):
+        reference_points, pos_text = self.prepare(
+            spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes, valid_ratios,
+            memory_text, pos_text, position_ids, src.device)
         output = src
+        for layer_id in range(len(self.layers)):
+            output, memory_text = self.forward_layer(
+                layer_id, output, memory_text, pos, reference_points, spatial_shapes, level_start_index,
+                key_padding_mask, text_attention_mask, pos_text, text_self_attention_masks)
+        return output, memory_text, src.new_zeros(1)
+
+    def prepare(self, shapes, valid_ratios, memory_text, pos_text, position_ids, device):
+        """Per-call constants of the layer loop: pixel reference points and text position codes."""
+        reference_points = None
         if self.num_layers > 0:
-            reference_points = self.get_reference_points(
-                spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes,
-                valid_ratios, device=src.device)
+            reference_points = self.get_reference_points(shapes, valid_ratios, device=device)
         if self.text_layers:
             bs, n_text, _ = memory_text.shape
             if pos_text is None and position_ids is None:
@@ -343,26 +389,29 @@ class TransformerEncoder(nn.Module):
                 pos_text = get_sine_pos_embed(pos_text, num_pos_feats=256, exchange_xy=False)
             if position_ids is not None:
                 pos_text = get_sine_pos_embed(position_ids[..., None], num_pos_feats=256, exchange_xy=False)
+        return reference_points, pos_text
 
-        adapter_loss = torch.zeros(1).to(src)
-        for layer_id, layer in enumerate(self.layers):
-            if self.fusion_layers:
-                output, memory_text = self.fusion_layers[layer_id](
-                    v=output, l=memory_text, attention_mask_v=key_padding_mask,
-                    attention_mask_l=text_attention_mask)
-            if self.text_layers:
-                memory_text = self.text_layers[layer_id](
-                    src=memory_text.transpose(0, 1),
-                    src_mask=~text_self_attention_masks,  # True = do not attend
-                    src_key_padding_mask=text_attention_mask,
-                    pos=(pos_text.transpose(0, 1) if pos_text is not None else None),
-                ).transpose(0, 1)
-            output, adapter_loss_ = layer(src=output, pos=pos, reference_points=reference_points,
+    def forward_layer(self, layer_id, output, memory_text, pos, reference_points, spatial_shapes,
+                      level_start_index, key_padding_mask, text_attention_mask, pos_text,
+                      text_self_attention_masks, fuse=True):
+        """One encoder layer: fusion -> text enhancer -> deformable image layer (reference :563-662).
+        ``fuse=False`` skips the fusion block (the caller has already applied it)."""
+        if self.fusion_layers and fuse:
+            output, memory_text = self.fusion_layers[layer_id](
+                v=output, l=memory_text, attention_mask_v=key_padding_mask,
+                attention_mask_l=text_attention_mask)
+        if self.text_layers:
+            memory_text = self.text_layers[layer_id](
+                src=memory_text.transpose(0, 1),
+                src_mask=~text_self_attention_masks,  # True = do not attend
+                src_key_padding_mask=text_attention_mask,
+                pos=(pos_text.transpose(0, 1) if pos_text is not None else None),
+            ).transpose(0, 1)
+        output, _ = self.layers[layer_id](src=output, pos=pos, reference_points=reference_points,
                                           spatial_shapes=spatial_shapes,
                                           level_start_index=level_start_index,
                                           key_padding_mask=key_padding_mask)
-            adapter_loss = adapter_loss + adapter_loss_
-        return output, memory_text, adapter_loss
+        return output, memory_text
 
 
 class TransformerDecoder(nn.Module):
@@ -395,7 +444,7 @@ class TransformerDecoder(nn.Module):
         intermediate = []
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
-        adapter_loss = torch.zeros(1).to(tgt)
+        adapter_loss = tgt.new_zeros(1)
         for layer_id, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
                 reference_points_input = (reference_points[:, :, None]
@@ -517,7 +566,23 @@ class Transformer(nn.Module):
     def init_ref_points(self, use_num_queries):
         self.refpoint_embed = nn.Embedding(use_num_queries, 4)
 
-    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None):
+    def _level_tables(self, shapes, device):
+        """Device copies of spatial_shapes / level_start_index, built once per level geometry
+        (the reference uploads them on every forward; a cached tensor also keeps the forward
+        capturable into a hipGraph)."""
+        cache = self.__dict__.setdefault("_level_table_cache", {})
+        key = (shapes, str(device))
+        if key not in cache:
+            sh = torch.as_tensor(shapes, dtype=torch.long, device=device)
+            start = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = (sh, start)
+        return cache[key]
+
+    def prepare_inputs(self, srcs, masks, pos_embeds):
+        """Flatten the levels: (src [B,S,C], mask [B,S], pos+level_embed [B,S,C], shapes list,
+        spatial_shapes / level_start_index device tables, valid_ratios) -- reference :239-267."""
         src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes = [], [], [], []
         for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
             bs, c, h, w = src.shape
@@ -533,20 +598,16 @@ class Transformer(nn.Module):
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
         # the op wants the level table on the device (int64); the host copy `shapes` is kept for
         # everything that only needs Python ints, so nothing reads the device tensor back
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flatten.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)),
-                                       spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = self._level_tables(tuple(shapes), src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        return (src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
+                level_start_index, valid_ratios)
 
-        memory, memory_text, adapter_loss1 = self.encoder(
-            src_flatten, pos=lvl_pos_embed_flatten, level_start_index=level_start_index,
-            spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, key_padding_mask=mask_flatten,
-            memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"],
-            position_ids=text_dict["position_ids"],
-            text_self_attention_masks=text_dict["text_self_attention_masks"],
-            spatial_shapes_list=shapes)
-        text_dict["encoded_text"] = memory_text
-
+    def select_and_decode(self, memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
+                          level_start_index, valid_ratios, text_dict, refpoint_embed=None, tgt=None,
+                          attn_mask=None):
+        """Two-stage query selection (top-k by max token logit) + decoder (reference :301-415)."""
+        bs = memory.shape[0]
         if self.two_stage_type == "standard":
             output_memory, output_proposals = gen_encoder_output_proposals(memory, mask_flatten, shapes)
             output_memory = self.enc_output_norm(self.enc_output(output_memory))
@@ -580,7 +641,7 @@ class Transformer(nn.Module):
             init_box_proposal = refpoint_embed_.sigmoid()
             topk_proposals = None
 
-        hs, references, adapter_loss2 = self.decoder(
+        hs, references, _ = self.decoder(
             tgt=tgt.transpose(0, 1), memory=memory.transpose(0, 1),
             memory_key_padding_mask=mask_flatten, pos=lvl_pos_embed_flatten.transpose(0, 1),
             refpoints_unsigmoid=refpoint_embed.transpose(0, 1), level_start_index=level_start_index,
@@ -593,7 +654,23 @@ class Transformer(nn.Module):
         else:
             hs_enc = ref_enc = None
         self.last_topk_proposals = topk_proposals  # exposed for the bit-exact index parity tests
-        return hs, references, hs_enc, ref_enc, init_box_proposal, adapter_loss1 + adapter_loss2
+        return hs, references, hs_enc, ref_enc, init_box_proposal
+
+    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None):
+        (src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes, level_start_index,
+         valid_ratios) = self.prepare_inputs(srcs, masks, pos_embeds)
+        memory, memory_text, adapter_loss1 = self.encoder(
+            src_flatten, pos=lvl_pos_embed_flatten, level_start_index=level_start_index,
+            spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, key_padding_mask=mask_flatten,
+            memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"],
+            position_ids=text_dict["position_ids"],
+            text_self_attention_masks=text_dict["text_self_attention_masks"],
+            spatial_shapes_list=shapes)
+        text_dict["encoded_text"] = memory_text
+        hs, references, hs_enc, ref_enc, init_box_proposal = self.select_and_decode(
+            memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes, level_start_index,
+            valid_ratios, text_dict, refpoint_embed, tgt, attn_mask)
+        return hs, references, hs_enc, ref_enc, init_box_proposal, adapter_loss1
 
 
 def build_transformer(args):
