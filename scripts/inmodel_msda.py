@@ -27,6 +27,10 @@ for i in range(3):
     trainer.run_step(data)
 _C.ms_deform_attn_backward = orig_b
 torch.cuda.synchronize()
+if os.environ.get("ZIRA_SAVE_INPUTS"):
+    torch.save({k: [t.cpu() for t in c[0]] for k, c in captured.items()}, os.environ["ZIRA_SAVE_INPUTS"])
+    if os.environ.get("ZIRA_SAVE_ONLY"):
+        sys.exit(0)
 for key, calls in captured.items():
     for ci in (0, len(calls) - 1):
         v, sh, st, loc, attn, go = calls[ci]

@@ -5,7 +5,10 @@ from bench import NORTH_STAR_SHAPES, make_msda_inputs
 from ziragroundingdino_amd import _C, _lib
 lib = _lib.load()
 dev = torch.device("cuda")
-v, sh, st, loc, attn, go = make_msda_inputs(2, 900, 8, 32, NORTH_STAR_SHAPES, 4, 0, dev)
+if len(sys.argv) > 1:
+    v, sh, st, loc, attn, go = [t.to(dev) for t in torch.load(sys.argv[1])[sys.argv[2] if len(sys.argv) > 2 else "dec"]]
+else:
+    v, sh, st, loc, attn, go = make_msda_inputs(2, 900, 8, 32, NORTH_STAR_SHAPES, 4, 0, dev)
 for _ in range(3):
     _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
 torch.cuda.synchronize()

@@ -63,7 +63,14 @@ def main():
     cfgs.append(("decoder_clustered", (v, sh, st, cl, attn, go), 900, 200))
     ve, _, _, _, attne, goe = make_msda_inputs(B, S, M, D, shapes, P, 2, dev)
     cfgs.append(("encoder", (ve, sh, st, encoder_loc(B, M, shapes, P, 3, dev), attne, goe), S, 20))
+    if os.environ.get("ZIRA_INPUTS"):  # MSDA inputs captured from a model step (scripts/inmodel_msda.py)
+        for key, t in torch.load(os.environ["ZIRA_INPUTS"]).items():
+            t = [x.to(dev) for x in t]
+            cfgs.append(("inmodel_" + key, tuple(t), t[3].shape[1], 200 if key == "dec" else 20))
+    only = os.environ.get("CASES")
     for name, (v, sh, st, loc, attn, go), Q, iters in cfgs:
+        if only and not any(o in name for o in only.split(",")):
+            continue
         fb, bb = msda_algorithmic_bytes(B, S, M, D, 4, Q, P)
         fwd = lambda: _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
         bwd = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)

@@ -300,3 +300,51 @@ def test_tiny_transformer(msda_backend):
     for i in range(3):
         close(grads[i], g["grad_srcs"][i], 2e-4, "grad srcs[%d]" % i)
     close(grads[3], g["grad_text"], 2e-4, "grad text")
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_rsb_zero_init_tiny_gradient_regime(dev):
+    """BASELINE configs[4] (1-shot softfreeze): at task start the branch weights are 1e-8 and the
+    twin is zero, so activations and gradients of the side branch are ~1e-8..1e-7.  The fused
+    epilogue must keep full fp32 relative accuracy there (no flush, no absolute-epsilon shortcuts);
+    reference values are the defining expression in float64."""
+    torch.manual_seed(3)
+    conv = rsb.RepZeroConv2d(48, 64, kernel_size=1).to(dev).train()       # ZiRa init: W=b=1e-8, twin 0
+    x = (torch.randn(2, 48, 9, 14) * 3).to(dev)
+    out, zl = conv(x)
+    go = torch.randn_like(out)
+    grads = torch.autograd.grad((out * go).sum() + 0.1 * zl, list(conv.parameters()))
+    # float64 restatement on the CPU
+    c64 = rsb.RepZeroConv2d(48, 64, kernel_size=1).double().train()
+    x64, go64 = x.detach().cpu().double(), go.detach().cpu().double()
+    br = c64.scaling * torch.nn.functional.conv2d(x64, c64.weight, c64.bias)
+    o64 = br + c64.freeze_conv(x64)
+    sl1 = lambda t: torch.where(t.abs() < 1, 0.5 * t * t, t.abs() - 0.5).mean()
+    z64 = sl1(br) + sl1(o64)
+    g64 = torch.autograd.grad((o64 * go64).sum() + 0.1 * z64, list(c64.parameters()))
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+    assert float(o64.abs().max()) < 1e-6                      # really the tiny regime
+    assert rel(out, o64) < 1e-5
+    assert rel(zl, z64) < 1e-4
+    for (n, _), a, b in zip(conv.named_parameters(), grads, g64):
+        assert rel(a, b) < 2e-4, (n, rel(a, b))
+
+
+def test_backbone_variants_feature_geometry():
+    """Swin-T (configs[1]) and Swin-B (configs[3]) backbones: channel counts and the /8, /16, /32
+    feature geometry the transformer's level table is built from (odd sizes are padded)."""
+    from types import SimpleNamespace
+
+    from ziragroundingdino_amd import backbone as zb
+
+    for name, chans in (("swin_T_224_1k", [192, 384, 768]), ("swin_B_384_22k", [256, 512, 1024])):
+        args = SimpleNamespace(backbone=name, hidden_dim=256, pe_temperatureH=20, pe_temperatureW=20,
+                               return_interm_indices=[1, 2, 3])
+        bb = zb.build_backbone(args).eval()
+        assert bb.num_channels == chans
+        x = torch.randn(1, 3, 100, 135)
+        m = torch.zeros(1, 100, 135, dtype=torch.bool)
+        with torch.no_grad():
+            feats, poss = bb(utils.NestedTensor(x, m))
+        assert [tuple(f.tensors.shape[1:]) for f in feats] == [(chans[0], 13, 17), (chans[1], 7, 9), (chans[2], 4, 5)]
+        assert all(p.shape[1] == 256 and p.shape[2:] == f.tensors.shape[2:] for p, f in zip(poss, feats))

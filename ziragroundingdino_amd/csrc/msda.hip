@@ -594,6 +594,7 @@ struct TilePlan {
     unsigned chunks;   // 16-sample chunks per item = ceil(LP / 16)
     unsigned eblk;     // entry slots per K1 block = ipb * chunks * 64
     unsigned rows;     // LDS rows per tile (upper bound: ceil(S / T))
+    unsigned wave_k2;  // 1: msda_bwd_tiles_wave (a wave per tile), 0: msda_bwd_tiles (a block per tile)
 };
 
 // block-granular head-major placement: virtual block id for (XCD = bid & 7, index = bid >> 3)
@@ -870,14 +871,114 @@ __device__ __forceinline__ uint2 fetch_tile_entry(const uint2 *__restrict__ reg_
     return reg_g[(size_t)lo * eblk + runoff[lo] + (e - pre[lo])];
 }
 
+// Row sums of the row-sorted entries sorted[e0, e1) (LDS), formed by one wave.
+//
+// The wave is NSLOT groups of D/4 lanes (lane = channel quad `cq` of group `slot`).  Group s
+// walks the s-th of NSLOT equal slices of the range IN ORDER, one entry per step (U grad_out rows
+// in flight), keeping the running sum of the current row in registers: a row change stores the
+// finished row with plain 16-byte stores.  That is ~4 VALU instructions per entry where a
+// segmented scan across the groups costs ~12, and K2 is VALU-bound.  Only a slice's first and
+// last row can be shared with a neighbouring slice; those 2*NSLOT partial sums go through `part`
+// (LDS, 2 KB + 64 B, may alias `sorted`: it is written after the last read of the range) and are
+// folded by two steps of the segmented scan.  Slices without a second row (or without entries)
+// contribute zero records on a neighbouring row, which keeps the record list row-sorted.
+template <unsigned NSLOT, unsigned U>
+__device__ __forceinline__ void rowsum_range(const uint2 *sorted, unsigned e0, unsigned e1,
+                                             const float *__restrict__ g_bm,
+                                             float *__restrict__ gv_t, size_t row_stride,
+                                             bool first, unsigned slot, unsigned cq,
+                                             unsigned *part)
+{
+    constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
+    constexpr unsigned CQN = 64 / NSLOT;
+    if (e1 <= e0) return;  // wave-uniform
+    const unsigned n = e1 - e0;
+    const unsigned per = (n + NSLOT - 1) / NSLOT;
+    const unsigned a = e0 + slot * per;
+    const unsigned b = (a + per < e1) ? a + per : e1;
+    const unsigned lastrow = sorted[e1 - 1].x & 0xfffu;
+    unsigned hrow = a < b ? (sorted[a].x & 0xfffu) : lastrow;
+    unsigned cur = hrow;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), hval = acc;
+    for (unsigned i = 0; i < per; i += U) {
+        unsigned rowu[U];
+        float wu[U];
+        float4 gu[U];
+#pragma unroll
+        for (unsigned u = 0; u < U; ++u) {  // issue all loads first
+            const unsigned e = a + i + u;
+            rowu[u] = kInvalidRow;
+            wu[u] = 0.f;
+            gu[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < b) {
+                const uint2 en = sorted[e];
+                rowu[u] = en.x & 0xfffu;
+                wu[u] = __uint_as_float(en.y);
+                gu[u] = *reinterpret_cast<const float4 *>(g_bm + (size_t)(en.x >> 12) * row_stride);
+            }
+        }
+#pragma unroll
+        for (unsigned u = 0; u < U; ++u) {
+            if (rowu[u] != kInvalidRow) {
+                if (rowu[u] != cur) {
+                    if (cur == hrow) {
+                        hval = acc;
+                    } else {
+                        float *p = gv_t + cur * row_stride;
+                        if (!first) add4(acc, *reinterpret_cast<const float4 *>(p));
+                        *reinterpret_cast<float4 *>(p) = acc;
+                    }
+                    cur = rowu[u];
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                acc.x = fmaf(wu[u], gu[u].x, acc.x);
+                acc.y = fmaf(wu[u], gu[u].y, acc.y);
+                acc.z = fmaf(wu[u], gu[u].z, acc.z);
+                acc.w = fmaf(wu[u], gu[u].w, acc.w);
+            }
+        }
+    }
+    float4 tval = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cur == hrow) hval = acc; else tval = acc;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane is done with sorted[e0, e1)
+    float4 *pv = reinterpret_cast<float4 *>(part);  // [2 * NSLOT][CQN]
+    unsigned *pr = part + 4 * 2 * NSLOT * CQN;      // [2 * NSLOT]
+    pv[(2 * slot) * CQN + cq] = hval;
+    pv[(2 * slot + 1) * CQN + cq] = tval;
+    if (cq == 0) { pr[2 * slot] = hrow; pr[2 * slot + 1] = cur; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    RowCarry carry;
+    carry.row = kInvalidRow;
+    carry.val = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (unsigned h = 0; h < 2; ++h) {
+        const unsigned k = h * NSLOT + slot;
+        rowsum_step<NSLOT>(pr[k], pv[k * CQN + cq], true, NSLOT - 1, slot, cq, first, gv_t, row_stride,
+                           carry);
+    }
+    if (carry.row != kInvalidRow && slot == 0) {
+        float *p = gv_t + carry.row * row_stride;
+        if (!first) add4(carry.val, *reinterpret_cast<const float4 *>(p));
+        *reinterpret_cast<float4 *>(p) = carry.val;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 #if ZIRA_ABLATE == 9  // developer build: per-phase wall-clock stamps of K2 (100 MHz counter)
 __device__ unsigned long long zira_k2_stamps[8 * 8192];
 #define K2_STAMP(i)                                                                         \
     do {                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < 8192) zira_k2_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); \
     } while (0)
+#define K2W_STAMP(i)                                                                        \
+    do {                                                                                    \
+        if (lane == 0 && vb2 < 8192) zira_k2_stamps[vb2 * 8 + (i)] = wall_clock64();        \
+    } while (0)
 #else
 #define K2_STAMP(i)
+#define K2W_STAMP(i)
 #endif
 
 template <int D>
@@ -1058,6 +1159,148 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
         __syncthreads();  // LDS is reused by the next batch
         K2_STAMP(7);
     }
+}
+
+// K2, wave-per-tile variant for sparse calls (decoder cross-attention: a few hundred queries, a
+// few hundred entries per tile).  Same algorithm as msda_bwd_tiles, but every WAVE owns a tile
+// of <= kWaveTileRows rows and runs it start to finish on its own -- no block barriers, 16-20
+// independent tiles in flight per CU instead of 4 -- so that the cost of a tile is one dependent
+// chain (descriptors -> entries -> grad_out rows -> store) and tiles with many more entries than
+// the mean (queries cluster on objects: max/mean ~ 6 in the model) delay only their own wave.
+constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
+#ifndef ZIRA_K2W_CAP
+#define ZIRA_K2W_CAP 512
+#endif
+#ifndef ZIRA_K2W_U
+#define ZIRA_K2W_U 4   // grad_out rows in flight per lane (8 spills at 96 VGPRs: 59 us instead of 48)
+#endif
+#ifndef ZIRA_K2W_MINWAVES
+#define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
+#endif
+constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;  // entries sorted per pass (>= 264: the partial records alias them)
+constexpr unsigned kWaveK2Waves = 4;
+
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, unsigned lane)
+{
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <int D>
+__global__ __launch_bounds__(kWaveK2Waves * 64, ZIRA_K2W_MINWAVES) void msda_bwd_tiles_wave(
+    const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
+    unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, TilePlan plan,
+    const unsigned *__restrict__ desc, const uint2 *__restrict__ region,
+    float *__restrict__ grad_value)
+{
+    constexpr unsigned NSLOT = 256 / D;
+    constexpr unsigned U = ZIRA_K2W_U;
+    constexpr unsigned EPL = kWaveTileCap / 64;  // entries per lane and pass
+    constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
+    extern __shared__ unsigned lds_k2w[];
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned R = plan.rows;
+    const unsigned per_wave = 2 * R + 2 + 2 * plan.nblk + 2 + 2 * kWaveTileCap;  // words (even)
+    unsigned *base = lds_k2w + (size_t)wave * per_wave;
+    unsigned *rowcnt = base;                      // [R]
+    unsigned *rowbase = rowcnt + R;               // [R + 1]
+    unsigned *pre = rowbase + R + 1;              // [nblk + 1]
+    unsigned *runoff = pre + plan.nblk + 1;       // [nblk]
+    uint2 *sorted = reinterpret_cast<uint2 *>(base + ((2 * R + 2 + 2 * plan.nblk + 2) & ~1u));
+
+    // wave-granular head-major placement
+    const unsigned xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned vb2 = xcd * per_xcd + idx * kWaveK2Waves + wave;
+    if (idx * kWaveK2Waves + wave >= per_xcd || vb2 >= nvirt) return;  // wave-uniform
+    K2W_STAMP(0);
+    const unsigned M = Mdiv.d;
+    const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
+    const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
+    const unsigned b = fast_div(g, Mdiv), m = g - b * M;
+    const unsigned hw = (unsigned)shapes[2 * l] * (unsigned)shapes[2 * l + 1];
+    const unsigned st = (unsigned)start[l];
+    const unsigned span = tile_span(hw, Tdiv);
+    const unsigned p0 = t * span;
+    if (p0 >= hw) return;
+    const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
+
+    const unsigned slot = lane % NSLOT, cq = lane / NSLOT;
+    const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
+    float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
+    const size_t row_stride = (size_t)M * D;
+    const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
+    const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
+
+    // run-length prefix over the K1 blocks of this head
+    unsigned N = 0;
+    for (unsigned c0 = 0; c0 < plan.nblk; c0 += 64) {
+        const unsigned i = c0 + lane;
+        const unsigned dd = i < plan.nblk ? dsc[i] : 0u;
+        const unsigned n = dd & 0xffffu;
+        const unsigned incl = wave_inclusive_scan(n, lane);
+        if (i < plan.nblk) { pre[i] = N + incl - n; runoff[i] = dd >> 16; }
+        N += __shfl(incl, 63);
+    }
+    if (lane == 0) pre[plan.nblk] = N;
+    K2W_STAMP(1);
+
+    for (unsigned e_lo = 0; e_lo == 0 || e_lo < N; e_lo += kWaveTileCap) {
+        const bool first = e_lo == 0;
+        const unsigned nb = (N - e_lo < kWaveTileCap) ? N - e_lo : kWaveTileCap;
+        for (unsigned i = lane; i < rows; i += 64) rowcnt[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        unsigned keyr[EPL], wr[EPL], rankr[EPL];
+#pragma unroll
+        for (unsigned u = 0; u < EPL; ++u) {
+            const unsigned i = lane + u * 64;
+            keyr[u] = kInvalidRow;
+            if (i < nb) {
+                unsigned blk;
+                const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                const unsigned row = en.x & 0xffffu;
+                keyr[u] = ((blk * plan.ipb + (en.x >> 16)) << 12) | row;
+                wr[u] = en.y;
+                rankr[u] = atomicAdd(&rowcnt[row], 1u);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        K2W_STAMP(2);
+        unsigned run = 0;
+        for (unsigned c0 = 0; c0 < rows; c0 += 64) {  // exclusive prefix over the rows
+            const unsigned r = c0 + lane;
+            const unsigned n = r < rows ? rowcnt[r] : 0u;
+            const unsigned incl = wave_inclusive_scan(n, lane);
+            if (r < rows) rowbase[r] = run + incl - n;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) rowbase[rows] = run;
+        __builtin_amdgcn_wave_barrier();
+        K2W_STAMP(3);
+#pragma unroll
+        for (unsigned u = 0; u < EPL; ++u)
+            if (keyr[u] != kInvalidRow)
+                sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
+        __builtin_amdgcn_wave_barrier();
+        K2W_STAMP(4);
+
+        if (first) {
+            for (unsigned r = slot; r < rows; r += NSLOT)
+                if (rowbase[r + 1] == rowbase[r])
+                    *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        K2W_STAMP(5);
+        rowsum_range<NSLOT, U>(sorted, 0, nb, g_bm, gv_t, row_stride, first, slot, cq,
+                               reinterpret_cast<unsigned *>(sorted));
+        K2W_STAMP(6);
+        __builtin_amdgcn_wave_barrier();
+    }
+    K2W_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1287,6 +1530,19 @@ int launch_bwd_rows(const float *grad_out, const float *value, const int64_t *sh
 
 // ---- tiled backward: plan, workspace layout, launch ---------------------------------------
 
+inline unsigned device_cu_count()
+{
+    static unsigned cus = 0;  // one device per process (one process per GPU)
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;  // MI355X
+        cus = (unsigned)n;
+    }
+    return cus;
+}
+
 inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, TilePlan &p)
 {
     if (!(D == 16 || D == 32 || D == 64) || !lean_ok(B, S, M, D, L, Q, P)) return false;
@@ -1302,6 +1558,22 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     // K2 runs one block per tile, 4 blocks per CU: aim for one full round of the chip (the
     // per-tile critical path is a chain of dependent memory round trips, so rounds cost), with
     // at most kMaxTileRows rows per tile (12-bit row field of the sorted entries)
+    p.wave_k2 = !dense;
+    if (p.wave_k2) {  // a wave per tile: <= kWaveTileRows rows each
+        // as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD), so that the grid is one round
+        const unsigned t_min = ((unsigned)S + kWaveTileRows - 1) / kWaveTileRows;
+        const unsigned t_fit = (device_cu_count() * 4 * ZIRA_K2W_MINWAVES) / (heads * (unsigned)L);
+        p.T = t_fit > t_min ? t_fit : t_min;
+        if (p.T > (unsigned)S) p.T = (unsigned)S;
+        p.NT = (unsigned)L * p.T;
+        p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
+        p.rows = ((unsigned)S + p.T - 1) / p.T;
+        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + 2 * kWaveTileCap;
+        if (p.NT <= 4096 && per_wave * 4 * kWaveK2Waves <= 64 * 1024 && Q < (1 << 20) &&
+            ((size_t)p.NT + (size_t)p.eblk * 5) * 4 <= 150 * 1024)
+            return true;
+        p.wave_k2 = 0;  // does not fit: block-per-tile variant below
+    }
     unsigned T = ((unsigned)S + kMaxTileRows - 1) / kMaxTileRows;
     const unsigned want = (1024 + heads * L - 1) / (heads * L);
     if (T < want) T = want;
@@ -1369,6 +1641,15 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
 
+    if (p.wave_k2) {
+        const unsigned nvw = heads * p.NT, perw = (nvw + 7) >> 3;
+        const unsigned blocks_per_xcd = (perw + kWaveK2Waves - 1) / kWaveK2Waves;
+        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + 2 * kWaveTileCap;
+        hipLaunchKernelGGL(msda_bwd_tiles_wave<D>, dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
+                           per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
+                           (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, gv);
+        return (int)hipGetLastError();
+    }
     const unsigned nv2 = heads * p.NT, per2 = (nv2 + 7) >> 3;
     // LDS batch: ~2x the mean number of entries per tile, between 1K and 4K entries
     const unsigned long long mean = (unsigned long long)Q * L * P * 4 / p.NT;
