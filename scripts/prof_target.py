@@ -24,6 +24,8 @@ elif shape == "clustered":
     g = torch.Generator().manual_seed(1)
     centre = torch.rand(B, Q, 1, 1, 1, 2, generator=g) * 0.8 + 0.1
     loc = (centre + 0.05 * torch.randn(B, Q, M, 4, P, 2, generator=g)).to(dev)
+if os.environ.get("ZIRA_INPUTS"):  # captured from a model step (scripts/inmodel_msda.py): shape = dec | enc
+    v, sh, st, loc, attn, go = [t.to(dev) for t in torch.load(os.environ["ZIRA_INPUTS"])[shape]]
 for _ in range(iters):
     if which in ("fwd", "both"):
         _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)

@@ -69,12 +69,16 @@ def test_hip_matches_reference_golden(path):
     _close(gl, ref_gl, tol, "grad_sampling_loc")
 
 
-def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1, clustered=False):
+def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1, clustered=False, hot=False):
     rng = np.random.default_rng(seed)
     L = len(shapes)
     S = sum(h * w for h, w in shapes)
     value = rng.standard_normal((B, S, M, D)).astype(dtype)
-    if clustered:  # decoder-like: box centre + small offsets
+    if hot:  # every query looks at one of three spots: a few tiles receive thousands of entries
+        spots = rng.uniform(0.2, 0.8, (3, 2))
+        centre = spots[rng.integers(0, 3, (B, Q))][:, :, None, None, None, :]
+        loc = (centre + 0.01 * rng.standard_normal((B, Q, M, L, P, 2))).astype(dtype)
+    elif clustered:  # decoder-like: box centre + small offsets
         centre = rng.uniform(0.1, 0.9, (B, Q, 1, 1, 1, 2))
         loc = (centre + 0.05 * rng.standard_normal((B, Q, M, L, P, 2))).astype(dtype)
     else:
@@ -104,6 +108,9 @@ CASES = [
     # (id, B, Q, M, D, shapes, P, kwargs)
     ("northstar_decoder", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(lo=0.0, hi=1.0)),
     ("northstar_clustered", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(clustered=True)),
+    ("northstar_hot_tiles", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(hot=True)),
+    ("d16_hot_tiles", 2, 700, 8, 16, [(40, 61), (20, 31)], 4, dict(hot=True)),
+    ("d64_hot_tiles", 1, 700, 4, 64, [(40, 61), (20, 31)], 4, dict(hot=True)),
     ("oob_heavy", 2, 333, 8, 32, [(20, 31), (10, 16), (5, 8), (3, 4)], 4, dict(lo=-0.5, hi=1.5)),
     ("lp_not_16", 3, 57, 4, 32, [(12, 9), (6, 5), (3, 3), (2, 2), (1, 1)], 5, {}),
     ("one_level_p1", 2, 200, 2, 32, [(17, 23)], 1, {}),

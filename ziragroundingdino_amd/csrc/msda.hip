@@ -578,6 +578,12 @@ constexpr unsigned kItemsPerWave = 3;  // K1: items per wave; a block has 4 or 1
 #ifndef ZIRA_K2_MINWAVES
 #define ZIRA_K2_MINWAVES 4
 #endif
+#ifndef ZIRA_K2_U
+#define ZIRA_K2_U 8
+#endif
+#ifndef ZIRA_K2_EPT
+#define ZIRA_K2_EPT 8
+#endif
 constexpr unsigned kK2Threads = ZIRA_K2_THREADS;
 constexpr unsigned kMaxTileRows = 4095;
 #ifndef ZIRA_TILE_ENTRIES
@@ -595,6 +601,7 @@ struct TilePlan {
     unsigned eblk;     // entry slots per K1 block = ipb * chunks * 64
     unsigned rows;     // LDS rows per tile (upper bound: ceil(S / T))
     unsigned wave_k2;  // 1: msda_bwd_tiles_wave (a wave per tile), 0: msda_bwd_tiles (a block per tile)
+    unsigned qwords;   // words of K2's slice queue (wave_k2 only, else 0)
 };
 
 // block-granular head-major placement: virtual block id for (XCD = bid & 7, index = bid >> 3)
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
     const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv,
     unsigned LP, float invP, unsigned Q, FastDiv nblkdiv, unsigned nvirt, unsigned per_xcd,
     FastDiv Tdiv, TilePlan plan, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-    unsigned *__restrict__ desc, uint2 *__restrict__ region)
+    unsigned *__restrict__ desc, uint2 *__restrict__ region, unsigned *__restrict__ queue)
 {
     constexpr unsigned D = 16 * CQR, CQ = 4 * CQR;
     constexpr unsigned kK1Threads = kK1Waves * 64, kIPB = kK1Waves * kItemsPerWave;
@@ -636,6 +643,8 @@ __global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
     const unsigned lane = threadIdx.x & 63;
     const float *vb = value + (size_t)b * S * M * D;
 
+    // K2's slice queue (wave-per-tile variant) starts empty: header and slots zeroed here
+    for (unsigned i = vblk * kK1Threads + threadIdx.x; i < plan.qwords; i += nvirt * kK1Threads) queue[i] = 0;
     for (unsigned i = threadIdx.x; i < plan.NT; i += kK1Threads) hist[i] = 0;
     __syncthreads();
 
@@ -658,8 +667,13 @@ __global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
             const unsigned s = ch * 16 + (lane >> 2);
             const Entry k = entry_setup<true>(shapes, start, loc_i, att_i, s, lane & 3, LP, invP,
                                               M, D, m);
+#if ZIRA_ABLATE == 23
+            const float d = 0.f;
+            if (k.w == 123.f) store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
+#else
             const float d = chunk_dots<CQ>(vb, k, g4, lane);
             store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
+#endif
 
             unsigned tr = kInvalidEntry, key = 0;
             if (k.inb && k.w != 0.f) {
@@ -706,7 +720,9 @@ __global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
         const unsigned excl = total + wbase + incl - n_mine;
         if (ti < plan.NT) {
             hist[ti] = excl;
+#if ZIRA_ABLATE != 21
             desc[((size_t)g * plan.NT + ti) * plan.nblk + blk] = (excl << 16) | n_mine;
+#endif
         }
         total += ctot;
         __syncthreads();
@@ -723,6 +739,9 @@ __global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
     __syncthreads();
     uint2 *out = region + (size_t)vblk * plan.eblk;
     const uint2 *src = reinterpret_cast<const uint2 *>(sorted);
+#if ZIRA_ABLATE == 22
+    if (total == 0x7fffffffu)
+#endif
     for (unsigned i = threadIdx.x; i < total; i += kK1Threads) out[i] = src[i];
 }
 
@@ -789,6 +808,34 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *s
 // that all blocks are resident at once (one round).
 // When a tile has more than `cap` entries (the LDS batch), later batches read-modify-write
 // the rows they touch; a row is always handled by the same wave, so program order suffices.
+// How a finished row sum reaches grad_value:
+//   kRowStore  the row belongs to this batch alone: plain 16-byte store
+//   kRowRmw    a later batch of the same tile (block-per-tile K2, tile larger than the LDS batch):
+//              read-modify-write; the earlier value may come from another wave of the block (same
+//              CU, same L1: the block barrier between batches orders it)
+//   kRowAtomic the tile is shared between waves anywhere on the chip (wave-per-tile K2, slices of
+//              a heavy tile): device-scope fp32 atomics onto rows the tile's owner zeroed with
+//              device-scope stores before it published the slices.  The eight XCDs have private
+//              L2s: plain stores would need a full L2 write-back (__threadfence) to be seen by
+//              another XCD, which costs milliseconds when hundreds of owners do it.
+enum : int { kRowStore = 0, kRowRmw = 1, kRowAtomic = 2 };
+
+__device__ __forceinline__ void flush_row(float *p, float4 acc, int mode)
+{
+#if ZIRA_ABLATE == 31  // developer build (wrong results): what do the atomics cost?
+    if (mode == kRowAtomic) mode = kRowStore;
+#endif
+    if (mode == kRowAtomic) {
+        unsafeAtomicAdd(p + 0, acc.x);
+        unsafeAtomicAdd(p + 1, acc.y);
+        unsafeAtomicAdd(p + 2, acc.z);
+        unsafeAtomicAdd(p + 3, acc.w);
+        return;
+    }
+    if (mode == kRowRmw) add4(acc, *reinterpret_cast<const float4 *>(p));
+    *reinterpret_cast<float4 *>(p) = acc;
+}
+
 struct RowCarry {
     unsigned row;
     float4 val;
@@ -796,7 +843,7 @@ struct RowCarry {
 
 template <unsigned NSLOT>
 __device__ __forceinline__ void rowsum_step(unsigned row, float4 val, bool valid, unsigned last,
-                                            unsigned slot, unsigned cq, bool first,
+                                            unsigned slot, unsigned cq, int mode,
                                             float *__restrict__ gv_t, size_t row_stride,
                                             RowCarry &carry)
 {
@@ -806,9 +853,7 @@ __device__ __forceinline__ void rowsum_step(unsigned row, float4 val, bool valid
         if (row_first == carry.row) {
             if (slot == 0) add4(val, carry.val);
         } else if (slot == 0) {
-            float *p = gv_t + carry.row * row_stride;
-            if (!first) add4(carry.val, *reinterpret_cast<const float4 *>(p));
-            *reinterpret_cast<float4 *>(p) = carry.val;
+            flush_row(gv_t + carry.row * row_stride, carry.val, mode);
         }
     }
     // segmented inclusive scan over the NSLOT adjacent lanes (entries are row-sorted)
@@ -834,11 +879,7 @@ __device__ __forceinline__ void rowsum_step(unsigned row, float4 val, bool valid
     }
     const unsigned next_row = dpp_u32<0x101>(row);  // row_shl:1
     const bool tail = valid && slot != last && (slot == NSLOT - 1 || next_row != row);
-    if (tail) {
-        float *p = gv_t + row * row_stride;
-        if (!first) add4(val, *reinterpret_cast<const float4 *>(p));
-        *reinterpret_cast<float4 *>(p) = val;
-    }
+    if (tail) flush_row(gv_t + row * row_stride, val, mode);
     // The last entry's running sum travels on to the next NSLOT entries.  Only slot 0 ever
     // consumes it, and lane (cq, 0) sits NSLOT-1 lanes below lane (cq, NSLOT-1) in the same
     // DPP row, so a full step hands it over with row_shl:(NSLOT-1).  A partial step is the
@@ -848,11 +889,7 @@ __device__ __forceinline__ void rowsum_step(unsigned row, float4 val, bool valid
         carry.val = dpp_f4<0x100 + (NSLOT - 1)>(val);
     } else {
         carry.row = kInvalidRow;
-        if (slot == last) {
-            float *p = gv_t + row * row_stride;
-            if (!first) add4(val, *reinterpret_cast<const float4 *>(p));
-            *reinterpret_cast<float4 *>(p) = val;
-        }
+        if (slot == last) flush_row(gv_t + row * row_stride, val, mode);
     }
 }
 
@@ -871,33 +908,37 @@ __device__ __forceinline__ uint2 fetch_tile_entry(const uint2 *__restrict__ reg_
     return reg_g[(size_t)lo * eblk + runoff[lo] + (e - pre[lo])];
 }
 
-// Row sums of the row-sorted entries sorted[e0, e1) (LDS), formed by one wave.
+// Row sums of the row-sorted entries sorted[0, n) (LDS), formed by NW waves.
 //
-// The wave is NSLOT groups of D/4 lanes (lane = channel quad `cq` of group `slot`).  Group s
-// walks the s-th of NSLOT equal slices of the range IN ORDER, one entry per step (U grad_out rows
-// in flight), keeping the running sum of the current row in registers: a row change stores the
-// finished row with plain 16-byte stores.  That is ~4 VALU instructions per entry where a
-// segmented scan across the groups costs ~12, and K2 is VALU-bound.  Only a slice's first and
-// last row can be shared with a neighbouring slice; those 2*NSLOT partial sums go through `part`
-// (LDS, 2 KB + 64 B, may alias `sorted`: it is written after the last read of the range) and are
-// folded by two steps of the segmented scan.  Slices without a second row (or without entries)
-// contribute zero records on a neighbouring row, which keeps the record list row-sorted.
-template <unsigned NSLOT, unsigned U>
-__device__ __forceinline__ void rowsum_range(const uint2 *sorted, unsigned e0, unsigned e1,
-                                             const float *__restrict__ g_bm,
-                                             float *__restrict__ gv_t, size_t row_stride,
-                                             bool first, unsigned slot, unsigned cq,
-                                             unsigned *part)
+// A wave is NSLOT groups of D/4 lanes (lane = channel quad `cq` of group `slot`).  The range is
+// cut into NW * NSLOT equal slices; group `slot` of wave `wave` walks slice wave * NSLOT + slot IN
+// ORDER, one entry per step (U grad_out rows in flight), keeping the running sum of the current
+// row in registers: a row change stores the finished row with plain 16-byte stores.  That is ~4
+// VALU instructions per entry where a segmented scan across the groups costs ~12 (K2 is
+// VALU-bound), and the slices are balanced by entries, not by rows.  Only a slice's first and
+// last row can be shared with a neighbouring slice: those 2 * NW * NSLOT partial sums go through
+// `part` (LDS) and are folded by wave 0 with 2 * NW steps of the segmented scan.  Slices without a
+// second row (or without entries) contribute zero records on a neighbouring row, which keeps the
+// record list row-sorted.  With NW == 1 `part` may alias `sorted` (it is written after the last
+// read of the range); with NW > 1 the caller's barriers separate the two.
+constexpr unsigned kRowsumPartWords = 512 + 32;  // per wave: 2 * NSLOT records of 64 / NSLOT float4 + their rows
+
+template <unsigned NSLOT, unsigned U, unsigned NW>
+__device__ __forceinline__ void rowsum_slices(const uint2 *sorted, unsigned n,
+                                              const float *__restrict__ g_bm,
+                                              float *__restrict__ gv_t, size_t row_stride,
+                                              int mode, unsigned wave, unsigned slot,
+                                              unsigned cq, unsigned *part)
 {
     constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
     constexpr unsigned CQN = 64 / NSLOT;
-    if (e1 <= e0) return;  // wave-uniform
-    const unsigned n = e1 - e0;
-    const unsigned per = (n + NSLOT - 1) / NSLOT;
-    const unsigned a = e0 + slot * per;
-    const unsigned b = (a + per < e1) ? a + per : e1;
-    const unsigned lastrow = sorted[e1 - 1].x & 0xfffu;
-    unsigned hrow = a < b ? (sorted[a].x & 0xfffu) : lastrow;
+    // n > 0 (block-uniform, checked by the caller)
+    const unsigned per = (n + NW * NSLOT - 1) / (NW * NSLOT);
+    const unsigned sid = wave * NSLOT + slot;
+    const unsigned a = sid * per;
+    const unsigned b = (a + per < n) ? a + per : n;
+    const unsigned lastrow = sorted[n - 1].x & 0xfffu;
+    const unsigned hrow = a < b ? (sorted[a].x & 0xfffu) : lastrow;
     unsigned cur = hrow;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), hval = acc;
     for (unsigned i = 0; i < per; i += U) {
@@ -921,13 +962,8 @@ __device__ __forceinline__ void rowsum_range(const uint2 *sorted, unsigned e0, u
         for (unsigned u = 0; u < U; ++u) {
             if (rowu[u] != kInvalidRow) {
                 if (rowu[u] != cur) {
-                    if (cur == hrow) {
-                        hval = acc;
-                    } else {
-                        float *p = gv_t + cur * row_stride;
-                        if (!first) add4(acc, *reinterpret_cast<const float4 *>(p));
-                        *reinterpret_cast<float4 *>(p) = acc;
-                    }
+                    if (cur == hrow) hval = acc;
+                    else flush_row(gv_t + cur * row_stride, acc, mode);
                     cur = rowu[u];
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -940,30 +976,36 @@ __device__ __forceinline__ void rowsum_range(const uint2 *sorted, unsigned e0, u
     }
     float4 tval = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cur == hrow) hval = acc; else tval = acc;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every lane is done with sorted[e0, e1)
-    float4 *pv = reinterpret_cast<float4 *>(part);  // [2 * NSLOT][CQN]
-    unsigned *pr = part + 4 * 2 * NSLOT * CQN;      // [2 * NSLOT]
-    pv[(2 * slot) * CQN + cq] = hval;
-    pv[(2 * slot + 1) * CQN + cq] = tval;
-    if (cq == 0) { pr[2 * slot] = hrow; pr[2 * slot + 1] = cur; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // every lane is done with sorted[]
+    }
+    float4 *pv = reinterpret_cast<float4 *>(part);      // [2 * NW * NSLOT][CQN]
+    unsigned *pr = part + 4 * 2 * NW * NSLOT * CQN;     // [2 * NW * NSLOT]
+    pv[(2 * sid) * CQN + cq] = hval;
+    pv[(2 * sid + 1) * CQN + cq] = tval;
+    if (cq == 0) { pr[2 * sid] = hrow; pr[2 * sid + 1] = cur; }
+}
+
+template <unsigned NSLOT, unsigned NW>
+__device__ __forceinline__ void rowsum_fold(const unsigned *part, float *__restrict__ gv_t,
+                                            size_t row_stride, int mode, unsigned slot,
+                                            unsigned cq)
+{
+    constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
+    constexpr unsigned CQN = 64 / NSLOT;
+    const float4 *pv = reinterpret_cast<const float4 *>(part);
+    const unsigned *pr = part + 4 * 2 * NW * NSLOT * CQN;
     RowCarry carry;
     carry.row = kInvalidRow;
     carry.val = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (unsigned h = 0; h < 2; ++h) {
+    for (unsigned h = 0; h < 2 * NW; ++h) {
         const unsigned k = h * NSLOT + slot;
-        rowsum_step<NSLOT>(pr[k], pv[k * CQN + cq], true, NSLOT - 1, slot, cq, first, gv_t, row_stride,
+        rowsum_step<NSLOT>(pr[k], pv[k * CQN + cq], true, NSLOT - 1, slot, cq, mode, gv_t, row_stride,
                            carry);
     }
-    if (carry.row != kInvalidRow && slot == 0) {
-        float *p = gv_t + carry.row * row_stride;
-        if (!first) add4(carry.val, *reinterpret_cast<const float4 *>(p));
-        *reinterpret_cast<float4 *>(p) = carry.val;
-    }
-    __builtin_amdgcn_wave_barrier();
+    if (carry.row != kInvalidRow && slot == 0) flush_row(gv_t + carry.row * row_stride, carry.val, mode);
 }
 
 #if ZIRA_ABLATE == 9  // developer build: per-phase wall-clock stamps of K2 (100 MHz counter)
@@ -974,7 +1016,7 @@ __device__ unsigned long long zira_k2_stamps[8 * 8192];
     } while (0)
 #define K2W_STAMP(i)                                                                        \
     do {                                                                                    \
-        if (lane == 0 && vb2 < 8192) zira_k2_stamps[vb2 * 8 + (i)] = wall_clock64();        \
+        if (lane == 0 && stamp_id < 8192) zira_k2_stamps[stamp_id * 8 + (i)] = wall_clock64();        \
     } while (0)
 #else
 #define K2_STAMP(i)
@@ -990,8 +1032,8 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
     float *__restrict__ grad_value)
 {
     constexpr unsigned NSLOT = 256 / D;  // entries per wave instruction
-    constexpr unsigned U = 4;            // wave instructions in flight
-    constexpr unsigned EPT = 4;          // entries a thread keeps in registers between passes
+    constexpr unsigned U = ZIRA_K2_U;    // grad_out rows in flight per lane
+    constexpr unsigned EPT = ZIRA_K2_EPT;  // entries a thread keeps in registers between passes
     constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
     extern __shared__ unsigned lds_k2[];
     const unsigned R = plan.rows;
@@ -1001,7 +1043,8 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
     unsigned *runoff = pre + plan.nblk + 1;   // [nblk]   offset of the run inside its K1 slice
     unsigned *scratch = runoff + plan.nblk;   // [8]
     uint2 *sorted = reinterpret_cast<uint2 *>(scratch + 8 + ((2 * R + 1 + 2 * plan.nblk + 1) & 1));
-    // sorted[cap]: (q << 12 | row), weight -- in row order
+    // sorted[cap]: (q << 12 | row), weight -- in row order; then kRowsumPartWords per wave
+    unsigned *part = reinterpret_cast<unsigned *>(sorted + cap);
 
     K2_STAMP(0);
     unsigned vb2;
@@ -1117,45 +1160,15 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
                     *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         K2_STAMP(5);
-        const unsigned e0 = rowbase[r0], e1 = rowbase[r1];
-        RowCarry carry;
-        carry.row = kInvalidRow;
-        carry.val = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (unsigned base = e0; base < e1; base += U * NSLOT) {
-            unsigned rowu[U];
-            float4 valu[U];
-            float wu[U];
-#pragma unroll
-            for (unsigned u = 0; u < U; ++u) {  // issue all loads first
-                const unsigned e = base + u * NSLOT + slot;
-                rowu[u] = kInvalidRow;
-                wu[u] = 0.f;
-                valu[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < e1) {
-                    const uint2 en = sorted[e];
-                    rowu[u] = en.x & 0xfffu;
-                    wu[u] = __uint_as_float(en.y);
-                    valu[u] = *reinterpret_cast<const float4 *>(g_bm + (size_t)(en.x >> 12) * row_stride);
-                }
-            }
-#pragma unroll
-            for (unsigned u = 0; u < U; ++u) {
-                const unsigned b0 = base + u * NSLOT;
-                if (b0 < e1) {  // wave-uniform
-                    const unsigned last = ((e1 - b0 < NSLOT) ? e1 - b0 : NSLOT) - 1;
-                    const float4 v = make_float4(wu[u] * valu[u].x, wu[u] * valu[u].y,
-                                                 wu[u] * valu[u].z, wu[u] * valu[u].w);
-                    rowsum_step<NSLOT>(rowu[u], v, rowu[u] != kInvalidRow, last, slot, cq, first,
-                                       gv_t, row_stride, carry);
-                }
-            }
+        if (nb) {  // block-uniform
+            rowsum_slices<NSLOT, U, kK2Threads / 64>(sorted, nb, g_bm, gv_t, row_stride,
+                                                     first ? kRowStore : kRowRmw, wave, slot, cq, part);
+            __syncthreads();
+            K2_STAMP(6);
+            if (wave == 0)
+                rowsum_fold<NSLOT, kK2Threads / 64>(part, gv_t, row_stride, first ? kRowStore : kRowRmw, slot,
+                                                    cq);
         }
-        if (carry.row != kInvalidRow && slot == 0) {
-            float *p = gv_t + carry.row * row_stride;
-            if (!first) add4(carry.val, *reinterpret_cast<const float4 *>(p));
-            *reinterpret_cast<float4 *>(p) = carry.val;
-        }
-        K2_STAMP(6);
         __syncthreads();  // LDS is reused by the next batch
         K2_STAMP(7);
     }
@@ -1163,10 +1176,21 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
 
 // K2, wave-per-tile variant for sparse calls (decoder cross-attention: a few hundred queries, a
 // few hundred entries per tile).  Same algorithm as msda_bwd_tiles, but every WAVE owns a tile
-// of <= kWaveTileRows rows and runs it start to finish on its own -- no block barriers, 16-20
+// of <= kWaveTileRows rows and runs it start to finish on its own -- no block barriers, 20
 // independent tiles in flight per CU instead of 4 -- so that the cost of a tile is one dependent
-// chain (descriptors -> entries -> grad_out rows -> store) and tiles with many more entries than
-// the mean (queries cluster on objects: max/mean ~ 6 in the model) delay only their own wave.
+// chain (descriptors -> entries -> grad_out rows -> store).
+//
+// Queries cluster on objects, so some tiles hold 10-20x the mean number of entries (measured in
+// the model; uniform synthetic inputs do not show it).  A tile with more than kWaveTileCap
+// entries is cut into slices of kWaveTileCap entries: its owner handles slice 0 like any other
+// tile and publishes slices 1.. in a small queue in the workspace (one fetch-add per heavy tile).
+// A second launch of the same kernel (kHelpers = true, a fixed grid that strides over the queue;
+// it ends at once when the queue is empty) adds the remaining slices onto the stored rows with
+// fp32 atomics -- the only place the tiled path uses them: <= N / kWaveTileCap addends per row.
+// The kernel boundary is what makes the owners' plain stores visible to the atomics: the eight
+// XCDs have private L2s and fp32 atomics execute at the memory side.  (A first version let
+// finishing owner waves pop slices inside the same launch: 5000 waves contending for one queue
+// head with device-scope compare-and-swap took 14 ms.)
 constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #ifndef ZIRA_K2W_CAP
 #define ZIRA_K2W_CAP 512
@@ -1177,8 +1201,13 @@ constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #ifndef ZIRA_K2W_MINWAVES
 #define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
 #endif
-constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;  // entries sorted per pass (>= 264: the partial records alias them)
+constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;  // entries per slice
 constexpr unsigned kWaveK2Waves = 4;
+// LDS words of a wave's sorted entries; the partial records of rowsum_slices alias them
+constexpr unsigned kWaveSortWords = 2 * kWaveTileCap > kRowsumPartWords ? 2 * kWaveTileCap : kRowsumPartWords;
+constexpr unsigned kWaveHelperBlocks = 512;  // helper launch: 2048 waves stride over the queue
+constexpr unsigned kQueueHeader = 4;       // words: [0] tail, [1] head, [2..3] unused
+constexpr unsigned kQueueSliceBits = 12;   // item = ((virtual tile << 12) | slice) + 1
 
 __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, unsigned lane)
 {
@@ -1190,115 +1219,143 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, unsigned lan
     return v;
 }
 
-template <int D>
+template <int D, bool kHelpers>
 __global__ __launch_bounds__(kWaveK2Waves * 64, ZIRA_K2W_MINWAVES) void msda_bwd_tiles_wave(
     const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
     unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, TilePlan plan,
     const unsigned *__restrict__ desc, const uint2 *__restrict__ region,
-    float *__restrict__ grad_value)
+    unsigned *__restrict__ queue, float *__restrict__ grad_value)
 {
     constexpr unsigned NSLOT = 256 / D;
     constexpr unsigned U = ZIRA_K2W_U;
-    constexpr unsigned EPL = kWaveTileCap / 64;  // entries per lane and pass
+    constexpr unsigned EPL = kWaveTileCap / 64;  // entries per lane and slice
     constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
     extern __shared__ unsigned lds_k2w[];
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
     const unsigned R = plan.rows;
-    const unsigned per_wave = 2 * R + 2 + 2 * plan.nblk + 2 + 2 * kWaveTileCap;  // words (even)
+    const unsigned per_wave = 2 * R + 2 + 2 * plan.nblk + 2 + kWaveSortWords;  // words (even)
     unsigned *base = lds_k2w + (size_t)wave * per_wave;
     unsigned *rowcnt = base;                      // [R]
     unsigned *rowbase = rowcnt + R;               // [R + 1]
     unsigned *pre = rowbase + R + 1;              // [nblk + 1]
     unsigned *runoff = pre + plan.nblk + 1;       // [nblk]
     uint2 *sorted = reinterpret_cast<uint2 *>(base + ((2 * R + 2 + 2 * plan.nblk + 2) & ~1u));
-
-    // wave-granular head-major placement
-    const unsigned xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const unsigned vb2 = xcd * per_xcd + idx * kWaveK2Waves + wave;
-    if (idx * kWaveK2Waves + wave >= per_xcd || vb2 >= nvirt) return;  // wave-uniform
-    K2W_STAMP(0);
-    const unsigned M = Mdiv.d;
-    const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
-    const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
-    const unsigned b = fast_div(g, Mdiv), m = g - b * M;
-    const unsigned hw = (unsigned)shapes[2 * l] * (unsigned)shapes[2 * l + 1];
-    const unsigned st = (unsigned)start[l];
-    const unsigned span = tile_span(hw, Tdiv);
-    const unsigned p0 = t * span;
-    if (p0 >= hw) return;
-    const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
-
     const unsigned slot = lane % NSLOT, cq = lane / NSLOT;
-    const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
-    float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
+    const unsigned M = Mdiv.d;
     const size_t row_stride = (size_t)M * D;
-    const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
-    const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
 
-    // run-length prefix over the K1 blocks of this head
-    unsigned N = 0;
-    for (unsigned c0 = 0; c0 < plan.nblk; c0 += 64) {
-        const unsigned i = c0 + lane;
-        const unsigned dd = i < plan.nblk ? dsc[i] : 0u;
-        const unsigned n = dd & 0xffffu;
-        const unsigned incl = wave_inclusive_scan(n, lane);
-        if (i < plan.nblk) { pre[i] = N + incl - n; runoff[i] = dd >> 16; }
-        N += __shfl(incl, 63);
+    unsigned vb2 = 0, slice = 0, qi = 0, qn = 0;
+    if (kHelpers) {  // stride over the published slices
+        qi = blockIdx.x * kWaveK2Waves + wave;
+        qn = __builtin_amdgcn_readfirstlane(queue[0]);
+    } else {         // wave-granular head-major placement of the tiles
+        const unsigned xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        vb2 = xcd * per_xcd + idx * kWaveK2Waves + wave;
+        if (idx * kWaveK2Waves + wave >= per_xcd || vb2 >= nvirt) return;  // wave-uniform
     }
-    if (lane == 0) pre[plan.nblk] = N;
-    K2W_STAMP(1);
+    const unsigned stamp_id = kHelpers ? 0xFFFFFFFFu : vb2;
+    (void)stamp_id;
+    for (;; qi += gridDim.x * kWaveK2Waves) {
+        if (kHelpers) {
+            if (qi >= qn) break;
+            const unsigned item = __builtin_amdgcn_readfirstlane(queue[kQueueHeader + qi]) - 1;
+            vb2 = item >> kQueueSliceBits;
+            slice = item & ((1u << kQueueSliceBits) - 1);
+        }
+        K2W_STAMP(0);
+        const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
+        const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
+        const unsigned b = fast_div(g, Mdiv), m = g - b * M;
+        const unsigned hw = (unsigned)shapes[2 * l] * (unsigned)shapes[2 * l + 1];
+        const unsigned st = (unsigned)start[l];
+        const unsigned span = tile_span(hw, Tdiv);
+        const unsigned p0 = t * span;
+        if (p0 < hw) {  // else: tile past the end of a small level (owners only)
+            const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
+            const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
+            float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
+            const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
+            const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
 
-    for (unsigned e_lo = 0; e_lo == 0 || e_lo < N; e_lo += kWaveTileCap) {
-        const bool first = e_lo == 0;
-        const unsigned nb = (N - e_lo < kWaveTileCap) ? N - e_lo : kWaveTileCap;
-        for (unsigned i = lane; i < rows; i += 64) rowcnt[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        unsigned keyr[EPL], wr[EPL], rankr[EPL];
-#pragma unroll
-        for (unsigned u = 0; u < EPL; ++u) {
-            const unsigned i = lane + u * 64;
-            keyr[u] = kInvalidRow;
-            if (i < nb) {
-                unsigned blk;
-                const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
-                const unsigned row = en.x & 0xffffu;
-                keyr[u] = ((blk * plan.ipb + (en.x >> 16)) << 12) | row;
-                wr[u] = en.y;
-                rankr[u] = atomicAdd(&rowcnt[row], 1u);
+            // run-length prefix over the K1 blocks of this head
+            unsigned N = 0;
+            for (unsigned c0 = 0; c0 < plan.nblk; c0 += 64) {
+                const unsigned i = c0 + lane;
+                const unsigned dd = i < plan.nblk ? dsc[i] : 0u;
+                const unsigned n = dd & 0xffffu;
+                const unsigned incl = wave_inclusive_scan(n, lane);
+                if (i < plan.nblk) { pre[i] = N + incl - n; runoff[i] = dd >> 16; }
+                N += __shfl(incl, 63);
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        K2W_STAMP(2);
-        unsigned run = 0;
-        for (unsigned c0 = 0; c0 < rows; c0 += 64) {  // exclusive prefix over the rows
-            const unsigned r = c0 + lane;
-            const unsigned n = r < rows ? rowcnt[r] : 0u;
-            const unsigned incl = wave_inclusive_scan(n, lane);
-            if (r < rows) rowbase[r] = run + incl - n;
-            run += __shfl(incl, 63);
-        }
-        if (lane == 0) rowbase[rows] = run;
-        __builtin_amdgcn_wave_barrier();
-        K2W_STAMP(3);
-#pragma unroll
-        for (unsigned u = 0; u < EPL; ++u)
-            if (keyr[u] != kInvalidRow)
-                sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
-        __builtin_amdgcn_wave_barrier();
-        K2W_STAMP(4);
+            if (lane == 0) pre[plan.nblk] = N;
+            K2W_STAMP(1);
 
-        if (first) {
-            for (unsigned r = slot; r < rows; r += NSLOT)
-                if (rowbase[r + 1] == rowbase[r])
-                    *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!kHelpers && N > kWaveTileCap && lane == 0) {  // publish slices 1 .. extra
+                const unsigned extra = (N - 1) / kWaveTileCap;
+                const unsigned at = __hip_atomic_fetch_add(&queue[0], extra, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned k = 1; k <= extra; ++k)
+                    queue[kQueueHeader + at + k - 1] = ((vb2 << kQueueSliceBits) | k) + 1;
+            }
+            const int mode = kHelpers ? kRowAtomic : kRowStore;
+            const unsigned e_lo = slice * kWaveTileCap;
+            const unsigned nb = (N - e_lo < kWaveTileCap) ? N - e_lo : kWaveTileCap;
+
+            for (unsigned i = lane; i < rows; i += 64) rowcnt[i] = 0;
+            __builtin_amdgcn_wave_barrier();
+            unsigned keyr[EPL], wr[EPL], rankr[EPL];
+#pragma unroll
+            for (unsigned u = 0; u < EPL; ++u) {
+                const unsigned i = lane + u * 64;
+                keyr[u] = kInvalidRow;
+                if (i < nb) {
+                    unsigned blk;
+                    const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                    const unsigned row = en.x & 0xffffu;
+                    keyr[u] = ((blk * plan.ipb + (en.x >> 16)) << 12) | row;
+                    wr[u] = en.y;
+                    rankr[u] = atomicAdd(&rowcnt[row], 1u);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            K2W_STAMP(2);
+            unsigned run = 0;
+            for (unsigned c0 = 0; c0 < rows; c0 += 64) {  // exclusive prefix over the rows
+                const unsigned r = c0 + lane;
+                const unsigned n = r < rows ? rowcnt[r] : 0u;
+                const unsigned incl = wave_inclusive_scan(n, lane);
+                if (r < rows) rowbase[r] = run + incl - n;
+                run += __shfl(incl, 63);
+            }
+            if (lane == 0) rowbase[rows] = run;
+            __builtin_amdgcn_wave_barrier();
+            K2W_STAMP(3);
+#pragma unroll
+            for (unsigned u = 0; u < EPL; ++u)
+                if (keyr[u] != kInvalidRow)
+                    sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
+            __builtin_amdgcn_wave_barrier();
+            K2W_STAMP(4);
+
+            if (!kHelpers) {  // rows nobody contributes to (in slice 0) are stored as zeros
+                for (unsigned r = slot; r < rows; r += NSLOT)
+                    if (rowbase[r + 1] == rowbase[r])
+                        *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            K2W_STAMP(5);
+            if (nb) {
+                unsigned *part = reinterpret_cast<unsigned *>(sorted);
+                rowsum_slices<NSLOT, U, 1>(sorted, nb, g_bm, gv_t, row_stride, mode, 0, slot, cq, part);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                rowsum_fold<NSLOT, 1>(part, gv_t, row_stride, mode, slot, cq);
+            }
+            K2W_STAMP(6);
+            __builtin_amdgcn_wave_barrier();
         }
-        K2W_STAMP(5);
-        rowsum_range<NSLOT, U>(sorted, 0, nb, g_bm, gv_t, row_stride, first, slot, cq,
-                               reinterpret_cast<unsigned *>(sorted));
-        K2W_STAMP(6);
-        __builtin_amdgcn_wave_barrier();
+        if (!kHelpers) break;
     }
     K2W_STAMP(7);
 }
@@ -1559,6 +1616,7 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     // per-tile critical path is a chain of dependent memory round trips, so rounds cost), with
     // at most kMaxTileRows rows per tile (12-bit row field of the sorted entries)
     p.wave_k2 = !dense;
+    p.qwords = 0;
     if (p.wave_k2) {  // a wave per tile: <= kWaveTileRows rows each
         // as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD), so that the grid is one round
         const unsigned t_min = ((unsigned)S + kWaveTileRows - 1) / kWaveTileRows;
@@ -1568,10 +1626,15 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
         p.NT = (unsigned)L * p.T;
         p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
         p.rows = ((unsigned)S + p.T - 1) / p.T;
-        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + 2 * kWaveTileCap;
+        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + kWaveSortWords;
+        // a heavy tile publishes ceil(N / cap) - 1 slices: at most (all entries) / cap in total
+        const unsigned long long all_entries = (unsigned long long)heads * Q * L * P * 4;
+        p.qwords = kQueueHeader + (unsigned)(all_entries / kWaveTileCap) + 1;
         if (p.NT <= 4096 && per_wave * 4 * kWaveK2Waves <= 64 * 1024 && Q < (1 << 20) &&
+            (unsigned long long)heads * p.NT < (1ull << (32 - kQueueSliceBits)) &&
             ((size_t)p.NT + (size_t)p.eblk * 5) * 4 <= 150 * 1024)
             return true;
+        p.qwords = 0;
         p.wave_k2 = 0;  // does not fit: block-per-tile variant below
     }
     unsigned T = ((unsigned)S + kMaxTileRows - 1) / kMaxTileRows;
@@ -1602,9 +1665,14 @@ inline size_t tile_desc_bytes(const TilePlan &p, int B, int M)
     return align256((size_t)B * M * p.NT * p.nblk * sizeof(unsigned));
 }
 
+inline size_t tile_region_bytes(const TilePlan &p, int B, int M)
+{
+    return align256((size_t)B * M * p.nblk * p.eblk * sizeof(uint2));
+}
+
 inline size_t tile_workspace_bytes(const TilePlan &p, int B, int M)
 {
-    return tile_desc_bytes(p, B, M) + (size_t)B * M * p.nblk * p.eblk * sizeof(uint2);
+    return tile_desc_bytes(p, B, M) + tile_region_bytes(p, B, M) + (size_t)p.qwords * sizeof(unsigned);
 }
 
 template <int CQR>
@@ -1616,6 +1684,7 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     constexpr int D = 16 * CQR;
     unsigned *desc = reinterpret_cast<unsigned *>(ws);
     uint2 *region = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(ws) + tile_desc_bytes(p, B, M));
+    unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(region) + tile_region_bytes(p, B, M));
     const unsigned heads = (unsigned)B * M;
     const FastDiv Mdiv = make_fast_div((unsigned)M), Tdiv = make_fast_div(p.T);
 
@@ -1632,22 +1701,31 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
         hipLaunchKernelGGL((msda_bwd_items<CQR, 16>), dim3(per1 * 8), dim3(16 * 64), lds1, st,
                            grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
                            (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
-                           nv1, per1, Tdiv, p, gl, ga, desc, region);
+                           nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
     else
         hipLaunchKernelGGL((msda_bwd_items<CQR, 4>), dim3(per1 * 8), dim3(4 * 64), lds1, st,
                            grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
                            (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
-                           nv1, per1, Tdiv, p, gl, ga, desc, region);
+                           nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+#if ZIRA_ABLATE >= 21 && ZIRA_ABLATE <= 29
+    return 0;  // developer build: K1 alone
+#endif
 
     if (p.wave_k2) {
         const unsigned nvw = heads * p.NT, perw = (nvw + 7) >> 3;
         const unsigned blocks_per_xcd = (perw + kWaveK2Waves - 1) / kWaveK2Waves;
-        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + 2 * kWaveTileCap;
-        hipLaunchKernelGGL(msda_bwd_tiles_wave<D>, dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
+        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + kWaveSortWords;
+        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false>), dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
                            per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
-                           (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, gv);
+                           (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        // slices 1.. of heavy tiles (ends at once when there are none)
+        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, true>), dim3(kWaveHelperBlocks), dim3(kWaveK2Waves * 64),
+                           per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
+                           (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
         return (int)hipGetLastError();
     }
     const unsigned nv2 = heads * p.NT, per2 = (nv2 + 7) >> 3;
@@ -1655,7 +1733,8 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     const unsigned long long mean = (unsigned long long)Q * L * P * 4 / p.NT;
     unsigned cap = 1024;
     while (cap < 8192 && cap < 2 * mean) cap <<= 1;
-    const size_t lds2 = ((size_t)p.rows * 2 + 1 + 2 * p.nblk + 1 + 8 + 1 + (size_t)cap * 2) * 4;
+    const size_t lds2 = ((size_t)p.rows * 2 + 1 + 2 * p.nblk + 1 + 8 + 1 + (size_t)cap * 2 +
+                         (kK2Threads / 64) * kRowsumPartWords) * 4;
     if (lds2 > 64 * 1024) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiles<D>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
