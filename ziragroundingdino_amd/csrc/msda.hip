@@ -579,7 +579,7 @@ constexpr unsigned kItemsPerWave = 3;  // K1: items per wave; a block has 4 or 1
 #define ZIRA_K2_MINWAVES 4
 #endif
 #ifndef ZIRA_K2_U
-#define ZIRA_K2_U 8
+#define ZIRA_K2_U 4   // grad_out rows in flight per lane
 #endif
 #ifndef ZIRA_K2_EPT
 #define ZIRA_K2_EPT 8
@@ -893,6 +893,20 @@ __device__ __forceinline__ void rowsum_step(unsigned row, float4 val, bool valid
     }
 }
 
+// entry e of the tile -> K1 block and position in the K1 region, through the run prefix in LDS
+__device__ __forceinline__ void locate_tile_entry(const unsigned *pre, const unsigned *runoff,
+                                                  unsigned nblk, unsigned eblk, unsigned e,
+                                                  unsigned &blk, unsigned &pos)
+{
+    unsigned lo = 0, hi = nblk;  // largest blk with pre[blk] <= e
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (pre[mid] <= e) lo = mid; else hi = mid;
+    }
+    blk = lo;
+    pos = lo * eblk + runoff[lo] + (e - pre[lo]);
+}
+
 // entry e of the tile -> (K1 block, entry) through the run prefix kept in LDS
 __device__ __forceinline__ uint2 fetch_tile_entry(const uint2 *__restrict__ reg_g,
                                                   const unsigned *pre, const unsigned *runoff,
@@ -923,7 +937,7 @@ __device__ __forceinline__ uint2 fetch_tile_entry(const uint2 *__restrict__ reg_
 // read of the range); with NW > 1 the caller's barriers separate the two.
 constexpr unsigned kRowsumPartWords = 512 + 32;  // per wave: 2 * NSLOT records of 64 / NSLOT float4 + their rows
 
-template <unsigned NSLOT, unsigned U, unsigned NW>
+template <unsigned NSLOT, unsigned U, unsigned NW, bool kPrefetch>
 __device__ __forceinline__ void rowsum_slices(const uint2 *sorted, unsigned n,
                                               const float *__restrict__ g_bm,
                                               float *__restrict__ gv_t, size_t row_stride,
@@ -941,37 +955,71 @@ __device__ __forceinline__ void rowsum_slices(const uint2 *sorted, unsigned n,
     const unsigned hrow = a < b ? (sorted[a].x & 0xfffu) : lastrow;
     unsigned cur = hrow;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), hval = acc;
-    for (unsigned i = 0; i < per; i += U) {
-        unsigned rowu[U];
-        float wu[U];
-        float4 gu[U];
-#pragma unroll
-        for (unsigned u = 0; u < U; ++u) {  // issue all loads first
-            const unsigned e = a + i + u;
-            rowu[u] = kInvalidRow;
-            wu[u] = 0.f;
-            gu[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < b) {
-                const uint2 en = sorted[e];
-                rowu[u] = en.x & 0xfffu;
-                wu[u] = __uint_as_float(en.y);
-                gu[u] = *reinterpret_cast<const float4 *>(g_bm + (size_t)(en.x >> 12) * row_stride);
-            }
-        }
+    // two batches of U entries in flight: while one is folded the other one's grad_out rows load
+    struct Batch {
+        unsigned row[U];
+        float w[U];
+        float4 g[U];
+    };
+    // Block-per-tile K2 (kPrefetch false) issues branch-free and behind a scheduling barrier: with
+    // the loads under `if (e < b)` the compiler has been seen to wait for each one before issuing
+    // the next (536 -> 625 us on the encoder shape); lanes past their slice read the last entry of
+    // the range and ignore it.  The wave-per-tile K2 schedules the predicated form well and saves
+    // the wasted loads (48.8 vs 50.3 us).
+    auto issue = [&](Batch &t, unsigned i) {
 #pragma unroll
         for (unsigned u = 0; u < U; ++u) {
-            if (rowu[u] != kInvalidRow) {
-                if (rowu[u] != cur) {
+            const unsigned e = a + i + u;
+            if (kPrefetch) {
+                t.row[u] = kInvalidRow;
+                t.w[u] = 0.f;
+                t.g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < b) {
+                    const uint2 en = sorted[e];
+                    t.row[u] = en.x & 0xfffu;
+                    t.w[u] = __uint_as_float(en.y);
+                    t.g[u] = *reinterpret_cast<const float4 *>(g_bm + (size_t)(en.x >> 12) * row_stride);
+                }
+            } else {
+                const uint2 en = sorted[e < n ? e : n - 1];
+                t.row[u] = e < b ? (en.x & 0xfffu) : kInvalidRow;
+                t.w[u] = __uint_as_float(en.y);
+                t.g[u] = *reinterpret_cast<const float4 *>(g_bm + (size_t)(en.x >> 12) * row_stride);
+            }
+        }
+    };
+    auto fold = [&](const Batch &t) {
+#pragma unroll
+        for (unsigned u = 0; u < U; ++u) {
+            if (t.row[u] != kInvalidRow) {
+                if (t.row[u] != cur) {
                     if (cur == hrow) hval = acc;
                     else flush_row(gv_t + cur * row_stride, acc, mode);
-                    cur = rowu[u];
+                    cur = t.row[u];
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                acc.x = fmaf(wu[u], gu[u].x, acc.x);
-                acc.y = fmaf(wu[u], gu[u].y, acc.y);
-                acc.z = fmaf(wu[u], gu[u].z, acc.z);
-                acc.w = fmaf(wu[u], gu[u].w, acc.w);
+                acc.x = fmaf(t.w[u], t.g[u].x, acc.x);
+                acc.y = fmaf(t.w[u], t.g[u].y, acc.y);
+                acc.z = fmaf(t.w[u], t.g[u].z, acc.z);
+                acc.w = fmaf(t.w[u], t.g[u].w, acc.w);
             }
+        }
+    };
+    if (kPrefetch) {  // wave-per-tile K2: one tile per wave, the chain of round trips is what costs
+        Batch ping, pong;
+        issue(ping, 0);
+        for (unsigned i = 0; i < per; i += 2 * U) {
+            issue(pong, i + U);
+            fold(ping);
+            issue(ping, i + 2 * U);
+            fold(pong);
+        }
+    } else {          // block-per-tile K2: the registers buy more than the overlap (measured)
+        for (unsigned i = 0; i < per; i += U) {
+            Batch t;
+            issue(t, i);
+            __builtin_amdgcn_sched_barrier(0);  // keep the U loads together, ahead of the first use
+            fold(t);
         }
     }
     float4 tval = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1161,7 +1209,7 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
         }
         K2_STAMP(5);
         if (nb) {  // block-uniform
-            rowsum_slices<NSLOT, U, kK2Threads / 64>(sorted, nb, g_bm, gv_t, row_stride,
+            rowsum_slices<NSLOT, U, kK2Threads / 64, false>(sorted, nb, g_bm, gv_t, row_stride,
                                                      first ? kRowStore : kRowRmw, wave, slot, cq, part);
             __syncthreads();
             K2_STAMP(6);
@@ -1196,7 +1244,7 @@ constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #define ZIRA_K2W_CAP 512
 #endif
 #ifndef ZIRA_K2W_U
-#define ZIRA_K2W_U 4   // grad_out rows in flight per lane (8 spills at 96 VGPRs: 59 us instead of 48)
+#define ZIRA_K2W_U 4   // grad_out rows per lane and batch; two batches are in flight (helpers: half)
 #endif
 #ifndef ZIRA_K2W_MINWAVES
 #define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
@@ -1220,7 +1268,7 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, unsigned lan
 }
 
 template <int D, bool kHelpers>
-__global__ __launch_bounds__(kWaveK2Waves * 64, ZIRA_K2W_MINWAVES) void msda_bwd_tiles_wave(
+__global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES) void msda_bwd_tiles_wave(
     const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
     unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, TilePlan plan,
@@ -1228,7 +1276,7 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, ZIRA_K2W_MINWAVES) void msda_bwd
     unsigned *__restrict__ queue, float *__restrict__ grad_value)
 {
     constexpr unsigned NSLOT = 256 / D;
-    constexpr unsigned U = ZIRA_K2W_U;
+    constexpr unsigned U = kHelpers ? ZIRA_K2W_U / 2 : ZIRA_K2W_U;
     constexpr unsigned EPL = kWaveTileCap / 64;  // entries per lane and slice
     constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
     extern __shared__ unsigned lds_k2w[];
@@ -1305,17 +1353,30 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, ZIRA_K2W_MINWAVES) void msda_bwd
 
             for (unsigned i = lane; i < rows; i += 64) rowcnt[i] = 0;
             __builtin_amdgcn_wave_barrier();
-            unsigned keyr[EPL], wr[EPL], rankr[EPL];
+            // three separate sweeps so that the binary searches (LDS), the entry loads (global) and
+            // the rank atomics (LDS) of the EPL entries of a lane overlap instead of chaining
+            unsigned keyr[EPL], wr[EPL], rankr[EPL], posr[EPL];
 #pragma unroll
             for (unsigned u = 0; u < EPL; ++u) {
                 const unsigned i = lane + u * 64;
                 keyr[u] = kInvalidRow;
+                posr[u] = 0;
                 if (i < nb) {
                     unsigned blk;
-                    const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
-                    const unsigned row = en.x & 0xffffu;
-                    keyr[u] = ((blk * plan.ipb + (en.x >> 16)) << 12) | row;
-                    wr[u] = en.y;
+                    locate_tile_entry(pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk, posr[u]);
+                    keyr[u] = blk * plan.ipb;
+                }
+            }
+            uint2 enr[EPL];
+#pragma unroll
+            for (unsigned u = 0; u < EPL; ++u)
+                enr[u] = keyr[u] != kInvalidRow ? reg_g[posr[u]] : make_uint2(0u, 0u);
+#pragma unroll
+            for (unsigned u = 0; u < EPL; ++u) {
+                if (keyr[u] != kInvalidRow) {
+                    const unsigned row = enr[u].x & 0xffffu;
+                    keyr[u] = ((keyr[u] + (enr[u].x >> 16)) << 12) | row;
+                    wr[u] = enr[u].y;
                     rankr[u] = atomicAdd(&rowcnt[row], 1u);
                 }
             }
@@ -1347,7 +1408,7 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, ZIRA_K2W_MINWAVES) void msda_bwd
             K2W_STAMP(5);
             if (nb) {
                 unsigned *part = reinterpret_cast<unsigned *>(sorted);
-                rowsum_slices<NSLOT, U, 1>(sorted, nb, g_bm, gv_t, row_stride, mode, 0, slot, cq, part);
+                rowsum_slices<NSLOT, U, 1, true>(sorted, nb, g_bm, gv_t, row_stride, mode, 0, slot, cq, part);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 rowsum_fold<NSLOT, 1>(part, gv_t, row_stride, mode, slot, cq);
