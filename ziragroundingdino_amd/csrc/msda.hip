@@ -29,6 +29,9 @@
 
 #include "zira_msda.h"
 
+#ifndef ZIRA_K1_GATHERS
+#define ZIRA_K1_GATHERS 8
+#endif
 #ifndef ZIRA_ABLATE
 #define ZIRA_ABLATE 0  // developer-only ablation switches; 0 in every shipped build
 #endif
@@ -464,17 +467,30 @@ __device__ __forceinline__ float chunk_dots(const float *__restrict__ vb, const 
     const int back = (int)((lane % SLOTS) * CQ * 4);
     const int offb_i = (int)k.offb;
     float mine = 0.f;
+    // All NI row gathers are issued before the first dot product.  Written as two loops with a
+    // scheduling barrier in between: left to itself the compiler put `s_waitcnt vmcnt(0)` behind
+    // every load (NI dependent round trips per chunk, K1 at twice the forward's time).
+    constexpr unsigned G = NI < ZIRA_K1_GATHERS ? NI : ZIRA_K1_GATHERS;  // gathers in flight
 #pragma unroll
-    for (unsigned j = 0; j < NI; ++j) {
-        const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)(j * SLOTS * 4), offb_i);
-        const float4 v = load_row16(vb, oj + cq * 16);
-        float d = v.x * g4.x;
-        d = fmaf(v.y, g4.y, d);
-        d = fmaf(v.z, g4.z, d);
-        d = fmaf(v.w, g4.w, d);
-        d = sum_over_row_lanes<CQ>(d);
-        const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d)));
-        if (lane / SLOTS == j) mine = t;
+    for (unsigned j0 = 0; j0 < NI; j0 += G) {
+        float4 v[G];
+#pragma unroll
+        for (unsigned j = 0; j < G; ++j) {
+            const unsigned oj =
+                (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)((j0 + j) * SLOTS * 4), offb_i);
+            v[j] = load_row16(vb, oj + cq * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (unsigned j = 0; j < G; ++j) {
+            float d = v[j].x * g4.x;
+            d = fmaf(v[j].y, g4.y, d);
+            d = fmaf(v[j].z, g4.z, d);
+            d = fmaf(v[j].w, g4.w, d);
+            d = sum_over_row_lanes<CQ>(d);
+            const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d)));
+            if (lane / SLOTS == j0 + j) mine = t;
+        }
     }
     return k.inb ? mine : 0.f;
 }
@@ -618,8 +634,11 @@ __device__ __forceinline__ unsigned tile_span(unsigned hw, FastDiv T)
     return fast_div(hw + T.d - 1, T);
 }
 
+// Occupancy: the dense variant (16 waves, 64 KB of LDS per block) is held to 64 VGPRs so that two
+// blocks fit a CU (20 B of spill, still 1.5% faster than one block at 77 VGPRs); the sparse variant
+// runs at 75 VGPRs with all eight gathers of a chunk in flight.
 template <int CQR, unsigned kK1Waves>
-__global__ __launch_bounds__(kK1Waves * 64) void msda_bwd_items(
+__global__ __launch_bounds__(kK1Waves * 64, kK1Waves == 16 ? 8 : 6) void msda_bwd_items(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
     const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv,
