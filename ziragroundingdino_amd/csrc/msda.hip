@@ -600,10 +600,13 @@ constexpr unsigned kItemsPerWave = 3;  // K1: items per wave; a block has 4 or 1
 #ifndef ZIRA_K2_EPT
 #define ZIRA_K2_EPT 8
 #endif
+#ifndef ZIRA_K2_FETCH_GROUP
+#define ZIRA_K2_FETCH_GROUP 8
+#endif
 constexpr unsigned kK2Threads = ZIRA_K2_THREADS;
 constexpr unsigned kMaxTileRows = 4095;
 #ifndef ZIRA_TILE_ENTRIES
-#define ZIRA_TILE_ENTRIES 2048
+#define ZIRA_TILE_ENTRIES 1024
 #endif
 constexpr unsigned kTargetTileEntries = ZIRA_TILE_ENTRIES;
 constexpr unsigned kInvalidEntry = 0xFFFFFFFFu;
@@ -1162,17 +1165,37 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
         // pass 1: count entries per row; small batches keep {entry, rank} in registers
         unsigned keyr[EPT], wr[EPT], rankr[EPT];
         if (in_regs) {
+            // groups of kFetchGroup entries: binary searches (LDS), then the entry loads (global)
+            // back to back, then the rank atomics (LDS) -- left alone the compiler waits for
+            // every load before it starts the next search
+            constexpr unsigned kFetchGroup = ZIRA_K2_FETCH_GROUP;
 #pragma unroll
-            for (unsigned u = 0; u < EPT; ++u) {
-                const unsigned i = threadIdx.x + u * kK2Threads;
-                keyr[u] = kInvalidRow;
-                if (i < nb) {
-                    unsigned blk;
-                    const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
-                    const unsigned row = en.x & 0xffffu;
-                    keyr[u] = ((blk * plan.ipb + (en.x >> 16)) << 12) | row;
-                    wr[u] = en.y;
-                    rankr[u] = atomicAdd(&rowcnt[row], 1u);
+            for (unsigned u0 = 0; u0 < EPT; u0 += kFetchGroup) {
+                unsigned posr[kFetchGroup];
+                uint2 enr[kFetchGroup];
+#pragma unroll
+                for (unsigned v = 0; v < kFetchGroup; ++v) {
+                    const unsigned u = u0 + v, i = threadIdx.x + u * kK2Threads;
+                    keyr[u] = kInvalidRow;
+                    posr[v] = 0;
+                    if (i < nb) {
+                        unsigned blk;
+                        locate_tile_entry(pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk, posr[v]);
+                        keyr[u] = blk * plan.ipb;
+                    }
+                }
+#pragma unroll
+                for (unsigned v = 0; v < kFetchGroup; ++v) enr[v] = reg_g[posr[v]];  // slot 0 if unused
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (unsigned v = 0; v < kFetchGroup; ++v) {
+                    const unsigned u = u0 + v;
+                    if (keyr[u] != kInvalidRow) {
+                        const unsigned row = enr[v].x & 0xffffu;
+                        keyr[u] = ((keyr[u] + (enr[v].x >> 16)) << 12) | row;
+                        wr[u] = enr[v].y;
+                        rankr[u] = atomicAdd(&rowcnt[row], 1u);
+                    }
                 }
             }
         } else {
