@@ -119,7 +119,8 @@ def pmc_traffic():
         dec = json.load(open(files[-1]))["decoder"]
         total = sum(k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"] for k in dec.values())
         return {"traffic": total, "traffic_source": os.path.relpath(files[-1], ROOT) +
-                " (uniform sampling locations at the same shape; sum of msda_fwd_lean, msda_bwd_items, msda_bwd_tiles)"}
+                " (uniform sampling locations at the same shape; sum over " +
+                ", ".join(sorted(k.split("<")[0] for k in dec)) + ")"}
     except Exception:
         return None
 

@@ -1295,7 +1295,7 @@ constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;  // entries per slice
 constexpr unsigned kWaveK2Waves = 4;
 // LDS words of a wave's sorted entries; the partial records of rowsum_slices alias them
 constexpr unsigned kWaveSortWords = 2 * kWaveTileCap > kRowsumPartWords ? 2 * kWaveTileCap : kRowsumPartWords;
-constexpr unsigned kWaveHelperBlocks = 512;  // helper launch: 2048 waves stride over the queue
+constexpr unsigned kWaveHelperBlocks = 512;  // helper launch: 2048 waves stride over the queue (an empty launch costs ~2 us whatever the grid)
 constexpr unsigned kQueueHeader = 4;       // words: [0] tail, [1] head, [2..3] unused
 constexpr unsigned kQueueSliceBits = 12;   // item = ((virtual tile << 12) | slice) + 1
 
@@ -1999,6 +1999,11 @@ const char *zira_msda_version(void) { return "zira_msda 0.1 gfx950"; }
 
 const char *zira_msda_variant_f32(int D)
 {
+    // D = 16 / 32 / 64 take the lean kernels (and, with a workspace, the tiled backward) whenever
+    // the call passes lean_ok(); the other specialised widths use the row-per-group kernels
+    if (D == 16 || D == 32 || D == 64)
+        return "fwd msda_fwd_lean; bwd msda_bwd_items + msda_bwd_tiles[_wave] (atomic-free, workspace) "
+               "or msda_bwd_lean_atomic";
     switch (lpr_for(D)) {
         case 1: return "rows<1>";
         case 2: return "rows<2>";

@@ -53,6 +53,19 @@ def _cascade_reduce(x: Tensor, op: str) -> Tensor:
     return v.amax() if op == "max" else v.sum()
 
 
+def _max_over_tokens(x: Tensor) -> Tensor:
+    """max over dim 1 of x [B, N, T] (N = 22 k image tokens, T = a few text tokens), shape
+    [B, 1, T], with ``torch.max(dim)``'s gradient routing.  One ``max`` over the strided long
+    dimension takes 250 us here (16 * T outputs, one block each); two short ones take ~15 us."""
+    B, N, T = x.shape
+    if N <= 512:
+        return x.max(dim=1, keepdim=True)[0]
+    pad = (-N) % 256
+    if pad:
+        x = F.pad(x, (0, 0, 0, pad), value=float("-inf"))
+    return x.view(B, -1, 256, T).max(dim=2)[0].max(dim=1, keepdim=True)[0]
+
+
 class _SubtractGlobalMax(torch.autograd.Function):
     """x - x.max() with the gradient autograd would give it (g - onehot(argmax) * sum(g), ties
     shared evenly) -- the reference's ``attn_weights - attn_weights.max()`` (fuse_modules.py:169).
@@ -124,7 +137,8 @@ class BiMultiHeadAttention(nn.Module):
             attn = torch.clamp(attn, max=50000)
 
         attn_T = attn.transpose(1, 2)
-        attn_l = attn_T - torch.max(attn_T, dim=-1, keepdim=True)[0]
+        # reference: attn_T - torch.max(attn_T, dim=-1, keepdim=True)[0]  (fuse_modules.py:180)
+        attn_l = attn_T - _max_over_tokens(attn).transpose(1, 2)
         if self.clamp_min_for_underflow:
             attn_l = torch.clamp(attn_l, min=-50000)
         if self.clamp_max_for_overflow:
