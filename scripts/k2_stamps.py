@@ -27,3 +27,23 @@ for i, nme in enumerate(names):
     print("  %-18s mean %7.2f us  p50 %7.2f  max %7.2f" % (nme, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
 print("  block lifetime     mean %7.2f us  max %7.2f" % (((a[:, 7] - a[:, 0]) / 100.0).mean(), ((a[:, 7] - a[:, 0]) / 100.0).max()))
 print("  block start spread (us): p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile((a[:, 0] - t0) / 100.0, [50, 90, 100])))
+# wave-per-tile K2: lifetime and phases by level (sparse plan: T tiles per level = row stamps / heads / L)
+if loc.shape[1] != v.shape[1]:
+    B, Q, M, L = loc.shape[0], loc.shape[1], loc.shape[2], loc.shape[3]
+    full = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
+    nt = None
+    for T in range(1, 400):
+        if B * M * L * T >= (full[:, 0] > 0).sum() and B * M * L * T <= 8192:
+            nt = L * T
+            break
+    if nt:
+        ids = np.nonzero((full[:, 0] > 0) & (full[:, 7] > 0))[0]
+        lvl = (ids % nt) // (nt // L)
+        life = (full[ids, 7] - full[ids, 0]) / 100.0
+        dd = np.diff(full[ids], axis=1) / 100.0
+        for l in range(L):
+            m = lvl == l
+            if m.any():
+                print("  level %d: %4d waves, lifetime mean %6.2f p90 %6.2f max %6.2f | phases mean %s" % (
+                    l, m.sum(), life[m].mean(), np.percentile(life[m], 90), life[m].max(),
+                    " ".join("%5.2f" % x for x in dd[m].mean(0))))
