@@ -348,3 +348,44 @@ def test_backbone_variants_feature_geometry():
             feats, poss = bb(utils.NestedTensor(x, m))
         assert [tuple(f.tensors.shape[1:]) for f in feats] == [(chans[0], 13, 17), (chans[1], 7, 9), (chans[2], 4, 5)]
         assert all(p.shape[1] == 256 and p.shape[2:] == f.tensors.shape[2:] for p, f in zip(poss, feats))
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_stacked_criterion_equals_per_set_loop(dev):
+    """The criterion's stacked fast path (all 7 prediction sets at once) against its per-set loop,
+    which is the reference's structure (two_stage_criterion.py:37-100) and is itself pinned to the
+    reference by ``test_two_stage_criterion``: same assignments, same 21 loss values, same
+    gradients."""
+    from types import SimpleNamespace
+
+    g = torch.Generator().manual_seed(11)
+    S, B, Q, C = 7, 2, 40, 32
+    logits = (torch.randn(S, B, Q, C, generator=g) * 2).to(dev).requires_grad_(True)
+    cxcy = torch.rand(S, B, Q, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(S, B, Q, 2, generator=g) * 0.3 + 0.05
+    boxes = torch.cat([cxcy, wh], -1).to(dev).requires_grad_(True)
+    targets = []
+    for n in (5, 3):
+        c = torch.rand(n, 2, generator=g) * 0.5 + 0.25
+        w = torch.rand(n, 2, generator=g) * 0.3 + 0.1
+        targets.append({"labels": torch.randint(0, 6, (n,), generator=g).to(dev), "boxes": torch.cat([c, w], -1).to(dev)})
+    crit = criterion.build_criterion(SimpleNamespace(aux_loss=True, dec_layers=6, max_text_len=C)).to(dev)
+    suffixes = ["_%d" % i for i in range(5)] + ["", "_enc"]
+    out = {"pred_logits": logits[5], "pred_boxes": boxes[5],
+           "aux_outputs": [{"pred_logits": logits[i], "pred_boxes": boxes[i]} for i in range(5)],
+           "enc_outputs": {"pred_logits": logits[6], "pred_boxes": boxes[6]}}
+    loop, loop_idx = crit(out, targets, return_indices=True)
+    fast, fast_idx = crit(dict(out, stacked=(logits, boxes, suffixes)), targets, return_indices=True)
+    assert set(loop) == set(fast) and len(fast) == 21
+    for (a, b), (c_, d) in zip(loop_idx["indices"] + loop_idx["enc_outputs"][0], fast_idx["indices"] + fast_idx["enc_outputs"][0]):
+        assert torch.equal(a, c_) and torch.equal(b, d)
+    for la, fa in zip(loop_idx["aux_outputs"], fast_idx["aux_outputs"]):
+        for (a, b), (c_, d) in zip(la, fa):
+            assert torch.equal(a, c_) and torch.equal(b, d)
+    for k in loop:
+        close(fast[k], loop[k], 1e-6, k)
+    w = crit.weight_dict
+    gl = torch.autograd.grad(sum(loop[k] * w[k] for k in loop), [logits, boxes])
+    gf = torch.autograd.grad(sum(fast[k] * w[k] for k in fast), [logits, boxes])
+    close(gf[0], gl[0], 1e-6, "grad logits")
+    close(gf[1], gl[1], 1e-6, "grad boxes")

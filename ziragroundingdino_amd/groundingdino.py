@@ -354,14 +354,35 @@ class GroundingDINO(nn.Module):
             hs, reference, hs_enc, ref_enc, init_box_proposal, _ = self.transformer(
                 srcs, masks, None, poss, None, None, text_dict)
 
-        outputs_coord_list = []
-        for layer_ref_sig, layer_bbox_embed, layer_hs in zip(reference[:-1], self.bbox_embed, hs):
-            unsig = layer_bbox_embed(layer_hs) + inverse_sigmoid(layer_ref_sig)
-            outputs_coord_list.append(unsig.sigmoid())
-        outputs_coord_list = torch.stack(outputs_coord_list)
-        outputs_class = torch.stack([
-            recover_to_cls_logits(layer_cls_embed(layer_hs, text_dict), cate_to_token_mask_list, for_fill=-100.0)
-            for layer_cls_embed, layer_hs in zip(self.class_embed, hs)])
+        # Heads (reference groundingdino_dual_zero_rep_branch.py:559-583).  The box MLP is shared by
+        # the decoder layers and the classifier is parameter-free, so all layers -- and in training
+        # the encoder proposals -- go through them as ONE stacked tensor instead of layer by layer.
+        n_dec = len(hs)
+        shared_heads = (all(m is self.bbox_embed[0] for m in self.bbox_embed)
+                        and all(m is self.class_embed[0] for m in self.class_embed))
+        enc_cls = getattr(self.transformer, "enc_out_class_embed", None)
+        with_enc = (self.training and hs_enc is not None and shared_heads
+                    and isinstance(enc_cls, ContrastiveEmbed)          # parameter-free: a deep copy
+                    and isinstance(self.class_embed[0], ContrastiveEmbed)  # computes the same thing
+                    and enc_cls.max_text_len == self.class_embed[0].max_text_len
+                    and hs_enc[-1].shape == hs[0].shape)
+        if shared_heads:
+            hs_all = torch.stack(list(hs))                                   # [L, B, Q, d]
+            ref_all = torch.stack(list(reference[:-1]))
+            outputs_coord_list = (self.bbox_embed[0](hs_all) + inverse_sigmoid(ref_all)).sigmoid()
+            cls_in = torch.cat([hs_all, hs_enc[-1][None]]) if with_enc else hs_all
+            cls_all = recover_to_cls_logits(self.class_embed[0](cls_in, text_dict),
+                                            cate_to_token_mask_list, for_fill=-100.0)
+            outputs_class = cls_all[:n_dec]
+        else:
+            outputs_coord_list = []
+            for layer_ref_sig, layer_bbox_embed, layer_hs in zip(reference[:-1], self.bbox_embed, hs):
+                unsig = layer_bbox_embed(layer_hs) + inverse_sigmoid(layer_ref_sig)
+                outputs_coord_list.append(unsig.sigmoid())
+            outputs_coord_list = torch.stack(outputs_coord_list)
+            outputs_class = torch.stack([
+                recover_to_cls_logits(layer_cls_embed(layer_hs, text_dict), cate_to_token_mask_list, for_fill=-100.0)
+                for layer_cls_embed, layer_hs in zip(self.class_embed, hs)])
         out = {"pred_logits": outputs_class[-1], "pred_boxes": outputs_coord_list[-1],
                "cate_to_token_mask_list": cate_to_token_mask_list}
 
@@ -370,9 +391,15 @@ class GroundingDINO(nn.Module):
                 out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b}
                                       for a, b in zip(outputs_class[:-1], outputs_coord_list[:-1])]
             if hs_enc is not None:
-                interm_class = self.transformer.enc_out_class_embed(hs_enc[-1], text_dict)
-                interm_class = recover_to_cls_logits(interm_class, cate_to_token_mask_list, for_fill=-100.0)
+                if with_enc:
+                    interm_class = cls_all[n_dec]
+                else:
+                    interm_class = self.transformer.enc_out_class_embed(hs_enc[-1], text_dict)
+                    interm_class = recover_to_cls_logits(interm_class, cate_to_token_mask_list, for_fill=-100.0)
                 out["enc_outputs"] = {"pred_logits": interm_class, "pred_boxes": ref_enc[-1]}
+            if with_enc and self.aux_loss:     # the criterion takes all 7 sets as stacked tensors
+                out["stacked"] = (cls_all, torch.cat([outputs_coord_list, ref_enc[-1][None]]),
+                                  ["_%d" % i for i in range(n_dec - 1)] + ["", "_enc"])
             assert targets is not None and self.criterion is not None
             loss_dict = self.criterion(out, targets)
             weight_dict = self.criterion.weight_dict

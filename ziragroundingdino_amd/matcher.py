@@ -27,8 +27,9 @@ class HungarianMatcher(nn.Module):
         self.gamma = gamma
 
     @torch.no_grad()
-    def cost_matrix(self, outputs, targets):
-        """[bs, num_queries, total_targets] matching cost (device tensor)."""
+    def cost_matrix(self, outputs, targets, check=True):
+        """[bs, num_queries, total_targets] matching cost (device tensor).  ``check=False`` returns
+        (cost, ok) with the xyxy-order check as a device scalar instead of asserting it."""
         bs, num_queries = outputs["pred_logits"].shape[:2]
         logits = outputs["pred_logits"].flatten(0, 1)
         out_bbox = outputs["pred_boxes"].flatten(0, 1)
@@ -42,9 +43,35 @@ class HungarianMatcher(nn.Module):
             pos = self.alpha * ((1 - p) ** self.gamma) * (-(p + 1e-8).log())
             cost_class = pos[:, tgt_ids] - neg[:, tgt_ids]
         cost_bbox = torch.cdist(out_bbox, tgt_bbox, p=1)
-        cost_giou = -generalized_box_iou(box_cxcywh_to_xyxy(out_bbox), box_cxcywh_to_xyxy(tgt_bbox))
+        b1, b2 = box_cxcywh_to_xyxy(out_bbox), box_cxcywh_to_xyxy(tgt_bbox)
+        if check:
+            cost_giou = -generalized_box_iou(b1, b2)
+        else:
+            ok = (b1[:, 2:] >= b1[:, :2]).all() & (b2[:, 2:] >= b2[:, :2]).all()
+            cost_giou = -generalized_box_iou(b1, b2, check=False)
         C = self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
-        return C.view(bs, num_queries, -1)
+        C = C.view(bs, num_queries, -1)
+        return C if check else (C, ok)
+
+    @torch.no_grad()
+    def forward_stacked(self, logits, boxes, targets):
+        """``forward`` for S prediction sets given as stacked tensors ``logits [S, B, Q, C]`` /
+        ``boxes [S, B, Q, 4]``: one cost computation over all S*B*Q predictions, one device->host
+        copy, S*B assignments.  The xyxy-order assertion of ``generalized_box_iou`` travels with
+        that copy instead of being its own host sync."""
+        S, B, Q = logits.shape[:3]
+        flat = {"pred_logits": logits.reshape(1, S * B * Q, -1), "pred_boxes": boxes.reshape(1, S * B * Q, 4)}
+        C, ok = self.cost_matrix(flat, targets, check=False)
+        host = torch.cat([C.reshape(-1), ok.to(C.dtype).reshape(1)]).cpu()
+        assert bool(host[-1]), "boxes not in xyxy order"
+        C = host[:-1].view(S, B, Q, -1)
+        sizes = [len(v["boxes"]) for v in targets]
+        results = []
+        for s in range(S):
+            indices = [linear_sum_assignment(c[i]) for i, c in enumerate(C[s].split(sizes, -1))]
+            results.append([(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64))
+                            for i, j in indices])
+        return results
 
     @torch.no_grad()
     def forward(self, outputs, targets):

@@ -150,15 +150,15 @@ def recover_to_cls_logits(logits: Tensor, cate_to_token_mask_list: List[Tensor],
                           for_fill=float("-inf")) -> Tensor:
     """token logits -> category logits: new[b, q, c] = max over the tokens of category c,
     ``for_fill`` elsewhere; same shape as ``logits`` (reference utils.py:312-320)."""
-    assert logits.shape[0] == len(cate_to_token_mask_list)
+    assert logits.shape[-3] == len(cate_to_token_mask_list)    # [..., B, Q, T]: leading dims = stacked sets
     new_logits = torch.full(logits.shape, for_fill, device=logits.device, dtype=logits.dtype)
     for bid, mask in enumerate(cate_to_token_mask_list):          # mask: [n_cat, n_token] bool
         n_cat, n_tok = mask.shape
         if n_cat == 0:
             continue
-        tok = logits[bid, :, :n_tok]                                # [Q, n_tok]
-        per_cat = tok[:, None, :].masked_fill(~mask[None], float("-inf")).max(dim=-1)[0]
-        new_logits[bid, :, :n_cat] = per_cat
+        tok = logits[..., bid, :, :n_tok]                           # [..., Q, n_tok]
+        per_cat = tok[..., None, :].masked_fill(~mask, float("-inf")).max(dim=-1)[0]
+        new_logits[..., bid, :, :n_cat] = per_cat
     return new_logits
 
 
