@@ -33,7 +33,7 @@
 #define ZIRA_K1_GATHERS 8
 #endif
 #ifndef ZIRA_ABLATE
-#define ZIRA_ABLATE 0  // developer-only ablation switches; 0 in every shipped build
+#define ZIRA_ABLATE 0  // 9 = developer build with per-phase time stamps in K2 (scripts/k2_stamps.py); 0 in shipped builds
 #endif
 
 namespace {
@@ -417,11 +417,7 @@ __global__ __launch_bounds__(kBlock, 8) void msda_fwd_lean(
             const int a = bp + (int)(j * SLOTS * 4);
             const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(a, offb_i);
             const float wj = __int_as_float(__builtin_amdgcn_ds_bpermute(a, w_i));
-#if ZIRA_ABLATE == 1
-            const float4 v = make_float4((float)oj, 1.f, 2.f, 3.f);
-#else
             const float4 v = load_row16(vb, oj + lane_off);
-#endif
             acc.x = fmaf(wj, v.x, acc.x);
             acc.y = fmaf(wj, v.y, acc.y);
             acc.z = fmaf(wj, v.z, acc.z);
@@ -689,13 +685,8 @@ __global__ __launch_bounds__(kK1Waves * 64, kK1Waves == 16 ? 8 : 6) void msda_bw
             const unsigned s = ch * 16 + (lane >> 2);
             const Entry k = entry_setup<true>(shapes, start, loc_i, att_i, s, lane & 3, LP, invP,
                                               M, D, m);
-#if ZIRA_ABLATE == 23
-            const float d = 0.f;
-            if (k.w == 123.f) store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
-#else
             const float d = chunk_dots<CQ>(vb, k, g4, lane);
             store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
-#endif
 
             unsigned tr = kInvalidEntry, key = 0;
             if (k.inb && k.w != 0.f) {
@@ -742,9 +733,7 @@ __global__ __launch_bounds__(kK1Waves * 64, kK1Waves == 16 ? 8 : 6) void msda_bw
         const unsigned excl = total + wbase + incl - n_mine;
         if (ti < plan.NT) {
             hist[ti] = excl;
-#if ZIRA_ABLATE != 21
             desc[((size_t)g * plan.NT + ti) * plan.nblk + blk] = (excl << 16) | n_mine;
-#endif
         }
         total += ctot;
         __syncthreads();
@@ -761,9 +750,6 @@ __global__ __launch_bounds__(kK1Waves * 64, kK1Waves == 16 ? 8 : 6) void msda_bw
     __syncthreads();
     uint2 *out = region + (size_t)vblk * plan.eblk;
     const uint2 *src = reinterpret_cast<const uint2 *>(sorted);
-#if ZIRA_ABLATE == 22
-    if (total == 0x7fffffffu)
-#endif
     for (unsigned i = threadIdx.x; i < total; i += kK1Threads) out[i] = src[i];
 }
 
@@ -844,12 +830,6 @@ enum : int { kRowStore = 0, kRowRmw = 1, kRowAtomic = 2 };
 
 __device__ __forceinline__ void flush_row(float *p, float4 acc, int mode)
 {
-#if ZIRA_ABLATE == 32  // developer build (wrong results): what do the row stores cost?
-    if (acc.x != 123.456f) return;
-#endif
-#if ZIRA_ABLATE == 31  // developer build (wrong results): what do the atomics cost?
-    if (mode == kRowAtomic) mode = kRowStore;
-#endif
     if (mode == kRowAtomic) {
         unsafeAtomicAdd(p + 0, acc.x);
         unsafeAtomicAdd(p + 1, acc.y);
@@ -1815,9 +1795,6 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
                            nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-#if ZIRA_ABLATE >= 21 && ZIRA_ABLATE <= 29
-    return 0;  // developer build: K1 alone
-#endif
 
     if (p.wave_k2) {
         const unsigned nvw = heads * p.NT, perw = (nvw + 7) >> 3;
