@@ -63,6 +63,14 @@ def main():
     cfgs.append(("decoder_clustered", (v, sh, st, cl, attn, go), 900, 200))
     ve, _, _, _, attne, goe = make_msda_inputs(B, S, M, D, shapes, P, 2, dev)
     cfgs.append(("encoder", (ve, sh, st, encoder_loc(B, M, shapes, P, 3, dev), attne, goe), S, 20))
+    if not os.environ.get("CASES"):  # measured streaming ceiling beside the 8 TB/s spec figure
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()   # 1 GiB
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        t = min(timeit(lambda: dst.copy_(src), 10) for _ in range(3))
+        print("device-to-device copy of 1 GiB: %.1f us -> %.0f GB/s read+write" % (t, 2 * src.numel() * 4 / t / 1e3), flush=True)
+        del src, dst
     if os.environ.get("ZIRA_INPUTS"):  # MSDA inputs captured from a model step (scripts/inmodel_msda.py)
         for key, t in torch.load(os.environ["ZIRA_INPUTS"]).items():
             t = [x.to(dev) for x in t]

@@ -87,3 +87,32 @@ def test_eval_mode_returns_instances():
     inst = res[0]["instances"]
     assert inst.pred_boxes.tensor.shape == (20, 4) and inst.scores.shape == (20,)
     assert inst.pred_classes.dtype == torch.int64 and torch.isfinite(inst.pred_boxes.tensor).all()
+
+
+def test_bf16_autocast_step_tracks_fp32():
+    """BASELINE configs[3] runs the GEMMs in bf16 (autocast) around the fp32 native ops: the MSDA
+    module and the RSB epilogue upcast their inputs, the decoder FFN stays in fp32 (reference
+    transformer_for_adapter.py:1004), the criterion is fp32.  The loss dict must be finite, have
+    the same keys and stay near the fp32 step (the side-branch losses, which sit in front of the
+    top-k query selection, within bf16 rounding; the set losses within a factor of two -- with
+    random-init logits near zero the selected queries change under bf16); gradients reach all 25
+    side-branch tensors."""
+    model = small_model().train()
+    model.before_train()                      # freeze everything but the side branches
+    model.use_frontend_graphs = False
+    data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+    ref = model(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(data)
+    assert set(out) == set(ref)
+    for k in ref:
+        assert torch.isfinite(out[k]), k
+        assert out[k].dtype == torch.float32, (k, out[k].dtype)
+        if "adapter" in k:
+            torch.testing.assert_close(out[k], ref[k], rtol=0.05, atol=1e-4, msg=k)
+        else:
+            assert 0.5 * float(ref[k]) - 0.05 <= float(out[k]) <= 2.0 * float(ref[k]) + 0.05, (k, float(out[k]), float(ref[k]))
+    sum(out.values()).backward()
+    grads = [(n, p.grad) for n, p in model.named_parameters() if p.requires_grad]
+    assert len(grads) == 25
+    assert all(g is not None and torch.isfinite(g).all() for _, g in grads)
