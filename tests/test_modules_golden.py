@@ -389,3 +389,31 @@ def test_stacked_criterion_equals_per_set_loop(dev):
     gf = torch.autograd.grad(sum(fast[k] * w[k] for k in fast), [logits, boxes])
     close(gf[0], gl[0], 1e-6, "grad logits")
     close(gf[1], gl[1], 1e-6, "grad boxes")
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_bi_attention_reassociated_equals_reference_order(dev):
+    """BiMultiHeadAttention re-brackets its three image-side projections around the (short) text
+    side; outputs and input gradients must equal the reference's order of operations
+    (``reassociate=False``, itself pinned by the BiAttentionBlock golden vectors) up to fp32
+    re-association -- with padding masks on both sides and more than one batch element."""
+    torch.manual_seed(5)
+    att = transformer.BiMultiHeadAttention(v_dim=64, l_dim=48, embed_dim=128, num_heads=4, dropout=0.0).to(dev)
+    for p in att.parameters():
+        p.data.normal_(0, 0.2)
+    v = torch.randn(2, 700, 64, device=dev, requires_grad=True)
+    l = torch.randn(2, 9, 48, device=dev, requires_grad=True)
+    mask_v = torch.zeros(2, 700, dtype=torch.bool, device=dev)
+    mask_v[1, 600:] = True
+    mask_l = torch.zeros(2, 9, dtype=torch.bool, device=dev)
+    mask_l[0, 7:] = True
+    gv, gl = torch.randn(2, 700, 64, device=dev), torch.randn(2, 9, 48, device=dev)
+    res = {}
+    for flag in (False, True):
+        att.reassociate = flag
+        ov, ol = att(v, l, attention_mask_v=mask_v, attention_mask_l=mask_l)
+        grads = torch.autograd.grad((ov * gv).sum() + (ol * gl).sum(), [v, l] + list(att.parameters()))
+        res[flag] = (ov, ol) + grads
+    names = ["out_v", "out_l", "grad_v", "grad_l"] + ["grad " + n for n, _ in att.named_parameters()]
+    for n, a, b in zip(names, res[True], res[False]):
+        close(a, b, 2e-5, n)
