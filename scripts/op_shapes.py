@@ -21,6 +21,11 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     trainer.run_step(data)
     torch.cuda.synchronize()
 rows = prof.key_averages(group_by_input_shape=True)
+flat = sorted(prof.key_averages(), key=lambda r: -r.self_device_time_total)
+tot_all = sum(r.self_device_time_total for r in flat)
+print("== top ops by device time (total %.1f ms)" % (tot_all / 1e3))
+for r in flat[:32]:
+    print("   %8.2f ms x%-5d %s" % (r.self_device_time_total / 1e3, r.count, r.key[:90]))
 want = sys.argv[1:] or ["aten::copy_", "aten::add", "aten::add_", "aten::native_layer_norm", "aten::clamp", "aten::mul", "aten::fill_", "aten::threshold_backward", "aten::masked_fill"]
 for name in want:
     sel = sorted([r for r in rows if r.key == name], key=lambda r: -r.self_device_time_total)
