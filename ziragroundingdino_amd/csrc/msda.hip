@@ -1254,12 +1254,14 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
 // chain (descriptors -> entries -> grad_out rows -> store).
 //
 // Queries cluster on objects, so some tiles hold 10-20x the mean number of entries (measured in
-// the model; uniform synthetic inputs do not show it).  A tile with more than kWaveTileCap
-// entries is cut into slices of kWaveTileCap entries: its owner handles slice 0 like any other
-// tile and publishes slices 1.. in a small queue in the workspace (one fetch-add per heavy tile).
-// A second launch of the same kernel (kHelpers = true, a fixed grid that strides over the queue;
-// it ends at once when the queue is empty) adds the remaining slices onto the stored rows with
-// fp32 atomics -- the only place the tiled path uses them: <= N / kWaveTileCap addends per row.
+// the model; uniform synthetic inputs do not show it: ~190 +- 14 entries per tile).  A tile with
+// more than kHeavyTile entries is cut into slices of kSliceEntries: its owner handles slice 0
+// like any other tile and publishes slices 1.. in a small queue in the workspace (one fetch-add
+// per heavy tile).  A second launch of the same kernel (kHelpers = true, a fixed grid that strides
+// over the queue; it ends at once when the queue is empty) adds the remaining slices onto the
+// stored rows with fp32 atomics -- the only place the tiled path uses them.  Shorter slices or a
+// lower threshold were measured and lose (every slice pays the descriptor prefix again and adds
+// its own atomics: 128-entry slices 86 us, threshold 256 94 us, 512 / 512 83 us in the model).
 // The kernel boundary is what makes the owners' plain stores visible to the atomics: the eight
 // XCDs have private L2s and fp32 atomics execute at the memory side.  (A first version let
 // finishing owner waves pop slices inside the same launch: 5000 waves contending for one queue
@@ -1274,13 +1276,22 @@ constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #ifndef ZIRA_K2W_MINWAVES
 #define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
 #endif
-constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;  // entries per slice
+#ifndef ZIRA_K2W_HEAVY
+#define ZIRA_K2W_HEAVY 512
+#endif
+#ifndef ZIRA_K2W_SLICE
+#define ZIRA_K2W_SLICE 512
+#endif
+constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;    // LDS sort capacity of a wave (entries)
+constexpr unsigned kHeavyTile = ZIRA_K2W_HEAVY;    // tiles above this many entries are sliced
+constexpr unsigned kSliceEntries = ZIRA_K2W_SLICE; // entries per slice of a heavy tile
+static_assert(kHeavyTile <= kWaveTileCap && kSliceEntries <= kWaveTileCap, "a slice / light tile must fit the LDS sort");
 constexpr unsigned kWaveK2Waves = 4;
 // LDS words of a wave's sorted entries; the partial records of rowsum_slices alias them
 constexpr unsigned kWaveSortWords = 2 * kWaveTileCap > kRowsumPartWords ? 2 * kWaveTileCap : kRowsumPartWords;
 constexpr unsigned kWaveHelperBlocks = 512;  // helper launch: 2048 waves stride over the queue (an empty launch costs ~2 us whatever the grid)
 constexpr unsigned kQueueHeader = 4;       // words: [0] tail, [1] head, [2..3] unused
-constexpr unsigned kQueueSliceBits = 12;   // item = ((virtual tile << 12) | slice) + 1
+constexpr unsigned kQueueSliceBits = 13;   // item = ((virtual tile << 13) | slice) + 1
 
 __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, unsigned lane)
 {
@@ -1365,16 +1376,18 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             if (lane == 0) pre[plan.nblk] = N;
             K2W_STAMP(1);
 
-            if (!kHelpers && N > kWaveTileCap && lane == 0) {  // publish slices 1 .. extra
-                const unsigned extra = (N - 1) / kWaveTileCap;
+            const bool heavy = N > kHeavyTile;  // wave-uniform
+            if (!kHelpers && heavy && lane == 0) {  // publish slices 1 .. extra
+                const unsigned extra = (N - 1) / kSliceEntries;
                 const unsigned at = __hip_atomic_fetch_add(&queue[0], extra, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT);
                 for (unsigned k = 1; k <= extra; ++k)
                     queue[kQueueHeader + at + k - 1] = ((vb2 << kQueueSliceBits) | k) + 1;
             }
             const int mode = kHelpers ? kRowAtomic : kRowStore;
-            const unsigned e_lo = slice * kWaveTileCap;
-            const unsigned nb = (N - e_lo < kWaveTileCap) ? N - e_lo : kWaveTileCap;
+            const unsigned span_e = heavy ? kSliceEntries : kWaveTileCap;
+            const unsigned e_lo = slice * span_e;
+            const unsigned nb = (N - e_lo < span_e) ? N - e_lo : span_e;
 
             for (unsigned i = lane; i < rows; i += 64) rowcnt[i] = 0;
             __builtin_amdgcn_wave_barrier();
@@ -1713,9 +1726,9 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
         p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
         p.rows = ((unsigned)S + p.T - 1) / p.T;
         const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + kWaveSortWords;
-        // a heavy tile publishes ceil(N / cap) - 1 slices: at most (all entries) / cap in total
+        // a heavy tile publishes ceil(N / kSliceEntries) - 1 slices: at most (all entries) / kSliceEntries in total
         const unsigned long long all_entries = (unsigned long long)heads * Q * L * P * 4;
-        p.qwords = kQueueHeader + (unsigned)(all_entries / kWaveTileCap) + 1;
+        p.qwords = kQueueHeader + (unsigned)(all_entries / kSliceEntries) + 1;
         if (p.NT <= 4096 && per_wave * 4 * kWaveK2Waves <= 64 * 1024 && Q < (1 << 20) &&
             (unsigned long long)heads * p.NT < (1ull << (32 - kQueueSliceBits)) &&
             ((size_t)p.NT + (size_t)p.eblk * 5) * 4 <= 150 * 1024)
