@@ -63,15 +63,19 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
                       float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                       void *stream);
 
-/* Atomic-free float32 backward (same results up to summation order).
- * `zira_msda_bwd_workspace_bytes` returns the scratch size the two-kernel "tiled" backward
- * needs for these dimensions, or 0 when that path does not apply (the plain entry point is
- * then the only one).  The workspace is caller-owned DEVICE memory, 16-byte aligned, needs no
- * initialisation and may be reused by later calls on the same stream; with workspace == NULL
- * or too small the call degrades to zira_msda_bwd_f32.  grad_value is written exactly once
- * and never zero-filled.  Extra precondition: the levels tile [0, S) exactly
- * (level_start_index[l] + H_l*W_l == level_start_index[l+1], last one == S), which the
- * reference module asserts (ms_deform_attn.py:284). */
+/* Sorted ("tiled") float32 backward: same results up to summation order, 2-6x faster than the
+ * plain entry point (no fp32 atomics on the common path).
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions
+ * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 223 MB at Q=S), or 0 when that path does
+ * not apply (the plain entry point is then the only one).  The workspace is caller-owned
+ * DEVICE memory, 16-byte aligned, needs no initialisation and may be reused by later calls
+ * on the same stream; with workspace == NULL or too small the call degrades to
+ * zira_msda_bwd_f32.  Two or three kernels are enqueued on `stream` (sort by tile, reduce
+ * tiles, and for sparse calls a short launch that adds the slices of overfull tiles with
+ * fp32 atomics); every element of grad_value is written by them, it is never pre-zeroed.
+ * Extra precondition: the levels tile [0, S) exactly (level_start_index[l] + H_l*W_l ==
+ * level_start_index[l+1], last one == S), which the reference module asserts
+ * (ms_deform_attn.py:284). */
 size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P);
 
 int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_t *spatial_shapes,
@@ -117,8 +121,8 @@ int zira_rsb_bwd_f32(const float *y_branch, const float *y_twin, const float *sc
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 
-/* Name of the kernel variant the f32 entry points pick for channel width D
- * ("rows<8>" = wave-per-(b,q,m) fast path, "generic" = element-per-thread path).
+/* Names of the kernels the f32 entry points pick for channel width D (the lean / tiled
+ * kernels for D = 16, 32, 64, "rows<N>" for 4, 8, 128, 256, "generic" otherwise).
  * Host-only helper for tests/bench labelling. Static storage. */
 const char *zira_msda_variant_f32(int D);
 
