@@ -118,6 +118,19 @@ int zira_rsb_bwd_f32(const float *y_branch, const float *y_twin, const float *sc
                      const float *grad_out, const float *grad_loss, size_t n, float *g_branch,
                      float *g_twin, float *g_scaling, float *workspace, void *stream);
 
+/* ---- tall-reduction product for the cross-modal fusion layers -------------------------------
+ * out[z] = X[z]^T * Y[z],  z < B;  X[z] is N x a (row-major; with x_transposed != 0 it is
+ * stored a x N), Y[z] is N x b, out[z] is a x b;  a, b multiples of 4.  N is the number of image
+ * tokens (tens of thousands), a and b are a few hundred at most: the three products of this
+ * shape in BiMultiHeadAttention (reference fuse_modules.py:188-222 after re-bracketing around the
+ * text side) -- a GEMM library runs them on one or two tiles.
+ * `workspace`: zira_xty_workspace_floats(B, N, a, b) floats of device scratch, no initialisation
+ * needed.  Deterministic (partial tiles folded in a fixed order). */
+size_t zira_xty_workspace_floats(int B, int N, int a, int b);
+
+int zira_xty_f32(const float *X, const float *Y, int B, int N, int a, int b, int x_transposed,
+                 float *out, float *workspace, void *stream);
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

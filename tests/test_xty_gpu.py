@@ -1,0 +1,50 @@
+"""Tall-reduction product kernel (csrc/xty.hip, C ABI zira_xty_f32) against torch.bmm in float64,
+and the two autograd wrappers BiMultiHeadAttention uses, against plain torch autograd."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ziragroundingdino_amd import dense  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,N,a,b,xt", [(2, 22223, 64, 256, False), (2, 22223, 64, 256, True),
+                                        (2, 22223, 256, 64, False), (1, 5000, 36, 256, True),
+                                        (3, 4097, 200, 132, False), (2, 2500, 4, 8, True),
+                                        (2, 3000, 320, 260, False)])
+def test_xty_matches_float64(B, N, a, b, xt):
+    g = torch.Generator().manual_seed(N + a + b)
+    X = torch.randn((B, a, N) if xt else (B, N, a), generator=g).to(DEV)
+    Y = torch.randn(B, N, b, generator=g).to(DEV)
+    assert dense._use_xty(X, Y, a, b, N)
+    got = dense.xty(X, Y, x_transposed=xt)
+    want = torch.bmm((X if xt else X.transpose(1, 2)).double(), Y.double())
+    assert got.shape == (B, a, b)
+    assert _rel(got, want) < 2e-6
+    assert torch.equal(got, dense.xty(X, Y, x_transposed=xt))            # fixed fold order: bit-stable
+
+
+def test_autograd_wrappers_match_torch():
+    g = torch.Generator().manual_seed(3)
+    B, N, a, d = 2, 9000, 48, 256
+    P = torch.randn(B, a, N, generator=g).to(DEV).requires_grad_(True)
+    V = torch.randn(B, N, d, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(B, a, d, generator=g).to(DEV)
+    got = torch.autograd.grad((dense.tall_reduce(P, V) * go).sum(), [P, V])
+    want = torch.autograd.grad((torch.bmm(P, V) * go).sum(), [P, V])
+    for x, y in zip(got, want):
+        assert _rel(x, y.double()) < 1e-5
+    L = torch.randn(B, N, a, generator=g).to(DEV).requires_grad_(True)
+    R = torch.randn(B, a, d, generator=g).to(DEV).requires_grad_(True)
+    bias = torch.randn(d, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(B, N, d, generator=g).to(DEV)
+    got = torch.autograd.grad((dense.wide_matmul(L, R, bias) * go).sum(), [L, R, bias])
+    want = torch.autograd.grad((torch.baddbmm(bias, L, R) * go).sum(), [L, R, bias])
+    for x, y in zip(got, want):
+        assert _rel(x, y.double()) < 1e-5

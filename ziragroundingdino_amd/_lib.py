@@ -14,6 +14,7 @@ SYMBOLS = (
     "zira_msda_fwd_f32", "zira_msda_bwd_f32", "zira_msda_fwd_f64", "zira_msda_bwd_f64",
     "zira_msda_bwd_workspace_bytes", "zira_msda_bwd_f32_ws",
     "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
+    "zira_xty_workspace_floats", "zira_xty_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -53,6 +54,10 @@ def load():
     lib.zira_rsb_fwd_f32.restype = i
     lib.zira_rsb_bwd_f32.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
     lib.zira_rsb_bwd_f32.restype = i
+    lib.zira_xty_workspace_floats.argtypes = [i, i, i, i]
+    lib.zira_xty_workspace_floats.restype = sz
+    lib.zira_xty_f32.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
+    lib.zira_xty_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

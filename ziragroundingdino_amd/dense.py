@@ -58,3 +58,98 @@ def conv_module_as_gemm(conv: torch.nn.Conv2d, x):
     if conv.dilation != (1, 1) or conv.groups != 1 or conv.padding_mode != "zeros" or isinstance(conv.padding, str):
         return conv(x)
     return conv2d_as_gemm(x, conv.weight, conv.bias, conv.stride, conv.padding)
+
+
+# ---------------------------------------------------------------------------------------------
+# Tall-reduction products (csrc/xty.hip): out[z] = X[z]^T @ Y[z] with a reduction over tens of
+# thousands of image tokens and a small output -- the shape BiMultiHeadAttention's re-bracketed
+# image side produces (transformer.py).  rocBLAS gives them one or two tiles (109 / 85 us at
+# N = 22223, 64 x 256); the split-reduction kernel takes ~15 us.
+# ---------------------------------------------------------------------------------------------
+_XTY_WS = {}
+
+
+def _use_xty(X, Y, a, b, N):
+    return (X.is_cuda and X.dtype == torch.float32 and Y.dtype == torch.float32 and N >= 2048
+            and a % 4 == 0 and b % 4 == 0 and a * b <= 512 * 512)
+
+
+def _xty_native(X, Y, x_transposed):
+    from . import _lib
+
+    lib = _lib.load()
+    X, Y = X.contiguous(), Y.contiguous()
+    B, N, b = Y.shape
+    a = X.shape[1] if x_transposed else X.shape[2]
+    out = torch.empty((B, a, b), dtype=torch.float32, device=X.device)
+    n = lib.zira_xty_workspace_floats(B, N, a, b)
+    key = (X.device, torch.cuda.current_stream(X.device).cuda_stream)
+    ws = _XTY_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _XTY_WS[key] = torch.empty(n, dtype=torch.float32, device=X.device)
+    rc = lib.zira_xty_f32(X.data_ptr(), Y.data_ptr(), B, N, a, b, int(bool(x_transposed)), out.data_ptr(),
+                          ws.data_ptr(), torch.cuda.current_stream(X.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError("zira_xty_f32 failed with HIP error %d" % rc)
+    return out
+
+
+def xty(X, Y, x_transposed=False):
+    """X^T @ Y per batch element, no autograd: X [B, N, a] (or [B, a, N] with ``x_transposed``),
+    Y [B, N, b] -> [B, a, b]."""
+    N, b = Y.shape[1], Y.shape[2]
+    a = X.shape[1] if x_transposed else X.shape[2]
+    if _use_xty(X, Y, a, b, N):
+        return _xty_native(X, Y, x_transposed)
+    return torch.bmm(X if x_transposed else X.transpose(1, 2), Y)
+
+
+class _TallReduce(torch.autograd.Function):
+    """P [B, a, N] @ V [B, N, b] -> [B, a, b]  (the forward itself is the tall reduction)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # fp32 also under autocast
+    def forward(ctx, P, V):
+        ctx.save_for_backward(P, V)
+        return xty(P, V, x_transposed=True)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        P, V = ctx.saved_tensors
+        g = g.to(P.dtype)
+        gP = torch.bmm(g, V.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gV = torch.bmm(P.transpose(1, 2), g) if ctx.needs_input_grad[1] else None
+        return gP, gV
+
+
+class _WideMatmul(torch.autograd.Function):
+    """(bias +) L [B, N, k] @ R [B, k, m] -> [B, N, m]: an ordinary GEMM forward whose gradient
+    w.r.t. the small right operand, L^T @ g, is the tall reduction."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, L, R, bias):
+        ctx.save_for_backward(L, R)
+        ctx.has_bias = bias is not None
+        return torch.bmm(L, R) if bias is None else torch.baddbmm(bias, L, R)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        L, R = ctx.saved_tensors
+        g = g.to(L.dtype).contiguous()
+        gL = torch.bmm(g, R.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gR = xty(L, g) if ctx.needs_input_grad[1] else None
+        gb = g.sum((0, 1)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gL, gR, gb
+
+
+def tall_reduce(P, V):
+    """P [B, a, N] @ V [B, N, b] with autograd."""
+    return _TallReduce.apply(P, V)
+
+
+def wide_matmul(L, R, bias=None):
+    """(bias +) L [B, N, k] @ R [B, k, m] with autograd; see ``_WideMatmul``."""
+    return _WideMatmul.apply(L, R, bias)

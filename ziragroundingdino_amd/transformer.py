@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from .dense import tall_reduce, wide_matmul
 from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
 from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
                     gen_sineembed_for_position, get_sine_pos_embed, inverse_sigmoid)
@@ -141,7 +142,7 @@ class BiMultiHeadAttention(nn.Module):
             wq = self.v_proj.weight.view(H, hd, -1)
             a = torch.einsum("hed,bthe->bdht", wq, k4) * self.scale             # [B, v_dim, H, T]
             c = torch.einsum("he,bthe->bht", self.v_proj.bias.view(H, hd), k4) * self.scale
-            attn = torch.bmm(v, a.reshape(bsz, -1, H * src_len)).view(bsz, tgt_len, H, src_len) + c[:, None]
+            attn = wide_matmul(v, a.reshape(bsz, -1, H * src_len)).view(bsz, tgt_len, H, src_len) + c[:, None]
             attn = attn.permute(0, 2, 1, 3).reshape(bsz * H, tgt_len, src_len)  # [bs*heads, n_img, n_text]
         else:
             q = self._heads(self.v_proj(v) * self.scale, bsz)
@@ -178,7 +179,7 @@ class BiMultiHeadAttention(nn.Module):
         probs_l = F.dropout(attn_l, p=self.dropout, training=self.training)
         if self.reassociate:
             wv = self.values_v_proj.weight.view(H, hd, -1)
-            u = torch.bmm(probs_l.reshape(bsz, H * src_len, tgt_len), v).view(bsz, H, src_len, -1)
+            u = tall_reduce(probs_l.reshape(bsz, H * src_len, tgt_len), v).view(bsz, H, src_len, -1)
             out_l = torch.einsum("bhtd,hed->bthe", u, wv)
             out_l = out_l + (probs_l.sum(-1).view(bsz, H, src_len).transpose(1, 2)[..., None]
                              * self.values_v_proj.bias.view(H, hd))
@@ -186,7 +187,7 @@ class BiMultiHeadAttention(nn.Module):
             wo = self.out_v_proj.weight.view(-1, H, hd)
             z = torch.einsum("bthe,dhe->bhtd", value_l4, wo).reshape(bsz, H * src_len, -1)
             pv = probs_v.view(bsz, H, tgt_len, src_len).permute(0, 2, 1, 3).reshape(bsz, tgt_len, H * src_len)
-            out_v = torch.baddbmm(self.out_v_proj.bias, pv, z)
+            out_v = wide_matmul(pv, z, self.out_v_proj.bias)
             return out_v, out_l
         out_v = torch.bmm(probs_v, value_l)
         out_l = torch.bmm(probs_l, value_v)
