@@ -8,9 +8,9 @@
 // forward, tokens^T x (score gradients) and (probabilities)^T x (output gradients) in the
 // backward.  A 64 x 256 output with a 22 k-long reduction is 0.7 GFLOP over 28 MB; a GEMM library
 // launches one or two tiles for it (109 / 85 us measured with rocBLAS).  Here the reduction is
-// split over `chunks` workgroups per output tile (a 64 x 256 or 256 x 64 tile, 8 x 8 outputs per
-// thread, operands staged through LDS 32 rows at a time, the next rows in flight meanwhile), partial tiles go to a workspace and a
-// second kernel folds them in a fixed order (deterministic, no atomics).
+// split over `chunks` workgroups per output tile (a 64 x 256 or 256 x 64 tile on fp32 MFMA,
+// operands straight from global memory), partial tiles go to a workspace and a second kernel
+// folds them in a fixed order (deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
@@ -19,120 +19,168 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kKT = 32;        // reduction rows staged per step
 constexpr int kMaxChunks = 128;
 
-template <int TA, int TB>
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float4 __attribute__((aligned(4))) float4_u;  // 4-byte aligned 16-byte load (rows of odd length)
+
+// One workgroup = 4 waves = one TA x TB tile of the output (64 x 256 or 256 x 64) over one chunk of
+// the reduction; a wave owns a 64 x 64 sub-tile as 2 x 2 MFMA blocks (v_mfma_f32_32x32x2_f32: two
+// reduction rows per instruction).  The operands of that instruction are exactly one float per
+// lane -- lane l holds X[n + l/32][i0 + l%32] and Y[n + l/32][j0 + l%32] -- so they are loaded
+// straight from global memory (two coalesced 128-byte rows per load), no LDS staging.
+// kUnroll row pairs are fetched before the first of their MFMAs is issued.
+template <int TA, int TB, bool XT>
 __global__ __launch_bounds__(kThreads) void xty_partial(const float *__restrict__ X,
                                                         const float *__restrict__ Y, int N, int a,
-                                                        int b, int x_transposed, int chunk_rows,
-                                                        int b_tiles, float *__restrict__ part)
+                                                        int b, int chunk_rows, int b_tiles,
+                                                        float *__restrict__ part)
 {
-    static_assert(TA * TB == kThreads * 64, "8 x 8 outputs per thread");
-    constexpr int XV = kKT * TA / 4 / kThreads;  // float4 (or 4 scalars) of X per thread and step
-    constexpr int YV = kKT * TB / 4 / kThreads;
-    __shared__ float xs[kKT][TA];
-    __shared__ float ys[kKT][TB];
+    static_assert(TA * TB == 64 * 256, "four 64 x 64 wave tiles");
+    constexpr int kUnroll = 8;  // MFMA steps (row pairs) per batch of operand loads
     const int chunk = blockIdx.x, chunks = gridDim.x, z = blockIdx.z;
-    const int a0 = (blockIdx.y / b_tiles) * TA, b0 = (blockIdx.y % b_tiles) * TB;
-    const int tid = threadIdx.x;
-    // thread (ti, tj) owns rows {4ti..4ti+3, TA/2+4ti..} x columns {4tj..4tj+3, TB/2+4tj..}:
-    // consecutive threads read consecutive float4 from LDS
-    const int tj = tid % (TB / 8), ti = tid / (TB / 8);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a0 = (blockIdx.y / b_tiles) * TA + (TA == 256 ? 64 * wave : 0);
+    const int b0 = (blockIdx.y % b_tiles) * TB + (TB == 256 ? 64 * wave : 0);
+    const int k = lane >> 5, c = lane & 31;
     const float *Xz = X + (size_t)z * N * a;
     const float *Yz = Y + (size_t)z * N * b;
     const int n_begin = chunk * chunk_rows;
     const int n_end = (n_begin + chunk_rows < N) ? n_begin + chunk_rows : N;
+    const bool ia[2] = {a0 + c < a, a0 + 32 + c < a};
+    const bool jb[2] = {b0 + c < b, b0 + 32 + c < b};
 
-    float acc[8][8];
+    v16f acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // global -> registers for the step starting at row n0 (zeros outside the chunk / the matrix)
-    float4 xr[XV], yr[YV];
-    auto fetch = [&](int n0) {
+    // A batch = kUnroll MFMA steps' worth of operands in registers; two batches alternate so that
+    // one is in flight while the other one is multiplied (the kernel is otherwise bound by the
+    // latency of its own loads: one workgroup per CU).
+    struct Batch {
+        float xa[XT ? 1 : kUnroll][2];
+        float4 xq[XT ? kUnroll / 2 : 1][2];
+        float yb[kUnroll][2];
+    };
+    constexpr int kRows = 2 * kUnroll;  // reduction rows per batch
+    // Loads are unconditional (indices clamped into the matrix) and values outside the chunk / the
+    // matrix are cleared with a bit mask: written with predicates the compiler emitted a branch and
+    // a full wait per load, and the MFMA pipe idled.
+    const int ca[2] = {ia[0] ? a0 + c : a - 1, ia[1] ? a0 + 32 + c : a - 1};
+    const int cb[2] = {jb[0] ? b0 + c : b - 1, jb[1] ? b0 + 32 + c : b - 1};
+    const unsigned ma[2] = {ia[0] ? 0xFFFFFFFFu : 0u, ia[1] ? 0xFFFFFFFFu : 0u};
+    const unsigned mb[2] = {jb[0] ? 0xFFFFFFFFu : 0u, jb[1] ? 0xFFFFFFFFu : 0u};
+    auto keep = [](float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); };
+    const bool cols_full = a0 + 64 <= a && b0 + 64 <= b;  // wave-uniform
+    auto fetch = [&](Batch &t, int n0) {
+        if (cols_full && n0 + kRows <= n_end) {  // interior batch: no clamps, no masks
+            const float *yp = Yz + (size_t)(n0 + k) * b + b0 + c;
 #pragma unroll
-        for (int u = 0; u < XV; ++u) {
-            const int e = tid + u * kThreads;
-            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x_transposed) {  // X is a x N: this thread takes 4 consecutive n of one column i
-                const int i = e / (kKT / 4), k = (e % (kKT / 4)) * 4, n = n0 + k;
-                if (a0 + i < a) {
-                    const float *src = Xz + (size_t)(a0 + i) * N + n;
-                    if (n < n_end) xr[u].x = src[0];
-                    if (n + 1 < n_end) xr[u].y = src[1];
-                    if (n + 2 < n_end) xr[u].z = src[2];
-                    if (n + 3 < n_end) xr[u].w = src[3];
+            for (int u = 0; u < kUnroll; ++u) {
+                t.yb[u][0] = yp[(size_t)2 * u * b];
+                t.yb[u][1] = yp[(size_t)2 * u * b + 32];
+            }
+            if (!XT) {
+                const float *xp = Xz + (size_t)(n0 + k) * a + a0 + c;
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    t.xa[u][0] = xp[(size_t)2 * u * a];
+                    t.xa[u][1] = xp[(size_t)2 * u * a + 32];
                 }
             } else {
-                const int k = e / (TA / 4), i = (e % (TA / 4)) * 4, n = n0 + k;
-                if (n < n_end && a0 + i < a) xr[u] = *reinterpret_cast<const float4 *>(Xz + (size_t)n * a + a0 + i);
+                const float *xp = Xz + (size_t)(a0 + c) * N + n0;
+#pragma unroll
+                for (int q = 0; q < kUnroll / 2; ++q) {
+                    t.xq[q][0] = *reinterpret_cast<const float4_u *>(xp + 4 * q);
+                    t.xq[q][1] = *reinterpret_cast<const float4_u *>(xp + (size_t)32 * N + 4 * q);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int n = n0 + 2 * u + k;
+            const unsigned mrow = n < n_end ? 0xFFFFFFFFu : 0u;
+            const int nc = n < N ? n : N - 1;
+            const float *yr = Yz + (size_t)nc * b;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) t.yb[u][h] = keep(yr[cb[h]], mrow & mb[h]);
+            if (!XT) {
+                const float *xr = Xz + (size_t)nc * a;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) t.xa[u][h] = keep(xr[ca[h]], mrow & ma[h]);
             }
         }
+        if (XT) {  // X stored a x N: a lane reads 4 consecutive n of its column = two MFMA steps
 #pragma unroll
-        for (int u = 0; u < YV; ++u) {
-            const int e = tid + u * kThreads;
-            const int k = e / (TB / 4), j = (e % (TB / 4)) * 4, n = n0 + k;
-            yr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < n_end && b0 + j < b) yr[u] = *reinterpret_cast<const float4 *>(Yz + (size_t)n * b + b0 + j);
-        }
-    };
-    auto stage = [&]() {  // registers -> LDS
+            for (int q = 0; q < kUnroll / 2; ++q) {
+                const int n = n0 + 4 * q;
 #pragma unroll
-        for (int u = 0; u < XV; ++u) {
-            const int e = tid + u * kThreads;
-            if (x_transposed) {
-                const int i = e / (kKT / 4), k = (e % (kKT / 4)) * 4;
-                xs[k][i] = xr[u].x; xs[k + 1][i] = xr[u].y; xs[k + 2][i] = xr[u].z; xs[k + 3][i] = xr[u].w;
-            } else {
-                const int k = e / (TA / 4), i = (e % (TA / 4)) * 4;
-                *reinterpret_cast<float4 *>(&xs[k][i]) = xr[u];
+                for (int h = 0; h < 2; ++h) {
+                    // one 16-byte read (rows of X have odd length: 4-byte alignment only); the last
+                    // rows of the matrix are read element by element
+                    const float *src = Xz + (size_t)ca[h] * N + n;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n + 3 < N) {
+                        v = *reinterpret_cast<const float4_u *>(src);
+                    } else {
+                        if (n < N) v.x = src[0];
+                        if (n + 1 < N) v.y = src[1];
+                        if (n + 2 < N) v.z = src[2];
+                    }
+                    v.x = keep(v.x, (n < n_end ? 0xFFFFFFFFu : 0u) & ma[h]);
+                    v.y = keep(v.y, (n + 1 < n_end ? 0xFFFFFFFFu : 0u) & ma[h]);
+                    v.z = keep(v.z, (n + 2 < n_end ? 0xFFFFFFFFu : 0u) & ma[h]);
+                    v.w = keep(v.w, (n + 3 < n_end ? 0xFFFFFFFFu : 0u) & ma[h]);
+                    t.xq[q][h] = v;
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < YV; ++u) {
-            const int e = tid + u * kThreads;
-            const int k = e / (TB / 4), j = (e % (TB / 4)) * 4;
-            *reinterpret_cast<float4 *>(&ys[k][j]) = yr[u];
-        }
     };
-
-    fetch(n_begin);
-    for (int n0 = n_begin; n0 < n_end; n0 += kKT) {
-        stage();
-        __syncthreads();
-        if (n0 + kKT < n_end) fetch(n0 + kKT);  // next step's rows travel while this one is multiplied
-#pragma unroll 8
-        for (int k = 0; k < kKT; ++k) {
-            const float4 xa = *reinterpret_cast<const float4 *>(&xs[k][4 * ti]);
-            const float4 xb = *reinterpret_cast<const float4 *>(&xs[k][TA / 2 + 4 * ti]);
-            const float4 ya = *reinterpret_cast<const float4 *>(&ys[k][4 * tj]);
-            const float4 yb = *reinterpret_cast<const float4 *>(&ys[k][TB / 2 + 4 * tj]);
-            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            const float yv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+    auto multiply = [&](const Batch &t) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(xv[i], yv[j], acc[i][j]);
-        }
-        __syncthreads();
+            for (int i = 0; i < 2; ++i) {
+                float xv;
+                if (XT) {
+                    const float4 q4 = t.xq[u / 2][i];
+                    xv = (u & 1) ? (k ? q4.w : q4.z) : (k ? q4.y : q4.x);
+                } else {
+                    xv = t.xa[u][i];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, t.yb[u][j], acc[i][j], 0, 0, 0);
+            }
+    };
+    Batch ping, pong;
+    fetch(ping, n_begin);
+    for (int n0 = n_begin; n0 < n_end; n0 += 2 * kRows) {
+        fetch(pong, n0 + kRows);
+        multiply(ping);
+        fetch(ping, n0 + 2 * kRows);
+        multiply(pong);
     }
-    // partial tile -> workspace [z][chunk][a][b]
+    // partial tile -> workspace [z][chunk][a][b]; accumulator register r of lane l is the element
+    // (row 8*(r/4) + 4*(l/32) + r%4, column l%32) of its 32 x 32 block
     float *pz = part + ((size_t)z * chunks + chunk) * a * b;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = a0 + (i < 4 ? 4 * ti + i : TA / 2 + 4 * ti + i - 4);
-        if (row >= a) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = b0 + (h ? TB / 2 : 0) + 4 * tj;
-            if (col < b)
-                *reinterpret_cast<float4 *>(pz + (size_t)row * b + col) =
-                    make_float4(acc[i][4 * h], acc[i][4 * h + 1], acc[i][4 * h + 2], acc[i][4 * h + 3]);
+        for (int j = 0; j < 2; ++j) {
+            const int col = b0 + 32 * j + c;
+            if (col >= b) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = a0 + 32 * i + 8 * (r / 4) + 4 * k + (r % 4);
+                if (row < a) pz[(size_t)row * b + col] = acc[i][j][r];
+            }
         }
-    }
 }
 
 // out = sum over chunks of the partial tiles.  A block folds 16 float4 of the output: 16 chunk
@@ -192,12 +240,22 @@ int zira_xty_f32(const float *X, const float *Y, int B, int N, int a, int b, int
     const int chunk_rows = (N + chunks - 1) / chunks;
     if (a <= b) {  // wide tile along b
         const int a_tiles = (a + 63) / 64, b_tiles = (b + 255) / 256;
-        hipLaunchKernelGGL((xty_partial<64, 256>), dim3(chunks, a_tiles * b_tiles, B), dim3(kThreads), 0,
-                           st, X, Y, N, a, b, x_transposed, chunk_rows, b_tiles, workspace);
+        const dim3 grid(chunks, a_tiles * b_tiles, B);
+        if (x_transposed)
+            hipLaunchKernelGGL((xty_partial<64, 256, true>), grid, dim3(kThreads), 0, st, X, Y, N, a, b,
+                               chunk_rows, b_tiles, workspace);
+        else
+            hipLaunchKernelGGL((xty_partial<64, 256, false>), grid, dim3(kThreads), 0, st, X, Y, N, a, b,
+                               chunk_rows, b_tiles, workspace);
     } else {
         const int a_tiles = (a + 255) / 256, b_tiles = (b + 63) / 64;
-        hipLaunchKernelGGL((xty_partial<256, 64>), dim3(chunks, a_tiles * b_tiles, B), dim3(kThreads), 0,
-                           st, X, Y, N, a, b, x_transposed, chunk_rows, b_tiles, workspace);
+        const dim3 grid(chunks, a_tiles * b_tiles, B);
+        if (x_transposed)
+            hipLaunchKernelGGL((xty_partial<256, 64, true>), grid, dim3(kThreads), 0, st, X, Y, N, a, b,
+                               chunk_rows, b_tiles, workspace);
+        else
+            hipLaunchKernelGGL((xty_partial<256, 64, false>), grid, dim3(kThreads), 0, st, X, Y, N, a, b,
+                               chunk_rows, b_tiles, workspace);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
