@@ -417,3 +417,29 @@ def test_bi_attention_reassociated_equals_reference_order(dev):
     names = ["out_v", "out_l", "grad_v", "grad_l"] + ["grad " + n for n, _ in att.named_parameters()]
     for n, a, b in zip(names, res[True], res[False]):
         close(a, b, 2e-5, n)
+
+
+@pytest.mark.parametrize("empty", ["one_image", "all_images"])
+def test_stacked_criterion_with_images_without_boxes(empty):
+    """Images without ground-truth boxes (common in detection batches): the stacked path must agree
+    with the per-set loop there too (class loss only; box losses 0)."""
+    from types import SimpleNamespace
+
+    g = torch.Generator().manual_seed(2)
+    S, B, Q, C = 7, 2, 30, 16
+    logits = torch.randn(S, B, Q, C, generator=g).requires_grad_(True)
+    boxes = torch.cat([torch.rand(S, B, Q, 2, generator=g) * 0.6 + 0.2, torch.rand(S, B, Q, 2, generator=g) * 0.3 + 0.05], -1)
+    n_per = (0, 4) if empty == "one_image" else (0, 0)
+    targets = [{"labels": torch.randint(0, 5, (n,), generator=g),
+                "boxes": torch.cat([torch.rand(n, 2, generator=g) * 0.5 + 0.25, torch.rand(n, 2, generator=g) * 0.3 + 0.1], -1)}
+               for n in n_per]
+    crit = criterion.build_criterion(SimpleNamespace(aux_loss=True, dec_layers=6, max_text_len=C))
+    out = {"pred_logits": logits[5], "pred_boxes": boxes[5],
+           "aux_outputs": [{"pred_logits": logits[i], "pred_boxes": boxes[i]} for i in range(5)],
+           "enc_outputs": {"pred_logits": logits[6], "pred_boxes": boxes[6]}}
+    loop = crit(out, targets)
+    fast = crit(dict(out, stacked=(logits, boxes, ["_%d" % i for i in range(5)] + ["", "_enc"])), targets)
+    assert set(loop) == set(fast)
+    for k in loop:
+        assert torch.isfinite(fast[k])
+        close(fast[k], loop[k], 1e-6, k)

@@ -163,7 +163,7 @@ class TwoStageCriterion(SetCriterion):
             tgt = boxes_all[t_i]
             l1 = F.l1_loss(src, tgt, reduction="none").sum(-1)
             giou = 1 - generalized_box_iou_aligned(box_cxcywh_to_xyxy(src), box_cxcywh_to_xyxy(tgt))
-            if len(set(counts)) == 1:      # the usual case: every set matches every target
+            if len(set(counts)) == 1 and counts[0] > 0:   # the usual case: every set matches every target
                 l1_s = l1.view(S, -1).sum(1) / num_boxes
                 giou_s = giou.view(S, -1).sum(1) / num_boxes
             else:
