@@ -126,7 +126,10 @@ def test_ragged_batch_different_sizes_and_captions():
     trainer = ZiraTrainer(model)
     a = synthetic_batch(1, 224, 320, n_categories=4, boxes_per_image=3, seed=1, device="cuda")[0]
     b = synthetic_batch(1, 200, 272, n_categories=2, boxes_per_image=1, seed=2, device="cuda")[0]
-    b["instances"] = b["instances"][:0]                      # no ground truth in the second image
+    from ziragroundingdino_amd.structures import Boxes, Instances
+    inst = b["instances"]                                    # no ground truth in the second image
+    b["instances"] = Instances(inst.image_size, gt_boxes=Boxes(inst.gt_boxes.tensor[:0]),
+                               gt_classes=inst.gt_classes[:0])
     data = [a, b]
     assert a["captions"] != b["captions"]
     for _ in range(2):
