@@ -42,8 +42,13 @@ class ZiraTrainer:
         for p in self.params:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
-        groups = [{"params": [p], "lr": lr * lr_factor(n), "weight_decay": weight_decay}
-                  for n, p in named]
+        # one parameter group per learning rate (the reference builds one per tensor; AdamW is
+        # element-wise, so the result is the same and the multi-tensor kernels see 12-13 tensors
+        # each instead of 25 groups of one)
+        by_lr = {}
+        for n, p in named:
+            by_lr.setdefault(lr * lr_factor(n), []).append(p)
+        groups = [{"params": ps, "lr": g_lr, "weight_decay": weight_decay} for g_lr, ps in by_lr.items()]
         self.optimizer = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay)
         self.clip_max_norm, self.clip_norm_type = clip_max_norm, clip_norm_type
         self.group = process_group
