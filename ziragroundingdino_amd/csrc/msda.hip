@@ -617,6 +617,8 @@ struct TilePlan {
     unsigned rows;     // LDS rows per tile (upper bound: ceil(S / T))
     unsigned wave_k2;  // 1: msda_bwd_tiles_wave (a wave per tile), 0: msda_bwd_tiles (a block per tile)
     unsigned qwords;   // words of K2's slice queue (wave_k2 only, else 0)
+    unsigned runlist;  // 1: K1 publishes a compact run list per tile (dense calls), 0: the tile x block matrix
+    unsigned run_base; // runlist: word offset of the records behind the counters
 };
 
 // block-granular head-major placement: virtual block id for (XCD = bid & 7, index = bid >> 3)
@@ -733,7 +735,19 @@ __global__ __launch_bounds__(kK1Waves * 64, kK1Waves == 16 ? 8 : 6) void msda_bw
         const unsigned excl = total + wbase + incl - n_mine;
         if (ti < plan.NT) {
             hist[ti] = excl;
-            desc[((size_t)g * plan.NT + ti) * plan.nblk + blk] = (excl << 16) | n_mine;
+            if (plan.runlist) {
+                // dense calls: a block of consecutive pixel-grid queries touches a few dozen of the
+                // ~1400 tiles of its head; only those runs are published, appended to the tile's list
+                // (desc = [heads * NT] run counters, zeroed by the host, then [heads * NT][nblk] records)
+                if (n_mine) {
+                    const size_t tg = (size_t)g * plan.NT + ti;
+                    const unsigned at = atomicAdd(&desc[tg], 1u);
+                    uint2 *runs = reinterpret_cast<uint2 *>(desc + plan.run_base) + tg * plan.nblk;
+                    runs[at] = make_uint2((blk << 16) | n_mine, excl);
+                }
+            } else {
+                desc[((size_t)g * plan.NT + ti) * plan.nblk + blk] = (excl << 16) | n_mine;
+            }
         }
         total += ctot;
         __syncthreads();
@@ -910,6 +924,17 @@ __device__ __forceinline__ void locate_tile_entry(const unsigned *pre, const uns
     }
     blk = lo;
     pos = lo * eblk + runoff[lo] + (e - pre[lo]);
+}
+
+// entry e of the tile -> index of its run (largest r with pre[r] <= e) among `nruns` runs
+__device__ __forceinline__ unsigned locate_run(const unsigned *pre, unsigned nruns, unsigned e)
+{
+    unsigned lo = 0, hi = nruns;
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (pre[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 // entry e of the tile -> (K1 block, entry) through the run prefix kept in LDS
@@ -1093,9 +1118,10 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
     unsigned *rowcnt = lds_k2;                // [R]      entries per row (this batch)
     unsigned *rowbase = rowcnt + R;           // [R + 1]  exclusive prefix of rowcnt
     unsigned *pre = rowbase + R + 1;          // [nblk + 1] exclusive prefix of the run lengths
-    unsigned *runoff = pre + plan.nblk + 1;   // [nblk]   offset of the run inside its K1 slice
-    unsigned *scratch = runoff + plan.nblk;   // [8]
-    uint2 *sorted = reinterpret_cast<uint2 *>(scratch + 8 + ((2 * R + 1 + 2 * plan.nblk + 1) & 1));
+    unsigned *runoff = pre + plan.nblk + 1;   // [nblk]   position of the run in the head's region
+    unsigned *runblk = runoff + plan.nblk;    // [nblk]   K1 block of the run
+    unsigned *scratch = runblk + plan.nblk;   // [8]
+    uint2 *sorted = reinterpret_cast<uint2 *>(scratch + 8 + ((2 * R + 1 + 3 * plan.nblk + 1) & 1));
     // sorted[cap]: (q << 12 | row), weight -- in row order; then kRowsumPartWords per wave
     unsigned *part = reinterpret_cast<unsigned *>(sorted + cap);
 
@@ -1120,19 +1146,32 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
     float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
     const size_t row_stride = (size_t)M * D;
 
-    // run-length prefix over the K1 blocks of this head (descriptor = offset << 16 | count)
-    const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
+    // run-length prefix over the runs of this tile: either one (possibly empty) run per K1 block of
+    // the head (descriptor = offset << 16 | count) or the compact list K1 appended to
     const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
+    const size_t tg = (size_t)g * plan.NT + tile;
+    const unsigned nruns = plan.runlist ? desc[tg] : plan.nblk;
+    const unsigned *dsc = desc + tg * plan.nblk;
+    const uint2 *runs = reinterpret_cast<const uint2 *>(desc + plan.run_base) + tg * plan.nblk;
     unsigned N = 0;
-    for (unsigned c0 = 0; c0 < plan.nblk; c0 += kK2Threads) {
+    for (unsigned c0 = 0; c0 < nruns; c0 += kK2Threads) {
         const unsigned i = c0 + threadIdx.x;
-        const unsigned dd = i < plan.nblk ? dsc[i] : 0u;
+        unsigned n = 0, off = 0, rb = i;
+        if (i < nruns) {
+            if (plan.runlist) {
+                const uint2 rec = runs[i];
+                n = rec.x & 0xffffu; rb = rec.x >> 16; off = rec.y;
+            } else {
+                const unsigned dd = dsc[i];
+                n = dd & 0xffffu; off = dd >> 16;
+            }
+        }
         unsigned tot;
-        const unsigned ex = block_exclusive_scan(dd & 0xffffu, scratch, tot);
-        if (i < plan.nblk) { pre[i] = N + ex; runoff[i] = dd >> 16; }
+        const unsigned ex = block_exclusive_scan(n, scratch, tot);
+        if (i < nruns) { pre[i] = N + ex; runoff[i] = rb * plan.eblk + off; runblk[i] = rb; }
         N += tot;
     }
-    if (threadIdx.x == 0) pre[plan.nblk] = N;
+    if (threadIdx.x == 0) pre[nruns] = N;
     K2_STAMP(1);
 
     // rows owned by this wave (same split in every batch)
@@ -1162,9 +1201,9 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
                     keyr[u] = kInvalidRow;
                     posr[v] = 0;
                     if (i < nb) {
-                        unsigned blk;
-                        locate_tile_entry(pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk, posr[v]);
-                        keyr[u] = blk * plan.ipb;
+                        const unsigned r = locate_run(pre, nruns, e_lo + i);
+                        posr[v] = runoff[r] + (e_lo + i - pre[r]);
+                        keyr[u] = runblk[r] * plan.ipb;
                     }
                 }
 #pragma unroll
@@ -1183,8 +1222,8 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
             }
         } else {
             for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
-                unsigned blk;
-                const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                const unsigned r = locate_run(pre, nruns, e_lo + i);
+                const uint2 en = reg_g[runoff[r] + (e_lo + i - pre[r])];
                 atomicAdd(&rowcnt[en.x & 0xffffu], 1u);
             }
         }
@@ -1216,11 +1255,11 @@ __global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
                     sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
         } else {
             for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
-                unsigned blk;
-                const uint2 en = fetch_tile_entry(reg_g, pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk);
+                const unsigned r = locate_run(pre, nruns, e_lo + i);
+                const uint2 en = reg_g[runoff[r] + (e_lo + i - pre[r])];
                 const unsigned row = en.x & 0xffffu;
                 const unsigned dst = atomicAdd(&rowcnt[row], 1u) & 0x7fffffffu;
-                sorted[dst] = make_uint2(((blk * plan.ipb + (en.x >> 16)) << 12) | row, en.y);
+                sorted[dst] = make_uint2(((runblk[r] * plan.ipb + (en.x >> 16)) << 12) | row, en.y);
             }
         }
         __syncthreads();
@@ -1716,6 +1755,8 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     // at most kMaxTileRows rows per tile (12-bit row field of the sorted entries)
     p.wave_k2 = !dense;
     p.qwords = 0;
+    p.runlist = 0;
+    p.run_base = 0;
     if (p.wave_k2) {  // a wave per tile: <= kWaveTileRows rows each
         // as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD), so that the grid is one round
         const unsigned t_min = ((unsigned)S + kWaveTileRows - 1) / kWaveTileRows;
@@ -1754,6 +1795,9 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     if (p.rows > kMaxTileRows || Q >= (1 << 20)) return false;  // sorted entry = q:20 | row:12
     if (((size_t)p.NT + (size_t)p.eblk * 5) * 4 > 150 * 1024) return false;  // K1 LDS
     if ((unsigned long long)heads * p.nblk * p.eblk >= (1ull << 32)) return false;
+    // dense calls publish compact run lists (blk:16 | count:16, offset); counters first, 256-B aligned
+    p.runlist = dense && p.nblk < (1u << 16) ? 1u : 0u;
+    p.run_base = (unsigned)((((size_t)heads * p.NT * sizeof(unsigned) + 255) & ~(size_t)255) / sizeof(unsigned));
     return true;
 }
 
@@ -1761,6 +1805,8 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 inline size_t tile_desc_bytes(const TilePlan &p, int B, int M)
 {
+    if (p.runlist)  // run counters, then up to nblk 8-byte records per tile (sparsely touched)
+        return (size_t)p.run_base * sizeof(unsigned) + align256((size_t)B * M * p.NT * p.nblk * sizeof(uint2));
     return align256((size_t)B * M * p.NT * p.nblk * sizeof(unsigned));
 }
 
@@ -1787,6 +1833,10 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     const unsigned heads = (unsigned)B * M;
     const FastDiv Mdiv = make_fast_div((unsigned)M), Tdiv = make_fast_div(p.T);
 
+    if (p.runlist) {  // the per-tile run counters start at zero
+        hipError_t em = hipMemsetAsync(desc, 0, (size_t)heads * p.NT * sizeof(unsigned), st);
+        if (em != hipSuccess) return (int)em;
+    }
     const unsigned nv1 = heads * p.nblk, per1 = (nv1 + 7) >> 3;
     const size_t lds1 = ((size_t)p.NT + (size_t)p.eblk * 5) * 4;
     const void *k1 = p.ipb == 16 * kItemsPerWave
@@ -1829,7 +1879,7 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     const unsigned long long mean = (unsigned long long)Q * L * P * 4 / p.NT;
     unsigned cap = 1024;
     while (cap < 8192 && cap < 2 * mean) cap <<= 1;
-    const size_t lds2 = ((size_t)p.rows * 2 + 1 + 2 * p.nblk + 1 + 8 + 1 + (size_t)cap * 2 +
+    const size_t lds2 = ((size_t)p.rows * 2 + 1 + 3 * p.nblk + 1 + 8 + 1 + (size_t)cap * 2 +
                          (kK2Threads / 64) * kRowsumPartWords) * 4;
     if (lds2 > 64 * 1024) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiles<D>),
