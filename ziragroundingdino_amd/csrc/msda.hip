@@ -1315,6 +1315,16 @@ constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #ifndef ZIRA_K2W_MINWAVES
 #define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
 #endif
+#ifndef ZIRA_DENSE_WAVE_K2
+#define ZIRA_DENSE_WAVE_K2 0   // 1: dense calls (encoder) on the wave-per-tile K2 as well.  Measured: its owners
+                               // take 292 us against 360 us for the block kernel, but with ~350 entries per tile
+                               // (NT <= 4096) a third of the tiles overflow the 512-entry sort: + 117 us of atomic
+                               // helper slices, or 442 us when the owners walk their slices; K1 + 30 us (4096 bins)
+#endif
+#ifndef ZIRA_DENSE_WAVE_ENTRIES
+#define ZIRA_DENSE_WAVE_ENTRIES 350
+#endif
+constexpr unsigned kDenseWaveEntries = ZIRA_DENSE_WAVE_ENTRIES;
 #ifndef ZIRA_K2W_HEAVY
 #define ZIRA_K2W_HEAVY 512
 #endif
@@ -1329,6 +1339,12 @@ constexpr unsigned kWaveK2Waves = 4;
 // LDS words of a wave's sorted entries; the partial records of rowsum_slices alias them
 constexpr unsigned kWaveSortWords = 2 * kWaveTileCap > kRowsumPartWords ? 2 * kWaveTileCap : kRowsumPartWords;
 constexpr unsigned kWaveHelperBlocks = 512;  // helper launch: 2048 waves stride over the queue (an empty launch costs ~2 us whatever the grid)
+// LDS words of one wave of msda_bwd_tiles_wave: rowcnt[R], rowbase[R+1], pre[nblk+1], runoff[nblk],
+// runblk[nblk] (rounded up to an even count), then the sorted entries
+__host__ __device__ inline unsigned wave_meta_words(unsigned R, unsigned nblk)
+{
+    return (2 * R + 2 + 3 * nblk + 1 + 1) & ~1u;
+}
 constexpr unsigned kQueueHeader = 4;       // words: [0] tail, [1] head, [2..3] unused
 constexpr unsigned kQueueSliceBits = 13;   // item = ((virtual tile << 13) | slice) + 1
 
@@ -1342,7 +1358,7 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v, unsigned lan
     return v;
 }
 
-template <int D, bool kHelpers>
+template <int D, bool kHelpers, bool kRunList>
 __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES) void msda_bwd_tiles_wave(
     const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
@@ -1358,13 +1374,14 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lane = threadIdx.x & 63;
     const unsigned R = plan.rows;
-    const unsigned per_wave = 2 * R + 2 + 2 * plan.nblk + 2 + kWaveSortWords;  // words (even)
+    const unsigned per_wave = wave_meta_words(R, plan.nblk) + kWaveSortWords;  // words (even)
     unsigned *base = lds_k2w + (size_t)wave * per_wave;
     unsigned *rowcnt = base;                      // [R]
     unsigned *rowbase = rowcnt + R;               // [R + 1]
     unsigned *pre = rowbase + R + 1;              // [nblk + 1]
-    unsigned *runoff = pre + plan.nblk + 1;       // [nblk]
-    uint2 *sorted = reinterpret_cast<uint2 *>(base + ((2 * R + 2 + 2 * plan.nblk + 2) & ~1u));
+    unsigned *runoff = pre + plan.nblk + 1;       // [nblk] position of the run in the head's region
+    unsigned *runblk = runoff + plan.nblk;        // [nblk] K1 block of the run
+    uint2 *sorted = reinterpret_cast<uint2 *>(base + wave_meta_words(R, plan.nblk));
     const unsigned slot = lane % NSLOT, cq = lane / NSLOT;
     const unsigned M = Mdiv.d;
     const size_t row_stride = (size_t)M * D;
@@ -1388,6 +1405,7 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             slice = item & ((1u << kQueueSliceBits) - 1);
         }
         K2W_STAMP(0);
+        bool more = false;  // dense calls: the owner walks the slices of an overfull tile itself
         const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
         const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
         const unsigned b = fast_div(g, Mdiv), m = g - b * M;
@@ -1399,32 +1417,52 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
             const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
             float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
-            const unsigned *dsc = desc + ((size_t)g * plan.NT + tile) * plan.nblk;
+            const size_t tg = (size_t)g * plan.NT + tile;
+            const unsigned nruns =
+                kRunList ? __builtin_amdgcn_readfirstlane(desc[tg]) : plan.nblk;  // see msda_bwd_tiles
+            const unsigned *dsc = desc + tg * plan.nblk;
+            const uint2 *runs = reinterpret_cast<const uint2 *>(desc + plan.run_base) + tg * plan.nblk;
             const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
 
-            // run-length prefix over the K1 blocks of this head
+            // run-length prefix over the runs of this tile
             unsigned N = 0;
-            for (unsigned c0 = 0; c0 < plan.nblk; c0 += 64) {
+            for (unsigned c0 = 0; c0 < nruns; c0 += 64) {
                 const unsigned i = c0 + lane;
-                const unsigned dd = i < plan.nblk ? dsc[i] : 0u;
-                const unsigned n = dd & 0xffffu;
+                unsigned n = 0, off = 0, rb = i;
+                if (i < nruns) {
+                    if (kRunList) {
+                        const uint2 rec = runs[i];
+                        n = rec.x & 0xffffu; rb = rec.x >> 16; off = rec.y;
+                    } else {
+                        const unsigned dd = dsc[i];
+                        n = dd & 0xffffu; off = dd >> 16;
+                    }
+                }
                 const unsigned incl = wave_inclusive_scan(n, lane);
-                if (i < plan.nblk) { pre[i] = N + incl - n; runoff[i] = dd >> 16; }
+                if (i < nruns) {
+                    pre[i] = N + incl - n;
+                    if (kRunList) { runoff[i] = rb * plan.eblk + off; runblk[i] = rb; }
+                    else runoff[i] = off;  // run i is K1 block i
+                }
                 N += __shfl(incl, 63);
             }
-            if (lane == 0) pre[plan.nblk] = N;
+            if (lane == 0) pre[nruns] = N;
             K2W_STAMP(1);
 
             const bool heavy = N > kHeavyTile;  // wave-uniform
-            if (!kHelpers && heavy && lane == 0) {  // publish slices 1 .. extra
+            if (!kHelpers && heavy && !kRunList && lane == 0) {  // publish slices 1 .. extra
                 const unsigned extra = (N - 1) / kSliceEntries;
                 const unsigned at = __hip_atomic_fetch_add(&queue[0], extra, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT);
                 for (unsigned k = 1; k <= extra; ++k)
                     queue[kQueueHeader + at + k - 1] = ((vb2 << kQueueSliceBits) | k) + 1;
             }
-            const int mode = kHelpers ? kRowAtomic : kRowStore;
+            // Dense calls (run lists) have a dozen rounds of tiles per wave slot, so an overfull tile
+            // is no tail: its owner takes the slices one after the other (read-modify-write of its
+            // own rows) instead of publishing them for the atomic helper launch.
+            const int mode = kHelpers ? kRowAtomic : (slice == 0 ? kRowStore : kRowRmw);
             const unsigned span_e = heavy ? kSliceEntries : kWaveTileCap;
+            more = !kHelpers && kRunList && heavy && (slice + 1) * span_e < N;
             const unsigned e_lo = slice * span_e;
             const unsigned nb = (N - e_lo < span_e) ? N - e_lo : span_e;
 
@@ -1439,9 +1477,15 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
                 keyr[u] = kInvalidRow;
                 posr[u] = 0;
                 if (i < nb) {
-                    unsigned blk;
-                    locate_tile_entry(pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk, posr[u]);
-                    keyr[u] = blk * plan.ipb;
+                    if (kRunList) {
+                        const unsigned r = locate_run(pre, nruns, e_lo + i);
+                        posr[u] = runoff[r] + (e_lo + i - pre[r]);
+                        keyr[u] = runblk[r] * plan.ipb;
+                    } else {
+                        unsigned blk;
+                        locate_tile_entry(pre, runoff, plan.nblk, plan.eblk, e_lo + i, blk, posr[u]);
+                        keyr[u] = blk * plan.ipb;
+                    }
                 }
             }
             uint2 enr[EPL];
@@ -1477,7 +1521,7 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             __builtin_amdgcn_wave_barrier();
             K2W_STAMP(4);
 
-            if (!kHelpers) {  // rows nobody contributes to (in slice 0) are stored as zeros
+            if (!kHelpers && slice == 0) {  // rows nobody contributes to (in slice 0) are stored as zeros
                 for (unsigned r = slot; r < rows; r += NSLOT)
                     if (rowbase[r + 1] == rowbase[r])
                         *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1493,7 +1537,11 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             K2W_STAMP(6);
             __builtin_amdgcn_wave_barrier();
         }
-        if (!kHelpers) break;
+        if (!kHelpers) {
+            if (!more) break;
+            ++slice;
+            qi -= gridDim.x * kWaveK2Waves;  // (undo the loop increment: same wave, same tile)
+        }
     }
     K2W_STAMP(7);
 }
@@ -1753,28 +1801,38 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     // K2 runs one block per tile, 4 blocks per CU: aim for one full round of the chip (the
     // per-tile critical path is a chain of dependent memory round trips, so rounds cost), with
     // at most kMaxTileRows rows per tile (12-bit row field of the sorted entries)
-    p.wave_k2 = !dense;
+    p.wave_k2 = ZIRA_DENSE_WAVE_K2 || !dense;
     p.qwords = 0;
     p.runlist = 0;
     p.run_base = 0;
     if (p.wave_k2) {  // a wave per tile: <= kWaveTileRows rows each
-        // as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD), so that the grid is one round
         const unsigned t_min = ((unsigned)S + kWaveTileRows - 1) / kWaveTileRows;
-        const unsigned t_fit = (device_cu_count() * 4 * ZIRA_K2W_MINWAVES) / (heads * (unsigned)L);
-        p.T = t_fit > t_min ? t_fit : t_min;
+        unsigned t_want;
+        if (dense) {  // many rounds anyway: tiles of ~kDenseWaveEntries entries (runs come as lists)
+            const unsigned long long per_level = (unsigned long long)Q * P * 4;
+            t_want = (unsigned)((per_level + kDenseWaveEntries - 1) / kDenseWaveEntries);
+            if (t_want > 4096u / (unsigned)L) t_want = 4096u / (unsigned)L;
+        } else {      // as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD): the grid is one round
+            t_want = (device_cu_count() * 4 * ZIRA_K2W_MINWAVES) / (heads * (unsigned)L);
+        }
+        p.T = t_want > t_min ? t_want : t_min;
         if (p.T > (unsigned)S) p.T = (unsigned)S;
         p.NT = (unsigned)L * p.T;
         p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
         p.rows = ((unsigned)S + p.T - 1) / p.T;
-        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + kWaveSortWords;
+        p.runlist = dense && p.nblk < (1u << 16) ? 1u : 0u;
+        p.run_base = (unsigned)((((size_t)heads * p.NT * sizeof(unsigned) + 255) & ~(size_t)255) / sizeof(unsigned));
+        const size_t per_wave = (size_t)wave_meta_words(p.rows, p.nblk) + kWaveSortWords;
         // a heavy tile publishes ceil(N / kSliceEntries) - 1 slices: at most (all entries) / kSliceEntries in total
         const unsigned long long all_entries = (unsigned long long)heads * Q * L * P * 4;
-        p.qwords = kQueueHeader + (unsigned)(all_entries / kSliceEntries) + 1;
+        p.qwords = dense ? 0u : kQueueHeader + (unsigned)(all_entries / kSliceEntries) + 1;
         if (p.NT <= 4096 && per_wave * 4 * kWaveK2Waves <= 64 * 1024 && Q < (1 << 20) &&
+            (!dense || p.runlist) && (unsigned long long)heads * p.nblk * p.eblk < (1ull << 32) &&
             (unsigned long long)heads * p.NT < (1ull << (32 - kQueueSliceBits)) &&
             ((size_t)p.NT + (size_t)p.eblk * 5) * 4 <= 150 * 1024)
             return true;
         p.qwords = 0;
+        p.runlist = 0;
         p.wave_k2 = 0;  // does not fit: block-per-tile variant below
     }
     unsigned T = ((unsigned)S + kMaxTileRows - 1) / kMaxTileRows;
@@ -1862,14 +1920,21 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     if (p.wave_k2) {
         const unsigned nvw = heads * p.NT, perw = (nvw + 7) >> 3;
         const unsigned blocks_per_xcd = (perw + kWaveK2Waves - 1) / kWaveK2Waves;
-        const size_t per_wave = 2 * (size_t)p.rows + 2 + 2 * (size_t)p.nblk + 2 + kWaveSortWords;
-        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false>), dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
+        const size_t per_wave = (size_t)wave_meta_words(p.rows, p.nblk) + kWaveSortWords;
+        if (p.runlist) {  // dense calls: owners walk their slices, no helper launch
+            hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false, true>), dim3(blocks_per_xcd * 8),
+                               dim3(kWaveK2Waves * 64), per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start,
+                               (unsigned)S, Mdiv, (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc,
+                               region, queue, gv);
+            return (int)hipGetLastError();
+        }
+        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false, false>), dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
                            per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
                            (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         // slices 1.. of heavy tiles (ends at once when there are none)
-        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, true>), dim3(kWaveHelperBlocks), dim3(kWaveK2Waves * 64),
+        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, true, false>), dim3(kWaveHelperBlocks), dim3(kWaveK2Waves * 64),
                            per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
                            (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
         return (int)hipGetLastError();
