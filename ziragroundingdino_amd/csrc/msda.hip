@@ -583,7 +583,8 @@ __global__ __launch_bounds__(kBlock, 8) void msda_bwd_lean_atomic(
 // IPB*LP*4 possible entries).  Precondition (as in the reference module,
 // ms_deform_attn.py:284): the levels tile [0, S) exactly.
 // ------------------------------------------------------------------------------------------
-constexpr unsigned kItemsPerWave = 3;  // K1: items per wave; a block has 4 or 16 waves
+constexpr unsigned kItemsPerWave = 3;  // K1: items per wave; a block has 4 (sparse calls) or 8 (dense) waves
+constexpr unsigned kK1DenseWaves = 8;
 #ifndef ZIRA_K2_THREADS
 #define ZIRA_K2_THREADS 256
 #endif
@@ -635,11 +636,11 @@ __device__ __forceinline__ unsigned tile_span(unsigned hw, FastDiv T)
     return fast_div(hw + T.d - 1, T);
 }
 
-// Occupancy: the dense variant (16 waves, 64 KB of LDS per block) is held to 64 VGPRs so that two
-// blocks fit a CU (20 B of spill, still 1.5% faster than one block at 77 VGPRs); the sparse variant
-// runs at 75 VGPRs with all eight gathers of a chunk in flight.
+// Occupancy: both variants run at <= 80 VGPRs (no spills) with all eight gathers of a chunk in
+// flight.  Dense calls use 8-wave blocks (24 queries, 36 KB of LDS: 3 blocks per CU); 16-wave
+// blocks needed 64 VGPRs (spills) to fit twice and were 5 % slower once the runs came as lists.
 template <int CQR, unsigned kK1Waves>
-__global__ __launch_bounds__(kK1Waves * 64, kK1Waves == 16 ? 8 : 6) void msda_bwd_items(
+__global__ __launch_bounds__(kK1Waves * 64, 6) void msda_bwd_items(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
     const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv,
@@ -1795,7 +1796,7 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     // chip; dense calls use 16-wave blocks so that the (tile x block) run table stays small
     const unsigned heads = (unsigned)B * M;
     const bool dense = (unsigned long long)heads * Q >= 16 * 4096;
-    p.ipb = (dense ? 16u : 4u) * kItemsPerWave;
+    p.ipb = (dense ? kK1DenseWaves : 4u) * kItemsPerWave;
     p.eblk = p.ipb * p.chunks * 64;
     if (p.eblk >= 65536) return false;
     // K2 runs one block per tile, 4 blocks per CU: aim for one full round of the chip (the
@@ -1897,15 +1898,15 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     }
     const unsigned nv1 = heads * p.nblk, per1 = (nv1 + 7) >> 3;
     const size_t lds1 = ((size_t)p.NT + (size_t)p.eblk * 5) * 4;
-    const void *k1 = p.ipb == 16 * kItemsPerWave
-                         ? reinterpret_cast<const void *>(&msda_bwd_items<CQR, 16>)
+    const void *k1 = p.ipb == kK1DenseWaves * kItemsPerWave
+                         ? reinterpret_cast<const void *>(&msda_bwd_items<CQR, kK1DenseWaves>)
                          : reinterpret_cast<const void *>(&msda_bwd_items<CQR, 4>);
     if (lds1 > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS (LP > 16 only)
         hipError_t ea = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (ea != hipSuccess) return (int)ea;
     }
-    if (p.ipb == 16 * kItemsPerWave)
-        hipLaunchKernelGGL((msda_bwd_items<CQR, 16>), dim3(per1 * 8), dim3(16 * 64), lds1, st,
+    if (p.ipb == kK1DenseWaves * kItemsPerWave)
+        hipLaunchKernelGGL((msda_bwd_items<CQR, kK1DenseWaves>), dim3(per1 * 8), dim3(kK1DenseWaves * 64), lds1, st,
                            grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
                            (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
                            nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
