@@ -66,7 +66,7 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
 /* Sorted ("tiled") float32 backward: same results up to summation order, 2-6x faster than the
  * plain entry point (no fp32 atomics on the common path).
  * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions
- * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 223 MB at Q=S), or 0 when that path does
+ * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 347 MB at Q=S), or 0 when that path does
  * not apply (the plain entry point is then the only one).  The workspace is caller-owned
  * DEVICE memory, 16-byte aligned, needs no initialisation and may be reused by later calls
  * on the same stream; with workspace == NULL or too small the call degrades to
