@@ -22,7 +22,13 @@ constexpr int kThreads = 256;
 constexpr int kMaxChunks = 128;
 
 typedef float v16f __attribute__((ext_vector_type(16)));
-typedef float4 __attribute__((aligned(4))) float4_u;  // 4-byte aligned 16-byte load (rows of odd length)
+// 16-byte load from a 4-byte aligned address (rows of odd length): one global_load_dwordx4 on gfx950
+__device__ __forceinline__ float4 load4_unaligned(const float *p)
+{
+    float4 v;
+    __builtin_memcpy(&v, p, sizeof(v));
+    return v;
+}
 
 // One workgroup = 4 waves = one TA x TB tile of the output (64 x 256 or 256 x 64) over one chunk of
 // the reduction; a wave owns a 64 x 64 sub-tile as 2 x 2 MFMA blocks (v_mfma_f32_32x32x2_f32: two
@@ -95,8 +101,8 @@ __global__ __launch_bounds__(kThreads) void xty_partial(const float *__restrict_
                 const float *xp = Xz + (size_t)(a0 + c) * N + n0;
 #pragma unroll
                 for (int q = 0; q < kUnroll / 2; ++q) {
-                    t.xq[q][0] = *reinterpret_cast<const float4_u *>(xp + 4 * q);
-                    t.xq[q][1] = *reinterpret_cast<const float4_u *>(xp + (size_t)32 * N + 4 * q);
+                    t.xq[q][0] = load4_unaligned(xp + 4 * q);
+                    t.xq[q][1] = load4_unaligned(xp + (size_t)32 * N + 4 * q);
                 }
             }
             return;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void xty_partial(const float *__restrict_
                     const float *src = Xz + (size_t)ca[h] * N + n;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (n + 3 < N) {
-                        v = *reinterpret_cast<const float4_u *>(src);
+                        v = load4_unaligned(src);
                     } else {
                         if (n < N) v.x = src[0];
                         if (n + 1 < N) v.y = src[1];
