@@ -139,3 +139,30 @@ def test_ragged_batch_different_sizes_and_captions():
     with torch.no_grad():
         res = model(data)
     assert len(res) == 2 and all("instances" in r for r in res)
+
+
+def test_no_padding_shortcut_changes_nothing():
+    """With equally sized images the key-padding fills are skipped (host-known ``no_padding``):
+    the loss dict must be bit-identical to the run that applies the all-False masks."""
+    model = small_model().train()
+    model.before_train()
+    model.use_frontend_graphs = False
+    data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+    from ziragroundingdino_amd import utils as zu
+
+    fast = model(data)
+    orig = zu.nested_tensor_from_tensor_list
+
+    def padded(tl):
+        out = orig(tl)
+        out.no_padding = False
+        return out
+
+    import ziragroundingdino_amd.groundingdino as gd
+    gd.nested_tensor_from_tensor_list = padded
+    try:
+        slow = model(data)
+    finally:
+        gd.nested_tensor_from_tensor_list = orig
+    for k in slow:
+        assert torch.equal(fast[k], slow[k]), k

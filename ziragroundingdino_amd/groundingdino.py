@@ -303,7 +303,8 @@ class GroundingDINO(nn.Module):
         features, poss = self.run_backbone(samples)
 
         out_or_loss = self.forward_features(features, poss, samples.mask, text_dict,
-                                            cate_to_token_mask_list, loss_linear_adapter, targets)
+                                            cate_to_token_mask_list, loss_linear_adapter, targets,
+                                            no_padding=getattr(samples, "no_padding", False))
         if self.training:
             return out_or_loss
         out = out_or_loss
@@ -317,7 +318,7 @@ class GroundingDINO(nn.Module):
         return processed
 
     def forward_features(self, features, poss, samples_mask, text_dict, cate_to_token_mask_list,
-                         loss_linear_adapter=None, targets=None):
+                         loss_linear_adapter=None, targets=None, no_padding=False):
         """Everything downstream of the frozen backbone / text encoder: input projections with
         the vision side branches, transformer, heads, and in training mode the criterion
         (reference :483-587).  ``features``: list of NestedTensor, ``poss``: their position
@@ -352,7 +353,7 @@ class GroundingDINO(nn.Module):
                 srcs, masks, poss, text_dict)
         else:
             hs, reference, hs_enc, ref_enc, init_box_proposal, _ = self.transformer(
-                srcs, masks, None, poss, None, None, text_dict)
+                srcs, masks, None, poss, None, None, text_dict, no_padding=no_padding)
 
         # Heads (reference groundingdino_dual_zero_rep_branch.py:559-583).  The box MLP is shared by
         # the decoder layers and the classifier is parameter-free, so all layers -- and in training

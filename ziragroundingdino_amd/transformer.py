@@ -653,7 +653,7 @@ class Transformer(nn.Module):
 
     def select_and_decode(self, memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
                           level_start_index, valid_ratios, text_dict, refpoint_embed=None, tgt=None,
-                          attn_mask=None):
+                          attn_mask=None, no_padding=False):
         """Two-stage query selection (top-k by max token logit) + decoder (reference :301-415)."""
         bs = memory.shape[0]
         if self.two_stage_type == "standard":
@@ -691,7 +691,8 @@ class Transformer(nn.Module):
 
         hs, references, _ = self.decoder(
             tgt=tgt.transpose(0, 1), memory=memory.transpose(0, 1),
-            memory_key_padding_mask=mask_flatten, pos=lvl_pos_embed_flatten.transpose(0, 1),
+            memory_key_padding_mask=None if no_padding else mask_flatten,
+            pos=lvl_pos_embed_flatten.transpose(0, 1),
             refpoints_unsigmoid=refpoint_embed.transpose(0, 1), level_start_index=level_start_index,
             spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, tgt_mask=attn_mask,
             memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"])
@@ -704,12 +705,17 @@ class Transformer(nn.Module):
         self.last_topk_proposals = topk_proposals  # exposed for the bit-exact index parity tests
         return hs, references, hs_enc, ref_enc, init_box_proposal
 
-    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None):
+    def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None,
+                no_padding=False):
+        """``no_padding``: the caller knows (on the host, from the image sizes) that ``masks`` are
+        all False; the key-padding fills of the 12 MSDA calls and 6 fusion blocks (a pass over the
+        45 MB value tensor each, forward and backward) are then skipped -- same results."""
         (src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes, level_start_index,
          valid_ratios) = self.prepare_inputs(srcs, masks, pos_embeds)
         memory, memory_text, adapter_loss1 = self.encoder(
             src_flatten, pos=lvl_pos_embed_flatten, level_start_index=level_start_index,
-            spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, key_padding_mask=mask_flatten,
+            spatial_shapes=spatial_shapes, valid_ratios=valid_ratios,
+            key_padding_mask=None if no_padding else mask_flatten,
             memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"],
             position_ids=text_dict["position_ids"],
             text_self_attention_masks=text_dict["text_self_attention_masks"],
@@ -717,7 +723,7 @@ class Transformer(nn.Module):
         text_dict["encoded_text"] = memory_text
         hs, references, hs_enc, ref_enc, init_box_proposal = self.select_and_decode(
             memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes, level_start_index,
-            valid_ratios, text_dict, refpoint_embed, tgt, attn_mask)
+            valid_ratios, text_dict, refpoint_embed, tgt, attn_mask, no_padding=no_padding)
         return hs, references, hs_enc, ref_enc, init_box_proposal, adapter_loss1
 
 

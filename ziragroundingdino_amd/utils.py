@@ -172,6 +172,7 @@ class NestedTensor(object):
     def __init__(self, tensors, mask: Optional[Tensor]):
         self.tensors = tensors
         self.mask = mask
+        self.no_padding = False  # True: all images fill the batch tensor (mask is all False)
 
     def to(self, device):
         mask = self.mask.to(device) if self.mask is not None else None
@@ -194,7 +195,9 @@ def nested_tensor_from_tensor_list(tensor_list) -> NestedTensor:
                           device=batch.device)
         for m, (h, w) in zip(mask, sizes):
             m[:h, :w] = False
-        return NestedTensor(batch, mask)
+        out = NestedTensor(batch, mask)
+        out.no_padding = all((h, w) == tuple(batch.shape[2:]) for h, w in sizes)  # known on the host
+        return out
     if tensor_list[0].ndim != 3:
         raise ValueError("not supported")
     c = tensor_list[0].shape[0]
@@ -206,4 +209,6 @@ def nested_tensor_from_tensor_list(tensor_list) -> NestedTensor:
     for img, pad_img, m in zip(tensor_list, tensor, mask):
         pad_img[:, :img.shape[1], :img.shape[2]].copy_(img)
         m[:img.shape[1], :img.shape[2]] = False
-    return NestedTensor(tensor, mask)
+    out = NestedTensor(tensor, mask)
+    out.no_padding = all(tuple(img.shape[1:]) == (h, w) for img in tensor_list)  # known on the host
+    return out
