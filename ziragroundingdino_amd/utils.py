@@ -161,7 +161,7 @@ def recover_to_cls_logits(logits: Tensor, cate_to_token_mask_list: List[Tensor],
         # A category without tokens (the mask generator emits one between the last "." and [SEP]
         # whenever the caption is shorter than the batch's longest, bertwarper.py:262-266) makes
         # the reference's max() over an empty selection raise; here it reads as "no such category".
-        per_cat = torch.where(torch.isneginf(per_cat), per_cat.new_tensor(for_fill), per_cat)
+        per_cat = per_cat.masked_fill(torch.isneginf(per_cat), for_fill)
         new_logits[..., bid, :, :n_cat] = per_cat
     return new_logits
 
