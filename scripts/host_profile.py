@@ -14,5 +14,5 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5): trainer.run_step(data)
 torch.cuda.synchronize(); pr.disable()
 for key in ("tottime", "cumtime"):
-    s = io.StringIO(); pstats.Stats(pr, stream=s).strip_dirs().sort_stats(key).print_stats(28)
-    print(s.getvalue()[:6000])
+    s = io.StringIO(); pstats.Stats(pr, stream=s).strip_dirs().sort_stats(key).print_stats(int(os.environ.get("TOP", "28")))
+    print(s.getvalue()[:12000])
