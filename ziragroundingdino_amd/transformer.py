@@ -118,6 +118,13 @@ class BiMultiHeadAttention(nn.Module):
             nn.init.xavier_uniform_(lin.weight)
             lin.bias.data.fill_(0)
 
+    def _clamp(self, x: Tensor) -> Tensor:
+        """clamp(min=-50000) then clamp(max=50000) (reference fuse_modules.py:171-177) as one kernel
+        when both are switched on -- same values, same gradient."""
+        lo = -50000 if self.clamp_min_for_underflow else None
+        hi = 50000 if self.clamp_max_for_overflow else None
+        return x if lo is None and hi is None else torch.clamp(x, min=lo, max=hi)
+
     def _heads(self, t: Tensor, bsz: int):
         return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).reshape(
             bsz * self.num_heads, -1, self.head_dim)
@@ -153,18 +160,12 @@ class BiMultiHeadAttention(nn.Module):
             attn = torch.bmm(q, k.transpose(1, 2))  # [bs*heads, n_img, n_text]
         if self.stable_softmax_2d:
             attn = _SubtractGlobalMax.apply(attn)
-        if self.clamp_min_for_underflow:
-            attn = torch.clamp(attn, min=-50000)
-        if self.clamp_max_for_overflow:
-            attn = torch.clamp(attn, max=50000)
+        attn = self._clamp(attn)
 
         attn_T = attn.transpose(1, 2)
         # reference: attn_T - torch.max(attn_T, dim=-1, keepdim=True)[0]  (fuse_modules.py:180)
         attn_l = attn_T - _max_over_tokens(attn).transpose(1, 2)
-        if self.clamp_min_for_underflow:
-            attn_l = torch.clamp(attn_l, min=-50000)
-        if self.clamp_max_for_overflow:
-            attn_l = torch.clamp(attn_l, max=50000)
+        attn_l = self._clamp(attn_l)
         if attention_mask_v is not None:
             mv = attention_mask_v[:, None, None, :].repeat(1, self.num_heads, 1, 1).flatten(0, 1)
             attn_l = attn_l.masked_fill(mv, float("-inf"))
