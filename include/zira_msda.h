@@ -131,6 +131,29 @@ size_t zira_xty_workspace_floats(int B, int N, int a, int b);
 int zira_xty_f32(const float *X, const float *Y, int B, int N, int a, int b, int x_transposed,
                  float *out, float *workspace, void *stream);
 
+/* ---- fused score post-processing of the bi-directional attention ---------------------------
+ * (reference fuse_modules.py:165-200: global-max shift, clamps, softmax over the text tokens,
+ * column-max shift, clamps, softmax over the image tokens -- ~300 PyTorch kernels per layer and
+ * direction).  Layout [B, N, H*T] throughout (N image tokens, H heads, T text tokens).
+ *   x = xm + c;  x1 = clamp(x - max(x));  pv = softmax_t(x1 | mask_l);
+ *   e = exp(clamp(x1 - max_n x1)) (0 where mask_v);  colsum = sum_n e      (p_l = e / colsum)
+ * mask_l [B,T] / mask_v [B,N]: bytes, non-zero = padded, may be NULL.  colmax [B,H*T] and gmax [1]
+ * are outputs of the forward that the backward needs again.  The backward takes the gradients
+ * w.r.t. pv, e and colsum and returns those w.r.t. xm and c; it assumes e and colsum are only
+ * used as e / colsum (then the paths through the two maxima vanish).  H*T <= 4096.
+ * workspace: zira_bisoftmax_workspace_floats(B, N, H, T) floats, no initialisation needed. */
+size_t zira_bisoftmax_workspace_floats(int B, int N, int H, int T);
+
+int zira_bisoftmax_fwd_f32(const float *xm, const float *c, const uint8_t *mask_l, const uint8_t *mask_v,
+                           int B, int N, int H, int T, int stable, int clamp_lo, int clamp_hi, float *pv,
+                           float *e, float *colsum, float *colmax, float *gmax, float *workspace,
+                           void *stream);
+
+int zira_bisoftmax_bwd_f32(const float *xm, const float *c, const uint8_t *mask_l, int B, int N, int H, int T,
+                           int stable, int clamp_lo, int clamp_hi, const float *pv, const float *e,
+                           const float *colmax, const float *gmax, const float *g_pv, const float *g_e,
+                           const float *g_colsum, float *g_xm, float *g_c, float *workspace, void *stream);
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -15,6 +15,7 @@ SYMBOLS = (
     "zira_msda_bwd_workspace_bytes", "zira_msda_bwd_f32_ws",
     "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
     "zira_xty_workspace_floats", "zira_xty_f32",
+    "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -58,6 +59,12 @@ def load():
     lib.zira_xty_workspace_floats.restype = sz
     lib.zira_xty_f32.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp]
     lib.zira_xty_f32.restype = i
+    lib.zira_bisoftmax_workspace_floats.argtypes = [i, i, i, i]
+    lib.zira_bisoftmax_workspace_floats.restype = sz
+    lib.zira_bisoftmax_fwd_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.zira_bisoftmax_fwd_f32.restype = i
+    lib.zira_bisoftmax_bwd_f32.argtypes = [vp, vp, vp, i, i, i, i, i, i, i] + [vp] * 11
+    lib.zira_bisoftmax_bwd_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

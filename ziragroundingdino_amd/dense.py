@@ -153,3 +153,103 @@ def tall_reduce(P, V):
 def wide_matmul(L, R, bias=None):
     """(bias +) L [B, N, k] @ R [B, k, m] with autograd; see ``_WideMatmul``."""
     return _WideMatmul.apply(L, R, bias)
+
+
+class _TallReduceNT(torch.autograd.Function):
+    """E [B, N, a]^T @ V [B, N, b] -> [B, a, b] (both operands token-major)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, E, V):
+        ctx.save_for_backward(E, V)
+        return xty(E, V)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        E, V = ctx.saved_tensors
+        g = g.to(E.dtype)
+        gE = torch.bmm(V, g.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gV = torch.bmm(E, g) if ctx.needs_input_grad[1] else None
+        return gE, gV
+
+
+def tall_reduce_nt(E, V):
+    """E [B, N, a]^T @ V [B, N, b] with autograd."""
+    return _TallReduceNT.apply(E, V)
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused score post-processing of the bi-directional attention (csrc/bisoftmax.hip)
+# ---------------------------------------------------------------------------------------------
+_BIS_WS = {}
+
+
+def _bis_workspace(lib, dev, B, N, H, T):
+    n = lib.zira_bisoftmax_workspace_floats(B, N, H, T)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _BIS_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _BIS_WS[key] = torch.empty(n, dtype=torch.float32, device=dev)
+    return ws
+
+
+def bi_softmax_supported(xm, H, T, dropout_active):
+    return (xm.is_cuda and xm.dtype == torch.float32 and not dropout_active and H * T <= 4096
+            and not torch.is_autocast_enabled())
+
+
+class _BiSoftmax(torch.autograd.Function):
+    """(xm [B,N,H*T], c [B,H*T], mask_l [B,T] | None, mask_v [B,N] | None) -> (pv, e, colsum); see
+    include/zira_msda.h.  The gradient is only valid when e and colsum are used as e / colsum."""
+
+    @staticmethod
+    def forward(ctx, xm, c, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi):
+        from . import _lib
+
+        lib = _lib.load()
+        xm, c = xm.contiguous(), c.contiguous()
+        B, N, HT = xm.shape
+        assert HT == H * T and c.shape == (B, HT)
+        ml = mask_l.contiguous().view(torch.uint8) if mask_l is not None else None
+        mv = mask_v.contiguous().view(torch.uint8) if mask_v is not None else None
+        pv, e = torch.empty_like(xm), torch.empty_like(xm)
+        colsum, colmax = torch.empty_like(c), torch.empty_like(c)
+        gmax = torch.empty(1, dtype=torch.float32, device=xm.device)
+        ws = _bis_workspace(lib, xm.device, B, N, H, T)
+        rc = lib.zira_bisoftmax_fwd_f32(
+            xm.data_ptr(), c.data_ptr(), ml.data_ptr() if ml is not None else None,
+            mv.data_ptr() if mv is not None else None, B, N, H, T, int(stable), int(clamp_lo), int(clamp_hi),
+            pv.data_ptr(), e.data_ptr(), colsum.data_ptr(), colmax.data_ptr(), gmax.data_ptr(), ws.data_ptr(),
+            torch.cuda.current_stream(xm.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_bisoftmax_fwd_f32 failed with HIP error %d" % rc)
+        ctx.save_for_backward(xm, c, pv, e, colmax, gmax)
+        ctx.ml = ml
+        ctx.dims = (B, N, H, T, int(stable), int(clamp_lo), int(clamp_hi))
+        return pv, e, colsum
+
+    @staticmethod
+    def backward(ctx, g_pv, g_e, g_cs):
+        from . import _lib
+
+        lib = _lib.load()
+        xm, c, pv, e, colmax, gmax = ctx.saved_tensors
+        B, N, H, T, stable, clo, chi = ctx.dims
+        g_pv = torch.zeros_like(xm) if g_pv is None else g_pv.contiguous()
+        g_e = torch.zeros_like(xm) if g_e is None else g_e.contiguous()
+        g_cs = torch.zeros_like(c) if g_cs is None else g_cs.contiguous()
+        g_xm, g_c = torch.empty_like(xm), torch.empty_like(c)
+        ws = _bis_workspace(lib, xm.device, B, N, H, T)
+        rc = lib.zira_bisoftmax_bwd_f32(
+            xm.data_ptr(), c.data_ptr(), ctx.ml.data_ptr() if ctx.ml is not None else None, B, N, H, T,
+            stable, clo, chi, pv.data_ptr(), e.data_ptr(), colmax.data_ptr(), gmax.data_ptr(), g_pv.data_ptr(),
+            g_e.data_ptr(), g_cs.data_ptr(), g_xm.data_ptr(), g_c.data_ptr(), ws.data_ptr(),
+            torch.cuda.current_stream(xm.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_bisoftmax_bwd_f32 failed with HIP error %d" % rc)
+        return g_xm, g_c, None, None, None, None, None, None, None
+
+
+def bi_softmax(xm, c, mask_l, mask_v, H, T, stable=True, clamp_lo=True, clamp_hi=True):
+    return _BiSoftmax.apply(xm, c, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi)

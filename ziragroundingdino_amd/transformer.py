@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .dense import tall_reduce, wide_matmul
+from .dense import bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul
 from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
 from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
                     gen_sineembed_for_position, get_sine_pos_embed, inverse_sigmoid)
@@ -91,6 +91,8 @@ class _SubtractGlobalMax(torch.autograd.Function):
 class BiMultiHeadAttention(nn.Module):
     """Image <-> text attention sharing one score matrix (reference fuse_modules.py:99-248)."""
 
+    fused_softmax = True  # score post-processing in one HIP op where it applies (fp32, no dropout)
+
     def __init__(self, v_dim, l_dim, embed_dim, num_heads, dropout=0.1, cfg=None):
         super().__init__()
         self.embed_dim = embed_dim
@@ -149,6 +151,20 @@ class BiMultiHeadAttention(nn.Module):
             wq = self.v_proj.weight.view(H, hd, -1)
             a = torch.einsum("hed,bthe->bdht", wq, k4) * self.scale             # [B, v_dim, H, T]
             c = torch.einsum("he,bthe->bht", self.v_proj.bias.view(H, hd), k4) * self.scale
+            if self.fused_softmax and bi_softmax_supported(v, H, src_len, self.training and self.dropout > 0):
+                # everything between the score GEMM and the two output GEMMs in one HIP op
+                # (csrc/bisoftmax.hip), tensors staying in the GEMMs' [B, N, H*T] layout
+                xm = wide_matmul(v, a.reshape(bsz, -1, H * src_len))
+                pv, e, colsum = bi_softmax(xm, c.reshape(bsz, H * src_len), attention_mask_l, attention_mask_v,
+                                           H, src_len, self.stable_softmax_2d, self.clamp_min_for_underflow,
+                                           self.clamp_max_for_overflow)
+                u = (tall_reduce_nt(e, v) / colsum[..., None]).view(bsz, H, src_len, -1)   # P_l v
+                out_l = torch.einsum("bhtd,hed->bthe", u, self.values_v_proj.weight.view(H, hd, -1))
+                out_l = out_l + self.values_v_proj.bias.view(H, hd)     # rows of P_l sum to one
+                out_l = self.out_l_proj(out_l.reshape(bsz, src_len, self.embed_dim))
+                z = torch.einsum("bthe,dhe->bhtd", value_l4, self.out_v_proj.weight.view(-1, H, hd))
+                out_v = wide_matmul(pv, z.reshape(bsz, H * src_len, -1), self.out_v_proj.bias)
+                return out_v, out_l
             attn = wide_matmul(v, a.reshape(bsz, -1, H * src_len)).view(bsz, tgt_len, H, src_len) + c[:, None]
             attn = attn.permute(0, 2, 1, 3).reshape(bsz * H, tgt_len, src_len)  # [bs*heads, n_img, n_text]
         else:
