@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ziragroundingdino_amd import transformer
 from bench import NORTH_STAR_SHAPES
 dev = torch.device("cuda"); torch.manual_seed(0)
+transformer.DeformableTransformerEncoderLayer.fuse_bias_relu = bool(int(os.environ.get('FUSE', '0')))
 layer = transformer.DeformableTransformerEncoderLayer(256, 2048, 0.0, "relu", 4, 8, 4).to(dev).train()
 for p in layer.parameters(): p.requires_grad_(False)
 S = sum(h * w for h, w in NORTH_STAR_SHAPES)
