@@ -29,8 +29,12 @@ def lr_factor(name: str) -> float:
 
 class ZiraTrainer:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), clip_max_norm=0.1,
-                 clip_norm_type=2.0, process_group=None):
+                 clip_norm_type=2.0, process_group=None, tuned_gemms=True):
         self.model = model
+        if tuned_gemms and next(model.parameters()).is_cuda:
+            from . import tuned_gemm
+
+            tuned_gemm.enable()  # per-shape GEMM kernel choices recorded for this step (see tuned_gemm.py)
         model.before_train()  # freeze everything but the side branches
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.names = [n for n, _ in named]
