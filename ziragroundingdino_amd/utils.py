@@ -56,6 +56,9 @@ class MLP(nn.Module):
         return x
 
 
+_SINE_CONSTS = {}
+
+
 def _interleaved_sincos(arg: Tensor) -> Tensor:
     """[..., n] -> [..., n] with sin on even and cos on odd channels (pairs share a frequency)."""
     return torch.stack((arg[..., 0::2].sin(), arg[..., 1::2].cos()), dim=-1).flatten(-2)
@@ -80,14 +83,19 @@ def get_sine_pos_embed(pos_tensor: Tensor, num_pos_feats: int = 128, temperature
 def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
     """[nq, bs, 2|4] (x, y[, w, h]) in [0,1] -> [nq, bs, 256|512], ordered (y, x[, w, h]);
     128 features each, temperature 10000 (reference utils.py:204-231)."""
-    dim_t = _dim_t(128, 10000, pos_tensor.device)
-    emb = [_interleaved_sincos(pos_tensor[:, :, i, None] * (2 * math.pi) / dim_t)
-           for i in range(pos_tensor.size(-1))]
-    if pos_tensor.size(-1) == 2:
-        return torch.cat((emb[1], emb[0]), dim=2)
-    if pos_tensor.size(-1) == 4:
-        return torch.cat((emb[1], emb[0], emb[2], emb[3]), dim=2)
-    raise ValueError("Unknown pos_tensor shape(-1):{}".format(pos_tensor.size(-1)))
+    n = pos_tensor.size(-1)
+    if n not in (2, 4):
+        raise ValueError("Unknown pos_tensor shape(-1):{}".format(n))
+    # all coordinates at once (same arithmetic per element as the reference's per-coordinate loop,
+    # 6 kernels instead of 30): reorder (x, y, ...) -> (y, x, ...), scale, divide, sin / cos
+    key = (str(pos_tensor.device), n)
+    consts = _SINE_CONSTS.get(key)
+    if consts is None:
+        order = torch.tensor([1, 0, 2, 3][:n], device=pos_tensor.device)
+        consts = _SINE_CONSTS[key] = (order, _dim_t(128, 10000, pos_tensor.device))
+    order, dim_t = consts
+    arg = pos_tensor.index_select(-1, order)[..., None] * (2 * math.pi) / dim_t      # [nq, bs, n, 128]
+    return _interleaved_sincos(arg).flatten(2)
 
 
 def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor, spatial_shapes,
