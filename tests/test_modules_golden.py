@@ -443,3 +443,31 @@ def test_stacked_criterion_with_images_without_boxes(empty):
     for k in loop:
         assert torch.isfinite(fast[k])
         close(fast[k], loop[k], 1e-6, k)
+
+
+def test_lean_mha_equals_nn_multihead_attention():
+    """transformer.lean_mha against nn.MultiheadAttention for the three call patterns of the model:
+    self-attention with q = k != v, cross-attention with a key-padding mask, self-attention with a
+    per-(batch*head) boolean mask; outputs and input gradients."""
+    torch.manual_seed(0)
+    mha = torch.nn.MultiheadAttention(64, 4, dropout=0.0).train()
+    L, S, B = 11, 7, 3
+    x = torch.randn(L, B, 64, requires_grad=True)
+    pos = torch.randn(L, B, 64)
+    mem = torch.randn(S, B, 64, requires_grad=True)
+    kpm = torch.zeros(B, S, dtype=torch.bool)
+    kpm[0, 5:] = True
+    am = torch.rand(B * 4, L, L) > 0.7
+    am[:, torch.arange(L), torch.arange(L)] = False          # never mask a whole row
+    qk = x + pos
+    cases = [((qk, qk, x), {}), ((x, mem, mem), {"key_padding_mask": kpm}), ((qk, qk, x), {"attn_mask": am})]
+    for (q, k, v), kw in cases:
+        want = mha(q, k, v, need_weights=False, **kw)[0]
+        got = transformer.lean_mha(mha, q, k, v, **kw)
+        close(got, want, 2e-6, "output")
+        g = torch.randn_like(want)
+        wrt = [x] + ([mem] if k is mem else [])
+        gw = torch.autograd.grad((want * g).sum(), wrt, retain_graph=True)
+        gg = torch.autograd.grad((got * g).sum(), wrt, retain_graph=True)
+        for a, b in zip(gg, gw):
+            close(a, b, 2e-6, "grad")
