@@ -16,7 +16,7 @@ n = 8 * 8192
 buf = (ctypes.c_ulonglong * n)()
 lib.zira_dev_read_k2_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.zira_dev_read_k2_stamps(buf, n) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)[:6000]  # owners (helpers: 6000+)
 a = a[a[:, 0] > 0]
 a = a[a[:, 7] > 0]
 t0 = a[:, 0].min()
@@ -47,3 +47,15 @@ if loc.shape[1] != v.shape[1]:
                 print("  level %d: %4d waves, lifetime mean %6.2f p90 %6.2f max %6.2f | phases mean %s" % (
                     l, m.sum(), life[m].mean(), np.percentile(life[m], 90), life[m].max(),
                     " ".join("%5.2f" % x for x in dd[m].mean(0))))
+# helper launch (stamp ids 6000 + wave): when do the slices start and how long do their phases take
+full = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
+own = full[:6000]; own = own[(own[:, 0] > 0) & (own[:, 7] > 0)]
+hel = full[6000:]; hel = hel[(hel[:, 0] > 0) & (hel[:, 7] > 0)]
+if len(hel) and len(own):
+    t_own0, t_own1 = own[:, 0].min(), own[:, 7].max()
+    busy = hel[hel[:, 6] > hel[:, 0]]
+    print("owners: %.2f us span; helper waves stamped %d (with a slice: %d); first helper start %.2f us after the owners' end, helper span %.2f us"
+          % ((t_own1 - t_own0) / 100.0, len(hel), len(busy), (hel[:, 0].min() - t_own1) / 100.0, (hel[:, 7].max() - hel[:, 0].min()) / 100.0))
+    if len(busy):
+        dd = np.diff(busy, axis=1) / 100.0
+        print("  helper phases mean: " + " ".join("%5.2f" % x for x in dd.mean(0)) + " | max: " + " ".join("%5.2f" % x for x in dd.max(0)))

@@ -996,7 +996,10 @@ __device__ __forceinline__ void rowsum_slices(const uint2 *sorted, unsigned n,
     // the loads under `if (e < b)` the compiler has been seen to wait for each one before issuing
     // the next (536 -> 625 us on the encoder shape); lanes past their slice read the last entry of
     // the range and ignore it.  The wave-per-tile K2 schedules the predicated form well and saves
-    // the wasted loads (48.8 vs 50.3 us).
+    // the wasted loads (48.8 vs 50.3 us).  (Its fold does wait with vmcnt(0), i.e. for the batch
+    // issued just before it as well; a branch-free ping/pong with exact vmcnt(U..) waits was
+    // measured again later: 46.4 -> 45.9 us with uniform locations, but 78 -> 81.5 us on the
+    // model's clustered ones -- the helper launch is bound by its atomics, not by this chain.)
     auto issue = [&](Batch &t, unsigned i) {
 #pragma unroll
         for (unsigned u = 0; u < U; ++u) {
@@ -1396,7 +1399,7 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
         vb2 = xcd * per_xcd + idx * kWaveK2Waves + wave;
         if (idx * kWaveK2Waves + wave >= per_xcd || vb2 >= nvirt) return;  // wave-uniform
     }
-    const unsigned stamp_id = kHelpers ? 0xFFFFFFFFu : vb2;
+    const unsigned stamp_id = kHelpers ? 6000u + blockIdx.x * kWaveK2Waves + wave : vb2;  // (developer stamps)
     (void)stamp_id;
     for (;; qi += gridDim.x * kWaveK2Waves) {
         if (kHelpers) {
