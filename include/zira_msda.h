@@ -154,6 +154,16 @@ int zira_bisoftmax_bwd_f32(const float *xm, const float *c, const uint8_t *mask_
                            const float *colmax, const float *gmax, const float *g_pv, const float *g_e,
                            const float *g_colsum, float *g_xm, float *g_c, float *workspace, void *stream);
 
+/* ---- Row LayerNorm forward (csrc/layernorm.hip) --------------------------------------------
+ * y[r, :] = (x[r, :] - mean_r) * rstd_r * gamma + beta over the last dimension C, the nn.LayerNorm
+ * of the encoder layers (reference transformer.py:810-811 norm1 / norm2, fuse_modules.py:262
+ * layer_norm_v) and of the Swin-T blocks (swin_transformer.py:215, 258, 304), for row-major fp32
+ * x [rows, C] with C % 4 == 0, C <= 1024 and 16-byte aligned pointers.  gamma / beta may be NULL
+ * (1 / 0); mean / rstd [rows] are the statistics aten::native_layer_norm returns (either may be
+ * NULL), so the backward can stay with aten::native_layer_norm_backward.  Two-pass variance. */
+int zira_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, int64_t rows, int C,
+                           float eps, float *y, float *mean, float *rstd, void *stream);
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .dense import conv_module_as_gemm
+from .dense import LayerNorm, conv_module_as_gemm
 from .transformer import DropPath
 from .utils import NestedTensor
 
@@ -85,10 +85,10 @@ class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, drop_path):
         super().__init__()
         self.window_size, self.shift_size = window_size, shift_size
-        self.norm1 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
         self.attn = WindowAttention(dim, window_size, num_heads)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, H, W, mask_matrix):
@@ -117,7 +117,7 @@ class PatchMerging(nn.Module):
     def __init__(self, dim):
         super().__init__()
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
-        self.norm = nn.LayerNorm(4 * dim)
+        self.norm = LayerNorm(4 * dim)
 
     def forward(self, x, H, W):
         B, L, C = x.shape
@@ -160,7 +160,7 @@ class PatchEmbed(nn.Module):
         super().__init__()
         self.patch_size = patch_size
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
-        self.norm = nn.LayerNorm(embed_dim)
+        self.norm = LayerNorm(embed_dim)
 
     def forward(self, x):
         _, _, H, W = x.shape
@@ -186,7 +186,7 @@ class SwinTransformer(nn.Module):
                        dpr[sum(depths[:i]):sum(depths[:i + 1])], downsample=i < self.num_layers - 1)
             for i in range(self.num_layers)])
         for i in self.out_indices:
-            self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
+            self.add_module(f"norm{i}", LayerNorm(self.num_features[i]))
 
     def forward(self, tensor_list: NestedTensor):
         x, Wh, Ww = self.patch_embed(tensor_list.tensors)

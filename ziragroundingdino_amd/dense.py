@@ -253,3 +253,70 @@ class _BiSoftmax(torch.autograd.Function):
 
 def bi_softmax(xm, c, mask_l, mask_v, H, T, stable=True, clamp_lo=True, clamp_hi=True):
     return _BiSoftmax.apply(xm, c, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi)
+
+
+# ---- row LayerNorm (csrc/layernorm.hip) ------------------------------------------------------
+LN_MIN_ROWS = 8192   # below this the launch is latency-bound either way and ATen's call path is leaner
+
+
+def layer_norm_supported(x, normalized_shape, weight, bias):
+    C = x.shape[-1] if x.dim() else 0
+    return (x.is_cuda and x.dtype == torch.float32 and len(normalized_shape) == 1 and normalized_shape[0] == C
+            and C % 4 == 0 and 0 < C <= 1024 and x.numel() // max(C, 1) >= LN_MIN_ROWS
+            and (weight is None or weight.dtype == torch.float32) and (bias is None or bias.dtype == torch.float32))
+
+
+class _LayerNorm(torch.autograd.Function):
+    """Forward on the row kernel (x read once, 4+ TB/s); backward is aten::native_layer_norm_backward on the
+    saved mean / rstd, i.e. exactly what autograd of F.layer_norm runs."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias, eps):
+        from . import _lib
+        C = x.shape[-1]
+        xc = x.contiguous()
+        rows = xc.numel() // C
+        y = torch.empty_like(xc)
+        stats = torch.empty((2, rows), device=x.device, dtype=torch.float32)
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        rc = _lib.load().zira_layernorm_fwd_f32(
+            xc.data_ptr(), w.data_ptr() if w is not None else None, b.data_ptr() if b is not None else None,
+            rows, C, float(eps), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+            torch.cuda.current_stream(x.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_layernorm_fwd_f32 failed with code %d" % rc)
+        ctx.save_for_backward(xc, w, b, stats)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        xc, w, b, stats = ctx.saved_tensors
+        lead = xc.shape[:-1] + (1,)
+        mask = [ctx.needs_input_grad[0], w is not None and ctx.needs_input_grad[1],
+                b is not None and ctx.needs_input_grad[2]]
+        gx, gw, gb = torch.ops.aten.native_layer_norm_backward(
+            gy.contiguous(), xc, [ctx.C], stats[0].view(lead), stats[1].view(lead), w, b, mask)
+        return gx, gw, gb, None
+
+
+def layer_norm(x, normalized_shape, weight=None, bias=None, eps=1e-5):
+    """F.layer_norm with the forward of wide fp32 activations on csrc/layernorm.hip."""
+    normalized_shape = tuple(normalized_shape) if not isinstance(normalized_shape, int) else (normalized_shape,)
+    if layer_norm_supported(x, normalized_shape, weight, bias):
+        return _LayerNorm.apply(x, weight, bias, eps)
+    return F.layer_norm(x, normalized_shape, weight, bias, eps)
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm (same parameters and state-dict keys) whose forward goes through layer_norm()."""
+
+    fused = True   # class-level switch for A/B runs
+
+    def forward(self, x):
+        if self.fused:
+            return layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        return super().forward(x)

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .dense import bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul
+from .dense import LayerNorm, bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul
 from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
 from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
                     gen_sineembed_for_position, get_sine_pos_embed, inverse_sigmoid)
@@ -294,8 +294,8 @@ class BiAttentionBlock(nn.Module):
     def __init__(self, v_dim, l_dim, embed_dim, num_heads, dropout=0.1, drop_path=0.0,
                  init_values=1e-4, cfg=None):
         super().__init__()
-        self.layer_norm_v = nn.LayerNorm(v_dim)
-        self.layer_norm_l = nn.LayerNorm(l_dim)
+        self.layer_norm_v = LayerNorm(v_dim)
+        self.layer_norm_l = LayerNorm(l_dim)
         self.attn = BiMultiHeadAttention(v_dim=v_dim, l_dim=l_dim, embed_dim=embed_dim,
                                          num_heads=num_heads, dropout=dropout)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
@@ -323,8 +323,8 @@ class TransformerEncoderLayer(nn.Module):
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
-        self.norm1 = nn.LayerNorm(d_model)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
         self.activation = _get_activation_fn(activation)
@@ -361,13 +361,13 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(embed_dim=d_model, num_levels=n_levels, num_heads=n_heads,
                                       num_points=n_points, batch_first=True)
         self.dropout1 = nn.Dropout(dropout)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = LayerNorm(d_model)
         self.linear1 = nn.Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation, d_model=d_ffn)
         self.dropout2 = nn.Dropout(dropout)
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
         self.use_adapter = False
 
     @staticmethod
@@ -409,20 +409,20 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.cross_attn = MSDeformAttn(embed_dim=d_model, num_levels=n_levels, num_heads=n_heads,
                                        num_points=n_points, batch_first=True)
         self.dropout1 = ident_or_drop()
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = LayerNorm(d_model)
         if use_text_cross_attention:
             self.ca_text = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
             self.catext_dropout = ident_or_drop()
-            self.catext_norm = nn.LayerNorm(d_model)
+            self.catext_norm = LayerNorm(d_model)
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
         self.dropout2 = ident_or_drop()
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
         self.linear1 = nn.Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation, d_model=d_ffn, batch_dim=1)
         self.dropout3 = ident_or_drop()
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout4 = ident_or_drop()
-        self.norm3 = nn.LayerNorm(d_model)
+        self.norm3 = LayerNorm(d_model)
         self.key_aware_proj = None
         self.use_text_feat_guide = use_text_feat_guide
         self.use_text_cross_attention = use_text_cross_attention
@@ -662,7 +662,7 @@ class Transformer(nn.Module):
             d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, dec_n_points,
             use_text_cross_attention=use_text_cross_attention, use_adapter=use_adapter)
         self.decoder = TransformerDecoder(
-            decoder_layer, num_decoder_layers, nn.LayerNorm(d_model),
+            decoder_layer, num_decoder_layers, LayerNorm(d_model),
             return_intermediate=return_intermediate_dec, d_model=d_model, query_dim=query_dim,
             num_feature_levels=num_feature_levels)
 
@@ -683,7 +683,7 @@ class Transformer(nn.Module):
         self.two_stage_type = two_stage_type
         if two_stage_type == "standard":
             self.enc_output = nn.Linear(d_model, d_model)
-            self.enc_output_norm = nn.LayerNorm(d_model)
+            self.enc_output_norm = LayerNorm(d_model)
             self.two_stage_wh_embedding = None
         if two_stage_type == "no":
             self.init_ref_points(num_queries)
