@@ -164,6 +164,11 @@ int zira_bisoftmax_bwd_f32(const float *xm, const float *c, const uint8_t *mask_
 int zira_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta, int64_t rows, int C,
                            float eps, float *y, float *mean, float *rstd, void *stream);
 
+/* Input gradient of the above: dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) with g = dy * gamma,
+ * xhat = (x - mean) * rstd; mean / rstd as returned by the forward.  (Parameter gradients: ATen.) */
+int zira_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
+                           const float *rstd, int64_t rows, int C, float *dx, void *stream);
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -74,3 +74,18 @@ def test_bf16_autocast_returns_fp32_like_aten():
         want = F.layer_norm(x, (256,))
     assert got.dtype == want.dtype == torch.float32
     assert float((got - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("rows,C", [(44446, 256), (8200, 96), (8200, 384), (8200, 768), (8192, 1024), (8195, 100)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_input_gradient_kernel_matches_float64(rows, C, affine):
+    g = torch.Generator().manual_seed(rows * 3 + C)
+    x = (torch.randn(rows, C, generator=g) * 2 - 0.5).to(DEV).requires_grad_(True)
+    w = torch.randn(C, generator=g).to(DEV) if affine else None       # frozen: no grad -> the row kernel
+    b = torch.randn(C, generator=g).to(DEV) if affine else None
+    go = torch.randn(rows, C, generator=g).to(DEV)
+    got, = torch.autograd.grad((dense.layer_norm(x, (C,), w, b) * go).sum(), [x])
+    xd = x.detach().double().requires_grad_(True)
+    want, = torch.autograd.grad((F.layer_norm(xd, (C,), None if w is None else w.double(),
+                                              None if b is None else b.double()) * go.double()).sum(), [xd])
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-6

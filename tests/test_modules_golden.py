@@ -471,3 +471,20 @@ def test_lean_mha_equals_nn_multihead_attention():
         gg = torch.autograd.grad((got * g).sum(), wrt, retain_graph=True)
         for a, b in zip(gg, gw):
             close(a, b, 2e-6, "grad")
+
+
+def test_bi_attention_block_training_droppath_equals_reference_formula():
+    """v + drop_path(gamma_v * delta_v) (reference fuse_modules.py:296-305, timm DropPath) is folded into one
+    addcmul with a [B, 1, C] scale: same RNG draws, same values up to one rounding."""
+    torch.manual_seed(0)
+    blk = transformer.BiAttentionBlock(v_dim=32, l_dim=32, embed_dim=64, num_heads=4, dropout=0.0,
+                                       drop_path=0.5, init_values=0.3).train()
+    v, l = torch.randn(4, 50, 32), torch.randn(4, 7, 32)
+    torch.manual_seed(7)
+    got_v, got_l = blk(v, l)
+    nv, nl = blk.layer_norm_v(v), blk.layer_norm_l(l)
+    dv, dl = blk.attn(nv, nl)
+    torch.manual_seed(7)
+    want_v = nv + blk.drop_path(blk.gamma_v * dv)
+    want_l = nl + blk.drop_path(blk.gamma_l * dl)
+    assert torch.allclose(got_v, want_v, atol=1e-6) and torch.allclose(got_l, want_l, atol=1e-6)

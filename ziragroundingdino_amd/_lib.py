@@ -16,7 +16,7 @@ SYMBOLS = (
     "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
     "zira_xty_workspace_floats", "zira_xty_f32",
     "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
-    "zira_layernorm_fwd_f32",
+    "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -68,6 +68,8 @@ def load():
     lib.zira_bisoftmax_bwd_f32.restype = i
     lib.zira_layernorm_fwd_f32.argtypes = [vp, vp, vp, ctypes.c_int64, i, ctypes.c_float, vp, vp, vp, vp]
     lib.zira_layernorm_fwd_f32.restype = i
+    lib.zira_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, i, vp, vp]
+    lib.zira_layernorm_bwd_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

@@ -11,8 +11,10 @@
 // (sum, then sum of squared deviations -- the same two-pass formula as the fp32 reference, not
 // E[x^2] - mean^2), reduced with DPP / permlane swaps; no LDS, no barriers.
 //
-// Outputs y, mean[rows], rstd[rows] (what aten::native_layer_norm returns, so the backward can stay
-// with aten::native_layer_norm_backward).
+// Outputs y, mean[rows], rstd[rows] (what aten::native_layer_norm returns).  The input gradient is the
+// same kind of stream (read dy and x, write dx) and has the same layout (ln_bwd_rows); the parameter
+// gradients (column sums over all rows) stay with aten::native_layer_norm_backward -- the ZiRa
+// fine-tune freezes every LayerNorm, so they are not computed at all on the path.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -112,16 +114,86 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_rows(
     }
 }
 
+// Input gradient of the same LayerNorm: with xhat = (x - mean) * rstd and g = dy * gamma,
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)).  Same row-in-registers layout (x and dy).
+template <int G, int NV>
+__global__ __launch_bounds__(kThreads) void ln_bwd_rows(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
+    const float *__restrict__ mean, const float *__restrict__ rstd, long rows, int C,
+    float *__restrict__ dx)
+{
+    const int c4 = C >> 2;
+    const int gl = threadIdx.x % G;
+    const long groups_per_block = kThreads / G;
+    const long g0 = (long)blockIdx.x * groups_per_block + threadIdx.x / G;
+    const long gstride = (long)gridDim.x * groups_per_block;
+    const float inv_c = 1.0f / (float)C;
+    float4 w[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = gl + k * G;
+        w[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (i < c4 && gamma) w[k] = reinterpret_cast<const float4 *>(gamma)[i];
+    }
+    for (long r = g0; r < rows; r += gstride) {
+        const float4 *xr = reinterpret_cast<const float4 *>(x + r * C);
+        const float4 *gr = reinterpret_cast<const float4 *>(dy + r * C);
+        const float mu = mean[r], rs = rstd[r];
+        float4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = gl + k * G;
+            xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g[k] = xh[k];
+            if (i < c4) {
+                const float4 xv = xr[i], gv = gr[i];
+                xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[k] = make_float4(gv.x * w[k].x, gv.y * w[k].y, gv.z * w[k].z, gv.w * w[k].w);
+            }
+            s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+            s2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+        }
+        const float m1 = group_sum<G>(s1) * inv_c;
+        const float m2 = group_sum<G>(s2) * inv_c;
+        float4 *dr = reinterpret_cast<float4 *>(dx + r * C);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = gl + k * G;
+            if (i < c4) {
+                float4 o;
+                o.x = rs * (g[k].x - m1 - xh[k].x * m2);
+                o.y = rs * (g[k].y - m1 - xh[k].y * m2);
+                o.z = rs * (g[k].z - m1 - xh[k].z * m2);
+                o.w = rs * (g[k].w - m1 - xh[k].w * m2);
+                dr[i] = o;
+            }
+        }
+    }
+}
+
+inline unsigned ln_blocks(long rows, long groups_per_block)
+{
+    long blocks = (rows + groups_per_block - 1) / groups_per_block;
+    const long cap = 256L * 8 * 4;  // 8 blocks per CU resident, a few rounds; grid-stride beyond
+    return (unsigned)(blocks > cap ? cap : blocks);
+}
+
+template <int G, int NV>
+int launch_ln_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
+                  const float *rstd, long rows, int C, float *dx, hipStream_t st)
+{
+    hipLaunchKernelGGL((ln_bwd_rows<G, NV>), dim3(ln_blocks(rows, kThreads / G)), dim3(kThreads), 0, st, dy,
+                       x, gamma, mean, rstd, rows, C, dx);
+    return (int)hipGetLastError();
+}
+
 template <int G, int NV>
 int launch_ln(const float *x, const float *gamma, const float *beta, long rows, int C, float eps,
               float *y, float *mean, float *rstd, hipStream_t st)
 {
-    const long groups_per_block = kThreads / G;
-    long blocks = (rows + groups_per_block - 1) / groups_per_block;
-    const long cap = 256L * 8 * 4;  // 8 blocks per CU resident, a few rounds; grid-stride beyond
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((ln_fwd_rows<G, NV>), dim3((unsigned)blocks), dim3(kThreads), 0, st, x, gamma,
-                       beta, rows, C, eps, y, mean, rstd);
+    hipLaunchKernelGGL((ln_fwd_rows<G, NV>), dim3(ln_blocks(rows, kThreads / G)), dim3(kThreads), 0, st, x,
+                       gamma, beta, rows, C, eps, y, mean, rstd);
     return (int)hipGetLastError();
 }
 
@@ -142,6 +214,21 @@ int zira_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta
     if (c4 <= 128) return launch_ln<64, 2>(x, gamma, beta, rows, C, eps, y, mean, rstd, st);
     if (c4 <= 192) return launch_ln<64, 3>(x, gamma, beta, rows, C, eps, y, mean, rstd, st);
     return launch_ln<64, 4>(x, gamma, beta, rows, C, eps, y, mean, rstd, st);
+}
+
+int zira_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
+                           const float *rstd, int64_t rows, int C, float *dx, void *stream)
+{
+    if (!dy || !x || !mean || !rstd || !dx || rows < 0 || C <= 0 || (C & 3) || C > 1024) return ZIRA_MSDA_EINVAL;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) return ZIRA_MSDA_EINVAL;
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int c4 = C >> 2;
+    if (c4 <= 32) return launch_ln_bwd<32, 1>(dy, x, gamma, mean, rstd, rows, C, dx, st);
+    if (c4 <= 64) return launch_ln_bwd<64, 1>(dy, x, gamma, mean, rstd, rows, C, dx, st);
+    if (c4 <= 128) return launch_ln_bwd<64, 2>(dy, x, gamma, mean, rstd, rows, C, dx, st);
+    if (c4 <= 192) return launch_ln_bwd<64, 3>(dy, x, gamma, mean, rstd, rows, C, dx, st);
+    return launch_ln_bwd<64, 4>(dy, x, gamma, mean, rstd, rows, C, dx, st);
 }
 
 }  // extern "C"
