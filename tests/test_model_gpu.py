@@ -166,3 +166,21 @@ def test_no_padding_shortcut_changes_nothing():
         gd.nested_tensor_from_tensor_list = orig
     for k in slow:
         assert torch.equal(fast[k], slow[k]), k
+
+
+def test_sampling_locations_one_pass_is_bit_identical():
+    """ref + offsets / (W, H) as one addcdiv (float divisor) == the reference's two-op expression
+    with its int64 divisor (ms_deform_attn.py:305-313): sampling pixels cannot move."""
+    from ziragroundingdino_amd import ms_deform_attn as m
+    g = torch.Generator().manual_seed(11)
+    ref = torch.rand(2, 3000, 4, 2, generator=g).cuda()
+    off = (torch.randn(2, 3000, 8, 4, 4, 2, generator=g) * 3).cuda()
+    sh = torch.tensor([[100, 167], [50, 84], [25, 42], [13, 21]], device="cuda")
+    try:
+        m.FUSED_LOCATIONS = True
+        a = m.sampling_locations_from_reference_points(ref, off, sh, 4)
+        m.FUSED_LOCATIONS = False
+        b = m.sampling_locations_from_reference_points(ref, off, sh, 4)
+    finally:
+        m.FUSED_LOCATIONS = True
+    assert torch.equal(a, b)
