@@ -488,3 +488,27 @@ def test_bi_attention_block_training_droppath_equals_reference_formula():
     want_v = nv + blk.drop_path(blk.gamma_v * dv)
     want_l = nl + blk.drop_path(blk.gamma_l * dl)
     assert torch.allclose(got_v, want_v, atol=1e-6) and torch.allclose(got_l, want_l, atol=1e-6)
+
+
+def test_small_attention_equals_sdpa():
+    """lean_mha's materialised-score path (two batched GEMMs + softmax) against torch SDPA, with an additive
+    mask, a broadcast key-padding mask and no mask, values and gradients."""
+    g = torch.Generator().manual_seed(2)
+    for B, H, L, S, d, kind in [(2, 8, 37, 37, 32, "none"), (2, 4, 11, 11, 64, "full"), (2, 8, 50, 9, 32, "kpm")]:
+        q = torch.randn(B, H, L, d, generator=g, requires_grad=True)
+        k = torch.randn(B, H, S, d, generator=g, requires_grad=True)
+        v = torch.randn(B, H, S, d, generator=g, requires_grad=True)
+        mask = None
+        if kind == "full":
+            mask = torch.zeros(B, H, L, S).masked_fill_(torch.rand(B, H, L, S, generator=g) < 0.3, float("-inf"))
+            mask[..., 0] = 0.0                                            # no fully masked row
+        elif kind == "kpm":
+            mask = torch.zeros(B, 1, 1, S); mask[1, ..., -3:] = float("-inf")
+        go = torch.randn(B, H, L, d, generator=g)
+        got = transformer._attention_small(q, k, v, mask)
+        want = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        assert torch.allclose(got, want, atol=2e-6)
+        gg = torch.autograd.grad((got * go).sum(), [q, k, v])
+        gw = torch.autograd.grad((want * go).sum(), [q, k, v])
+        for a, b in zip(gg, gw):
+            assert torch.allclose(a, b, atol=5e-6)

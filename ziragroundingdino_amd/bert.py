@@ -6,7 +6,8 @@ block-diagonal ``[bs, T, T]`` sub-sentence mask and per-phrase position ids; tha
 not run on the transformers release in this image and no pretrained weights are available
 offline, so the same computation is written out here with HF's parameter names
 (``embeddings.word_embeddings.weight``, ``encoder.layer.N.attention.self.query.weight`` ...) so a
-bert-base-uncased state dict loads unchanged.  Attention is torch SDPA (MFMA via the library).
+bert-base-uncased state dict loads unchanged.  Attention: two batched GEMMs and a softmax (captions are short;
+torch SDPA beyond transformer.SMALL_ATTENTION_SCORES).
 """
 import zlib
 from types import SimpleNamespace
@@ -14,6 +15,8 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from .transformer import SMALL_ATTENTION_SCORES, Switches, _attention_small
 
 
 class BertConfig(SimpleNamespace):
@@ -48,8 +51,11 @@ class _SelfAttention(nn.Module):
     def forward(self, x, bias):
         B, T, C = x.shape
         split = lambda t: t.view(B, T, self.h, C // self.h).transpose(1, 2)
-        o = F.scaled_dot_product_attention(split(self.query(x)), split(self.key(x)),
-                                           split(self.value(x)), attn_mask=bias)
+        q, k, v = split(self.query(x)), split(self.key(x)), split(self.value(x))
+        if Switches.small_attention and B * self.h * T * T <= SMALL_ATTENTION_SCORES:
+            o = _attention_small(q, k, v, bias)   # captions are <= 256 tokens: see transformer._attention_small
+        else:
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
         return o.transpose(1, 2).reshape(B, T, C)
 
 

@@ -13,6 +13,7 @@ The ablation-only ``use_adapter`` (Adapter / MoE) branch is not part of the ZiRa
 Every multi-scale deformable attention call (6 encoder layers with Q = S, 6 decoder layers
 with Q = 900) runs the gfx950 kernels through ``MultiScaleDeformableAttention``.
 """
+import math
 from typing import Optional
 
 import torch
@@ -88,15 +89,42 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
             kpm = torch.zeros_like(kpm, dtype=q.dtype).masked_fill_(kpm, float("-inf"))
         kpm = kpm.view(B, 1, 1, S)
         mask = kpm if mask is None else mask + kpm
-    out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask,
-                                         dropout_p=mha.dropout if mha.training else 0.0)
+    dropout_p = mha.dropout if mha.training else 0.0
+    if Switches.small_attention and B * H * L * S <= SMALL_ATTENTION_SCORES:
+        out = _attention_small(q, k, v, mask, dropout_p)
+    else:
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=dropout_p)
     out = out.permute(2, 0, 1, 3).reshape(L, B, E)
     return F.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+
+
+SMALL_ATTENTION_SCORES = 1 << 25   # score elements (B*H*L*S) up to which the scores are simply materialised
+
+
+def _attention_small(q, k, v, mask, dropout_p=0.0):
+    """softmax(q k^T / sqrt(d) + mask) v with the scores in memory: two batched GEMMs and a softmax.
+    Every attention of this model outside the backbone is small (<= 900 x 900 per head, 16 heads x
+    images), and the fused SDPA kernel of this stack runs such a problem on a handful of workgroups:
+    61-74 us forward and 130-140 us backward per call, whatever the size (18 calls per step); the three
+    plain kernels take a few microseconds each.  q, k, v: [B, H, L|S, d] (any strides)."""
+    B, H, L, d = q.shape
+    S = k.shape[2]
+    q3, k3, v3 = q.reshape(B * H, L, d), k.reshape(B * H, S, d), v.reshape(B * H, S, d)
+    scale = 1.0 / math.sqrt(d)
+    if mask is not None:
+        scores = torch.baddbmm(mask.expand(B, H, L, S).reshape(B * H, L, S), q3, k3.transpose(1, 2), alpha=scale)
+    else:
+        scores = torch.bmm(q3 * scale, k3.transpose(1, 2))
+    p = scores.softmax(-1)
+    if dropout_p > 0.0:
+        p = F.dropout(p, dropout_p)
+    return torch.bmm(p, v3).view(B, H, L, d)
 
 
 class Switches:
     """Module-level implementation switches (True = the leaner equivalent path)."""
     lean_mha = True
+    small_attention = True   # lean_mha: materialised scores instead of the fused SDPA kernel for small problems
 
 
 def _mha(mha, query, key, value, key_padding_mask=None, attn_mask=None):
