@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transformer-graph", action="store_true",
+                    help="replay encoder / decoder layers from hipGraphs (opt-in; same kernels, ~half the host time)")
     ap.add_argument("--cpu-sample-div", type=int, default=1,
                     help="cpu_baseline runs one step on an image with sides divided by this")
     args = ap.parse_args()
@@ -170,6 +172,7 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev))).to(dev).train()
+    model.use_transformer_graph = args.transformer_graph
     trainer = ZiraTrainer(model)
     data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard
 
@@ -239,7 +242,7 @@ def main():
                             "full fwd+loss+bwd+clip+AdamW" % (args.batch, args.height, args.width),
                 "images_per_gpu": args.batch,
                 "global_batch": args.batch * world,
-                "parallelism": "dp%d" % world,
+                "parallelism": "dp%d" % world, "transformer_graph": bool(args.transformer_graph),
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "msda_kernel_variant": _lib.variant_f32(32),
             },

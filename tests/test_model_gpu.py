@@ -184,3 +184,23 @@ def test_sampling_locations_one_pass_is_bit_identical():
     finally:
         m.FUSED_LOCATIONS = True
     assert torch.equal(a, b)
+
+
+def test_transformer_graph_path_matches_eager_and_survives_replays():
+    """Opt-in hipGraph replay of the encoder / decoder layers (graphs.GraphedTransformer): same losses as the
+    eager path step by step (stochastic depth off so that both see the same arithmetic), ten replays."""
+    def run(use_graph):
+        model = small_model().train()            # seeds itself; stochastic depth is off in small_model
+        model.use_transformer_graph = use_graph
+        trainer = ZiraTrainer(model)
+        data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+        losses = []
+        for _ in range(10):
+            out = trainer.run_step(data)
+            losses.append(float(sum(out.values())))
+        torch.cuda.synchronize()
+        return losses
+    eager, graphed = run(False), run(True)
+    assert all(torch.isfinite(torch.tensor(graphed)))
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (eager, graphed)

@@ -80,34 +80,51 @@ class _EncoderLayerPiece(torch.nn.Module):
     (the fusion block in front of them runs eagerly, see GraphedTransformer).  The level tables
     are constants of the piece (cached device tensors)."""
 
-    def __init__(self, encoder, layer_id, spatial_shapes, level_start_index):
+    def __init__(self, encoder, layer_id, spatial_shapes, level_start_index, no_padding=False):
         super().__init__()
-        self.encoder, self.layer_id = encoder, layer_id
+        self.encoder, self.layer_id, self.no_padding = encoder, layer_id, no_padding
         self.spatial_shapes, self.level_start_index = spatial_shapes, level_start_index
 
     def forward(self, output, memory_text, pos, reference_points, key_padding_mask,
                 text_attention_mask, pos_text, text_self_attention_masks):
         return self.encoder.forward_layer(
             self.layer_id, output, memory_text, pos, reference_points, self.spatial_shapes,
-            self.level_start_index, key_padding_mask, text_attention_mask, pos_text,
-            text_self_attention_masks, fuse=False)
+            self.level_start_index, None if self.no_padding else key_padding_mask, text_attention_mask,
+            pos_text, text_self_attention_masks, fuse=False)
 
 
 class _SelectDecodePiece(torch.nn.Module):
     """Two-stage query selection + the whole decoder with a tensor-only signature."""
 
-    def __init__(self, transformer, shapes, spatial_shapes, level_start_index):
+    def __init__(self, transformer, shapes, spatial_shapes, level_start_index, no_padding=False):
         super().__init__()
-        self.transformer, self.shapes = transformer, shapes
+        self.transformer, self.shapes, self.no_padding = transformer, shapes, no_padding
         self.spatial_shapes, self.level_start_index = spatial_shapes, level_start_index
 
     def forward(self, memory, memory_text, mask_flatten, lvl_pos, valid_ratios, text_token_mask):
         text_dict = {"encoded_text": memory_text, "text_token_mask": text_token_mask}
         hs, refs, hs_enc, ref_enc, init_box = self.transformer.select_and_decode(
             memory, mask_flatten, lvl_pos, self.shapes, self.spatial_shapes, self.level_start_index,
-            valid_ratios, text_dict)
+            valid_ratios, text_dict, no_padding=self.no_padding)
         self.n_hs, self.n_refs = len(hs), len(refs)
         return (*hs, *refs, hs_enc, ref_enc, init_box)
+
+
+class _DecoderPiece(torch.nn.Module):
+    """The decoder alone (query selection stays eager), tensor-only signature."""
+
+    def __init__(self, transformer, spatial_shapes, level_start_index, no_padding=False):
+        super().__init__()
+        self.transformer, self.no_padding = transformer, no_padding
+        self.spatial_shapes, self.level_start_index = spatial_shapes, level_start_index
+
+    def forward(self, tgt, refpoint_embed, memory, memory_text, mask_flatten, lvl_pos, valid_ratios, text_token_mask):
+        text_dict = {"encoded_text": memory_text, "text_token_mask": text_token_mask}
+        hs, refs = self.transformer.run_decoder(tgt, refpoint_embed, memory, mask_flatten, lvl_pos,
+                                                self.spatial_shapes, self.level_start_index, valid_ratios,
+                                                text_dict, no_padding=self.no_padding)
+        self.n_hs, self.n_refs = len(hs), len(refs)
+        return (*hs, *refs)
 
 
 def _graph(mod, args):
@@ -121,25 +138,31 @@ class GraphedTransformer:
     enqueue the ~1500 small kernels of the forward alone, longer than the GPU needs to run them.
 
     The transformer is cut into seven graphed pieces -- text enhancer + deformable layer of each
-    encoder layer, and query selection + decoder -- each with its own pair of graphs and memory
-    pool; the six image<->text fusion blocks between them stay eager.  (On ROCm 7.2 / torch 2.10
-    graphs that contain three or more BiAttention blocks replay once and then take a GPU memory
-    fault; stacks of the other layer types replay indefinitely.  scripts/graph_bisect*.py hold
-    the bisection.)
+    encoder layer, and the six decoder layers -- each with its own pair of graphs and memory pool;
+    the six image<->text fusion blocks between them and the two-stage query selection stay eager.
+    (On ROCm 7.2 / torch 2.10 a graph that contains the query selection -- top-k over the 22 k
+    pixel logits, gathers -- or three or more BiAttention blocks replays once and then takes a GPU
+    memory fault; the pieces used here have been replayed for tens of steps.  scripts/graph_bisect*.py
+    and scripts/try_graph.py hold the bisection.)
     One set of graphs per input signature (image size / caption length); further signatures
     run eagerly after ``max_signatures``."""
+
+    graph_encoder = True   # class-level switches: which pieces are graphed (developer bisection)
+    graph_decoder = True
+    graph_selection = False  # two-stage query selection eager (graphed, it faults on the second replay: see class doc)
 
     def __init__(self, transformer, max_signatures=2):
         self.transformer = transformer
         self.max_signatures = max_signatures
         self._cache = {}
 
-    def __call__(self, srcs, masks, poss, text_dict):
+    def __call__(self, srcs, masks, poss, text_dict, no_padding=False):
         t = self.transformer
         key = (tuple((tuple(x.shape), x.requires_grad) for x in srcs),
-               tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad)
+               tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad, bool(no_padding))
         if key not in self._cache and len(self._cache) >= self.max_signatures:
-            hs, refs, hs_enc, ref_enc, init_box, _ = t(srcs, masks, None, poss, None, None, text_dict)
+            hs, refs, hs_enc, ref_enc, init_box, _ = t(srcs, masks, None, poss, None, None, text_dict,
+                                                       no_padding=no_padding)
             return hs, refs, hs_enc, ref_enc, init_box
 
         (src, mask_flat, lvl_pos, shapes, spatial_shapes, level_start_index,
@@ -157,19 +180,31 @@ class GraphedTransformer:
         output = src
         for i in range(len(enc.layers)):
             if enc.fusion_layers:  # eager: graphed BiAttention blocks fault on replay (see class doc)
-                output, memory_text = enc.fusion_layers[i](v=output, l=memory_text, attention_mask_v=mask_flat,
+                output, memory_text = enc.fusion_layers[i](v=output, l=memory_text,
+                                                           attention_mask_v=None if no_padding else mask_flat,
                                                            attention_mask_l=text_attention_mask)
             args = (output, memory_text, lvl_pos, reference_points, mask_flat, text_attention_mask,
                     pos_text, tsm)
             if len(entry["layers"]) <= i:
-                entry["layers"].append(_graph(_EncoderLayerPiece(enc, i, spatial_shapes, level_start_index), args))
+                piece = _EncoderLayerPiece(enc, i, spatial_shapes, level_start_index, no_padding)
+                entry["layers"].append(_graph(piece, args) if self.graph_encoder else piece)
             output, memory_text = entry["layers"][i](*args)
         text_dict["encoded_text"] = memory_text
 
+        if not self.graph_selection:   # selection eager, decoder layers graphed
+            refpoint_embed, tgt, init_box, hs_enc, ref_enc = t.select_queries(output, mask_flat, shapes, text_dict)
+            args = (tgt, refpoint_embed, output, memory_text, mask_flat, lvl_pos, valid_ratios,
+                    text_dict["text_token_mask"])
+            if entry["decode"] is None:
+                piece = _DecoderPiece(t, spatial_shapes, level_start_index, no_padding)
+                entry["decode"] = (_graph(piece, args) if self.graph_decoder else piece, piece)
+            graphed, piece = entry["decode"]
+            out = graphed(*args)
+            return list(out[:piece.n_hs]), list(out[piece.n_hs:]), hs_enc, ref_enc, init_box
         args = (output, memory_text, mask_flat, lvl_pos, valid_ratios, text_dict["text_token_mask"])
         if entry["decode"] is None:
-            piece = _SelectDecodePiece(t, shapes, spatial_shapes, level_start_index)
-            entry["decode"] = (_graph(piece, args), piece)
+            piece = _SelectDecodePiece(t, shapes, spatial_shapes, level_start_index, no_padding)
+            entry["decode"] = (_graph(piece, args) if self.graph_decoder else piece, piece)
         graphed, piece = entry["decode"]
         out = graphed(*args)
         nh, nr = piece.n_hs, piece.n_refs

@@ -369,7 +369,7 @@ class GroundingDINO(nn.Module):
         if (self.use_transformer_graph and self.training and srcs[0].is_cuda
                 and self._frozen(self.transformer) and torch.is_grad_enabled()):
             hs, reference, hs_enc, ref_enc, init_box_proposal = self._graphed_transformer(
-                srcs, masks, poss, text_dict)
+                srcs, masks, poss, text_dict, no_padding=no_padding)
         else:
             hs, reference, hs_enc, ref_enc, init_box_proposal, _ = self.transformer(
                 srcs, masks, None, poss, None, None, text_dict, no_padding=no_padding)

@@ -789,10 +789,9 @@ class Transformer(nn.Module):
         return (src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
                 level_start_index, valid_ratios)
 
-    def select_and_decode(self, memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
-                          level_start_index, valid_ratios, text_dict, refpoint_embed=None, tgt=None,
-                          attn_mask=None, no_padding=False):
-        """Two-stage query selection (top-k by max token logit) + decoder (reference :301-415)."""
+    def select_queries(self, memory, mask_flatten, shapes, text_dict, refpoint_embed=None, tgt=None):
+        """Two-stage query selection: top-k pixels by max token logit (reference :301-372).
+        -> (refpoint_embed, tgt, init_box_proposal, hs_enc, ref_enc)."""
         bs = memory.shape[0]
         if self.two_stage_type == "standard":
             output_memory, output_proposals = gen_encoder_output_proposals(memory, mask_flatten, shapes)
@@ -811,22 +810,24 @@ class Transformer(nn.Module):
                 tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
             else:
                 tgt_ = tgt_undetach.detach()
-            if refpoint_embed is not None:
-                refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
-                tgt = torch.cat([tgt, tgt_], dim=1)
-            else:
-                refpoint_embed, tgt = refpoint_embed_, tgt_
+            hs_enc = tgt_undetach.unsqueeze(0)
+            ref_enc = refpoint_embed_undetach.sigmoid().unsqueeze(0)
         else:
             tgt_ = self.tgt_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
             refpoint_embed_ = self.refpoint_embed.weight[:, None, :].repeat(1, bs, 1).transpose(0, 1)
-            if refpoint_embed is not None:
-                refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
-                tgt = torch.cat([tgt, tgt_], dim=1)
-            else:
-                refpoint_embed, tgt = refpoint_embed_, tgt_
             init_box_proposal = refpoint_embed_.sigmoid()
-            topk_proposals = None
+            topk_proposals = hs_enc = ref_enc = None
+        if refpoint_embed is not None:
+            refpoint_embed = torch.cat([refpoint_embed, refpoint_embed_], dim=1)
+            tgt = torch.cat([tgt, tgt_], dim=1)
+        else:
+            refpoint_embed, tgt = refpoint_embed_, tgt_
+        self.last_topk_proposals = topk_proposals  # exposed for the bit-exact index parity tests
+        return refpoint_embed, tgt, init_box_proposal, hs_enc, ref_enc
 
+    def run_decoder(self, tgt, refpoint_embed, memory, mask_flatten, lvl_pos_embed_flatten, spatial_shapes,
+                    level_start_index, valid_ratios, text_dict, attn_mask=None, no_padding=False):
+        """The six decoder layers on the selected queries (reference :374-400) -> (hs, references)."""
         hs, references, _ = self.decoder(
             tgt=tgt.transpose(0, 1), memory=memory.transpose(0, 1),
             memory_key_padding_mask=None if no_padding else mask_flatten,
@@ -834,13 +835,17 @@ class Transformer(nn.Module):
             refpoints_unsigmoid=refpoint_embed.transpose(0, 1), level_start_index=level_start_index,
             spatial_shapes=spatial_shapes, valid_ratios=valid_ratios, tgt_mask=attn_mask,
             memory_text=text_dict["encoded_text"], text_attention_mask=~text_dict["text_token_mask"])
+        return hs, references
 
-        if self.two_stage_type == "standard":
-            hs_enc = tgt_undetach.unsqueeze(0)
-            ref_enc = refpoint_embed_undetach.sigmoid().unsqueeze(0)
-        else:
-            hs_enc = ref_enc = None
-        self.last_topk_proposals = topk_proposals  # exposed for the bit-exact index parity tests
+    def select_and_decode(self, memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
+                          level_start_index, valid_ratios, text_dict, refpoint_embed=None, tgt=None,
+                          attn_mask=None, no_padding=False):
+        """Two-stage query selection (top-k by max token logit) + decoder (reference :301-415)."""
+        refpoint_embed, tgt, init_box_proposal, hs_enc, ref_enc = self.select_queries(
+            memory, mask_flatten, shapes, text_dict, refpoint_embed, tgt)
+        hs, references = self.run_decoder(tgt, refpoint_embed, memory, mask_flatten, lvl_pos_embed_flatten,
+                                          spatial_shapes, level_start_index, valid_ratios, text_dict,
+                                          attn_mask, no_padding)
         return hs, references, hs_enc, ref_enc, init_box_proposal
 
     def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None,
