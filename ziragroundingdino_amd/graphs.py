@@ -105,7 +105,7 @@ class _SelectDecodePiece(torch.nn.Module):
         text_dict = {"encoded_text": memory_text, "text_token_mask": text_token_mask}
         hs, refs, hs_enc, ref_enc, init_box = self.transformer.select_and_decode(
             memory, mask_flatten, lvl_pos, self.shapes, self.spatial_shapes, self.level_start_index,
-            valid_ratios, text_dict, no_padding=self.no_padding)
+            valid_ratios, text_dict, no_padding=self.no_padding, sort_for_topk=True)  # topk faults on replay
         self.n_hs, self.n_refs = len(hs), len(refs)
         return (*hs, *refs, hs_enc, ref_enc, init_box)
 
@@ -138,18 +138,18 @@ class GraphedTransformer:
     enqueue the ~1500 small kernels of the forward alone, longer than the GPU needs to run them.
 
     The transformer is cut into seven graphed pieces -- text enhancer + deformable layer of each
-    encoder layer, and the six decoder layers -- each with its own pair of graphs and memory pool;
-    the six image<->text fusion blocks between them and the two-stage query selection stay eager.
-    (On ROCm 7.2 / torch 2.10 a graph that contains the query selection -- top-k over the 22 k
-    pixel logits, gathers -- or three or more BiAttention blocks replays once and then takes a GPU
-    memory fault; the pieces used here have been replayed for tens of steps.  scripts/graph_bisect*.py
-    and scripts/try_graph.py hold the bisection.)
+    encoder layer, and query selection + decoder -- each with its own pair of graphs and memory
+    pool; the six image<->text fusion blocks between them stay eager.  Two things fault on the second
+    replay on ROCm 7.2 / torch 2.10 and are avoided: ``torch.topk`` inside a graph (the graphed query
+    selection takes the first k of a stable descending sort instead: same indices unless logits tie)
+    and graphs that contain three or more BiAttention blocks.  scripts/try_graph.py and
+    scripts/graph_bisect*.py hold the bisection.
     One set of graphs per input signature (image size / caption length); further signatures
     run eagerly after ``max_signatures``."""
 
     graph_encoder = True   # class-level switches: which pieces are graphed (developer bisection)
     graph_decoder = True
-    graph_selection = False  # two-stage query selection eager (graphed, it faults on the second replay: see class doc)
+    graph_selection = True   # False: two-stage query selection runs eagerly (with torch.topk), decoder layers graphed
 
     def __init__(self, transformer, max_signatures=2):
         self.transformer = transformer

@@ -125,6 +125,7 @@ class Switches:
     """Module-level implementation switches (True = the leaner equivalent path)."""
     lean_mha = True
     small_attention = True   # lean_mha: materialised scores instead of the fused SDPA kernel for small problems
+    sort_for_topk = False    # select_queries: stable sort instead of torch.topk everywhere (developer switch)
 
 
 def _mha(mha, query, key, value, key_padding_mask=None, attn_mask=None):
@@ -789,9 +790,12 @@ class Transformer(nn.Module):
         return (src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
                 level_start_index, valid_ratios)
 
-    def select_queries(self, memory, mask_flatten, shapes, text_dict, refpoint_embed=None, tgt=None):
+    def select_queries(self, memory, mask_flatten, shapes, text_dict, refpoint_embed=None, tgt=None,
+                       sort_for_topk=False):
         """Two-stage query selection: top-k pixels by max token logit (reference :301-372).
-        -> (refpoint_embed, tgt, init_box_proposal, hs_enc, ref_enc)."""
+        -> (refpoint_embed, tgt, init_box_proposal, hs_enc, ref_enc).
+        ``sort_for_topk``: take the first k of a stable descending sort instead of torch.topk (same
+        indices unless logits tie); torch.topk inside a replayed hipGraph faults on ROCm 7.2."""
         bs = memory.shape[0]
         if self.two_stage_type == "standard":
             output_memory, output_proposals = gen_encoder_output_proposals(memory, mask_flatten, shapes)
@@ -799,7 +803,10 @@ class Transformer(nn.Module):
             enc_outputs_class_unselected = self.enc_out_class_embed(output_memory, text_dict)
             topk_logits = enc_outputs_class_unselected.max(-1)[0]
             enc_outputs_coord_unselected = self.enc_out_bbox_embed(output_memory) + output_proposals
-            topk_proposals = torch.topk(topk_logits, self.num_queries, dim=1)[1]  # bs, nq (int64)
+            if sort_for_topk or Switches.sort_for_topk:
+                topk_proposals = torch.sort(topk_logits, dim=1, descending=True, stable=True)[1][:, :self.num_queries]
+            else:
+                topk_proposals = torch.topk(topk_logits, self.num_queries, dim=1)[1]  # bs, nq (int64)
             gather4 = topk_proposals.unsqueeze(-1).repeat(1, 1, 4)
             refpoint_embed_undetach = torch.gather(enc_outputs_coord_unselected, 1, gather4)
             refpoint_embed_ = refpoint_embed_undetach.detach()
@@ -839,10 +846,10 @@ class Transformer(nn.Module):
 
     def select_and_decode(self, memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
                           level_start_index, valid_ratios, text_dict, refpoint_embed=None, tgt=None,
-                          attn_mask=None, no_padding=False):
+                          attn_mask=None, no_padding=False, sort_for_topk=False):
         """Two-stage query selection (top-k by max token logit) + decoder (reference :301-415)."""
         refpoint_embed, tgt, init_box_proposal, hs_enc, ref_enc = self.select_queries(
-            memory, mask_flatten, shapes, text_dict, refpoint_embed, tgt)
+            memory, mask_flatten, shapes, text_dict, refpoint_embed, tgt, sort_for_topk=sort_for_topk)
         hs, references = self.run_decoder(tgt, refpoint_embed, memory, mask_flatten, lvl_pos_embed_flatten,
                                           spatial_shapes, level_start_index, valid_ratios, text_dict,
                                           attn_mask, no_padding)
