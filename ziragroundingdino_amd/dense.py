@@ -12,6 +12,19 @@ import torch
 import torch.nn.functional as F
 
 
+def _scratch(cache, dev, n):
+    """n floats of kernel scratch: cached per (device, stream) in eager mode; while a stream is being
+    captured into a hipGraph the allocation is left to the graph's own pool (a cached tensor would be
+    baked into the graph and then replaced or shared behind its back)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.float32, device=dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < n:
+        ws = cache[key] = torch.empty(n, dtype=torch.float32, device=dev)
+    return ws
+
+
 def conv_columns(x, kernel, stride=1, padding=0):
     """im2col view of x for a (kh, kw) kernel: ([B, C*kh*kw, Ho*Wo], Ho, Wo); free for 1x1."""
     kh, kw = kernel
@@ -83,10 +96,7 @@ def _xty_native(X, Y, x_transposed):
     a = X.shape[1] if x_transposed else X.shape[2]
     out = torch.empty((B, a, b), dtype=torch.float32, device=X.device)
     n = lib.zira_xty_workspace_floats(B, N, a, b)
-    key = (X.device, torch.cuda.current_stream(X.device).cuda_stream)
-    ws = _XTY_WS.get(key)
-    if ws is None or ws.numel() < n:
-        ws = _XTY_WS[key] = torch.empty(n, dtype=torch.float32, device=X.device)
+    ws = _scratch(_XTY_WS, X.device, n)
     rc = lib.zira_xty_f32(X.data_ptr(), Y.data_ptr(), B, N, a, b, int(bool(x_transposed)), out.data_ptr(),
                           ws.data_ptr(), torch.cuda.current_stream(X.device).cuda_stream)
     if rc != 0:
@@ -187,11 +197,7 @@ _BIS_WS = {}
 
 def _bis_workspace(lib, dev, B, N, H, T):
     n = lib.zira_bisoftmax_workspace_floats(B, N, H, T)
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _BIS_WS.get(key)
-    if ws is None or ws.numel() < n:
-        ws = _BIS_WS[key] = torch.empty(n, dtype=torch.float32, device=dev)
-    return ws
+    return _scratch(_BIS_WS, dev, n)
 
 
 def bi_softmax_supported(xm, H, T, dropout_active):

@@ -110,6 +110,17 @@ class _SelectDecodePiece(torch.nn.Module):
         return (*hs, *refs, hs_enc, ref_enc, init_box)
 
 
+class _FusionPiece(torch.nn.Module):
+    """One image<->text fusion block (BiAttentionBlock) with a tensor-only signature."""
+
+    def __init__(self, block, no_padding=False):
+        super().__init__()
+        self.block, self.no_padding = block, no_padding
+
+    def forward(self, v, l, mask_v, mask_l):
+        return self.block(v=v, l=l, attention_mask_v=None if self.no_padding else mask_v, attention_mask_l=mask_l)
+
+
 class _DecoderPiece(torch.nn.Module):
     """The decoder alone (query selection stays eager), tensor-only signature."""
 
@@ -149,6 +160,7 @@ class GraphedTransformer:
 
     graph_encoder = True   # class-level switches: which pieces are graphed (developer bisection)
     graph_decoder = True
+    graph_fusion = False     # True: each fusion block replays from its own graph pair as well (300-step soak passes; no faster: the step is GPU-bound by then)
     graph_selection = True   # False: two-stage query selection runs eagerly (with torch.topk), decoder layers graphed
 
     def __init__(self, transformer, max_signatures=2):
@@ -176,10 +188,15 @@ class GraphedTransformer:
 
         entry = self._cache.get(key)
         if entry is None:
-            entry = self._cache[key] = {"layers": [], "decode": None}
+            entry = self._cache[key] = {"layers": [], "fusion": [], "decode": None}
         output = src
         for i in range(len(enc.layers)):
-            if enc.fusion_layers:  # eager: graphed BiAttention blocks fault on replay (see class doc)
+            if enc.fusion_layers and self.graph_fusion:   # one graph pair per block (developer switch)
+                fargs = (output, memory_text, mask_flat, text_attention_mask)
+                if len(entry["fusion"]) <= i:
+                    entry["fusion"].append(_graph(_FusionPiece(enc.fusion_layers[i], no_padding), fargs))
+                output, memory_text = entry["fusion"][i](*fargs)
+            elif enc.fusion_layers:  # eager: graphs with several BiAttention blocks fault on replay (see class doc)
                 output, memory_text = enc.fusion_layers[i](v=output, l=memory_text,
                                                            attention_mask_v=None if no_padding else mask_flat,
                                                            attention_mask_l=text_attention_mask)
