@@ -999,7 +999,9 @@ __device__ __forceinline__ void rowsum_slices(const uint2 *sorted, unsigned n,
     // the wasted loads (48.8 vs 50.3 us).  (Its fold does wait with vmcnt(0), i.e. for the batch
     // issued just before it as well; a branch-free ping/pong with exact vmcnt(U..) waits was
     // measured again later: 46.4 -> 45.9 us with uniform locations, but 78 -> 81.5 us on the
-    // model's clustered ones -- the helper launch is bound by its atomics, not by this chain.)
+    // model's clustered ones.  Dropping the helper launch's walk-time atomics altogether (wrong results)
+    // only takes the model-shaped backward from 83 to 73 us, and parking finished rows in LDS to issue
+    // their atomics four rows at a time made it slower (82.7 -> 88.5 us).)
     auto issue = [&](Batch &t, unsigned i) {
 #pragma unroll
         for (unsigned u = 0; u < U; ++u) {
