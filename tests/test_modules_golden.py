@@ -512,3 +512,24 @@ def test_small_attention_equals_sdpa():
         gw = torch.autograd.grad((want * go).sum(), [q, k, v])
         for a, b in zip(gg, gw):
             assert torch.allclose(a, b, atol=5e-6)
+
+
+def test_sampling_locations_addcdiv_is_bit_identical_on_cpu():
+    """One-pass ref + offsets / (W, H) (float divisor) against the reference's expression with its int64
+    divisor (ms_deform_attn.py:305-313), values bit for bit and gradients to one rounding."""
+    from ziragroundingdino_amd import ms_deform_attn as m
+    g = torch.Generator().manual_seed(4)
+    ref = torch.rand(2, 60, 4, 2, generator=g)
+    off = (torch.randn(2, 60, 8, 4, 4, 2, generator=g) * 3).requires_grad_(True)
+    sh = torch.tensor([[100, 167], [50, 84], [25, 42], [13, 21]])
+    outs, grads = [], []
+    try:
+        for fused in (True, False):
+            m.FUSED_LOCATIONS = fused
+            loc = m.sampling_locations_from_reference_points(ref, off, sh, 4)
+            outs.append(loc.detach())
+            grads.append(torch.autograd.grad(loc.square().sum(), [off])[0])
+    finally:
+        m.FUSED_LOCATIONS = True
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(grads[0], grads[1], rtol=1e-6, atol=1e-8)
