@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage: scripts/build_variant.sh <name> [-DZIRA_...=v ...]  -> build_ab/<name>.so (developer A/B builds; run here, they travel with gpurun)
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $root/build_ab
+src=$root/ziragroundingdino_amd/csrc
+hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -munsafe-fp-atomics -I$root/include "$@" \
+  $src/msda.hip $src/msda_cells.hip $src/rsb.hip $src/xty.hip $src/bisoftmax.hip $src/layernorm.hip -o $root/build_ab/$name.so

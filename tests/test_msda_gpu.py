@@ -268,7 +268,9 @@ def test_tiled_and_atomic_backward_agree(oracle):
         for a, b, w, name in zip(tiled, atomic, want, ("grad_value", "grad_loc", "grad_attn")):
             _close(a, w, 2e-5, "tiled " + name)
             _close(b, w, 2e-5, "atomic " + name)
-        assert torch.equal(tiled[1], atomic[1]) and torch.equal(tiled[2], atomic[2])
+        # the two paths fold the D channels in different lane orders: equal up to rounding
+        torch.testing.assert_close(tiled[1], atomic[1], rtol=1e-4, atol=1e-5 * float(atomic[1].abs().max()))
+        torch.testing.assert_close(tiled[2], atomic[2], rtol=1e-4, atol=1e-5 * float(atomic[2].abs().max()))
 
 
 def test_tiled_backward_overwrites_poisoned_grad_value():

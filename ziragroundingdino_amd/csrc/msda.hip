@@ -27,6 +27,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+#include <string.h>
+
+#include "msda_internal.h"
 #include "zira_msda.h"
 
 #ifndef ZIRA_K1_GATHERS
@@ -2053,10 +2057,28 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
     return ZIRA_MSDA_EINVAL;
 }
 
+// Which sorted backward serves a call: the cell walk (csrc/msda_cells.hip) for dense calls (encoder
+// self-attention: every pixel is a query), the round-1 entry sort for sparse ones (decoder
+// cross-attention).  Developer switch for A/B runs: ZIRA_MSDA_BWD=cells | tiled forces one of them.
+static bool use_cells_path(int B, int M, int Q)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ZIRA_MSDA_BWD");
+        v = !e ? 2 : (strcmp(e, "tiled") == 0 ? 0 : (strcmp(e, "cells") == 0 ? 1 : 2));
+    }
+    if (v != 2) return v == 1;
+    return (unsigned long long)B * M * Q >= 16 * 4096;
+}
+
 size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P)
 {
     TilePlan p;
     if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0) return 0;
+    if (use_cells_path(B, M, Q)) {
+        const size_t n = zira::cells_workspace_bytes(B, S, M, D, L, Q, P);
+        if (n) return n;
+    }
     if (!make_tile_plan(B, S, M, D, L, Q, P, p)) return 0;
     return tile_workspace_bytes(p, B, M);
 }
@@ -2069,6 +2091,12 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
     if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv ||
         !gl || !ga)
         return ZIRA_MSDA_EINVAL;
+    if (workspace && use_cells_path(B, M, Q) && !((uintptr_t)workspace & 15)) {
+        const size_t need = zira::cells_workspace_bytes(B, S, M, D, L, Q, P);
+        if (need && workspace_bytes >= need)
+            return zira::cells_backward_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
+                                            gv, gl, ga, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     TilePlan p;
     if (!workspace || !make_tile_plan(B, S, M, D, L, Q, P, p) ||
         workspace_bytes < tile_workspace_bytes(p, B, M) || ((uintptr_t)workspace & 15))

@@ -1,0 +1,22 @@
+// msda_internal.h -- links the translation units of libzira_msda.so (not part of the C ABI).
+#ifndef ZIRA_MSDA_INTERNAL_H_
+#define ZIRA_MSDA_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zira {
+
+// "Cell walk" backward (csrc/msda_cells.hip): bin kernel + walk kernel, caller-provided workspace.
+// cells_workspace_bytes() returns 0 when the path does not apply to these dimensions.
+size_t cells_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P);
+
+int cells_backward_f32(const float *grad_out, const float *value, const int64_t *shapes,
+                       const int64_t *start, const float *loc, const float *attn, int B, int S,
+                       int M, int D, int L, int Q, int P, float *grad_value, float *grad_loc,
+                       float *grad_attn, void *workspace, size_t workspace_bytes, hipStream_t st);
+
+}  // namespace zira
+
+#endif
