@@ -20,6 +20,8 @@ elif shape == "clustered":
     g = torch.Generator().manual_seed(1)
     centre = torch.rand(B, Q, 1, 1, 1, 2, generator=g) * 0.8 + 0.1
     loc = (centre + 0.05 * torch.randn(B, Q, M, 4, P, 2, generator=g)).to(dev)
+if shape.startswith("inmodel_"):  # captured from a model step by scripts/inmodel_msda.py (ZIRA_SAVE_INPUTS)
+    v, sh, st, loc, attn, go = [t.to(dev) for t in torch.load(os.environ.get("ZIRA_INPUTS", "/tmp/inmodel.pt"))[shape[8:]]]
 for _ in range(3):
     _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
 torch.cuda.synchronize()

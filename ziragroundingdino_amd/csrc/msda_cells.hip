@@ -533,27 +533,43 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
 
         // ---- the tile's runs: one (possibly empty) per bin block of the head -------------------
         unsigned n = 0, nruns = 0;
-        for (unsigned c0 = 0; c0 < G.nblk; c0 += 64) {
-            const unsigned i = c0 + lane;
-            const unsigned d = i < G.nblk ? desc[((size_t)head * NT + it.tile) * G.nblk + i] : 0u;
-            const unsigned cn = d & 0xffffu;
-            const unsigned incl = wave_incl_scan(cn, lane);
-            const unsigned long long mask = __ballot(cn != 0);
-            const unsigned slot = nruns + __popcll(mask & ((1ull << lane) - 1));
-            if (cn) {
-                runpre[slot] = n + incl - cn;
-                runoff[slot] = i * G.slice + (d >> 16);
+        const unsigned *drow = desc + ((size_t)head * NT + it.tile) * G.nblk;
+        for (unsigned c0 = 0; c0 < G.nblk; c0 += 64 * 8) {
+            unsigned d[8];
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) {  // (all descriptor loads of the chunk in flight together)
+                const unsigned i = c0 + 64 * k + lane;
+                d[k] = i < G.nblk ? drow[i] : 0u;
             }
-            n += __shfl(incl, 63);
-            nruns += __popcll(mask);
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) {
+                if (c0 + 64 * k < G.nblk) {  // wave-uniform
+                    const unsigned i = c0 + 64 * k + lane;
+                    const unsigned cn = d[k] & 0xffffu;
+                    const unsigned incl = wave_incl_scan(cn, lane);
+                    const unsigned long long mask = __ballot(cn != 0);
+                    const unsigned slot = nruns + __popcll(mask & ((1ull << lane) - 1));
+                    if (cn) {
+                        runpre[slot] = n + incl - cn;
+                        runoff[slot] = i * G.slice + (d[k] >> 16);
+                    }
+                    n += __shfl(incl, 63);
+                    nruns += __popcll(mask);
+                }
+            }
         }
         if (lane == 0) runpre[nruns] = n;
         ZIRA_WAVE_SYNC();
         WCLOCK(vt, 2);
         WSTAMP(vt, 8, ((unsigned long long)n << 32) | (it.l << 16) | (Lv.K << 8) | Lv.twl);
-        // this work item's share of the tile's records
-        const unsigned e_lo = (unsigned)(((unsigned long long)n * it.k) / Lv.K);
-        const unsigned e_hi = (unsigned)(((unsigned long long)n * (it.k + 1)) / Lv.K);
+        // This work item's share of the tile's records: every K-th one, and when they do not fit one pass,
+        // every (K * NP)-th one per pass.  Interleaved on purpose: consecutive records come from consecutive
+        // queries, i.e. from one spatial band, and would all land in one or two walkers of the tile.
+        const unsigned n_mine = n > it.k ? (n - it.k + Lv.K - 1) / Lv.K : 0u;
+        const unsigned RC = G.cap / 3;  // (the records' words wait behind the stream buffer, see below)
+        unsigned NP = (n_mine + RC - 1) / RC;
+        if (NP < 1) NP = 1;
+        const unsigned stride = Lv.K * NP;
 
         // walker state that does not depend on the pass.  Addresses are a wave-uniform base plus a 32-bit
         // element offset (one head's slice of value / grad_out is far below 2^32 bytes)
@@ -587,12 +603,16 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
         float *gl_h = grad_loc + 2 * (((size_t)b * G.Q * G.M + m) * G.LP + (size_t)it.l * G.P);
         const unsigned mlp = G.M * G.LP;
 
-        // Records per pass.  The records' (run, index, walker, step) words wait at the end of the stream
-        // buffer while the stream is laid out at its start; nb is halved below when the two do not fit.
-        unsigned RC = G.cap / 3;
-        for (unsigned r_lo = e_lo; r_lo == e_lo || r_lo < e_hi;) {
-            unsigned nb = e_hi - r_lo < RC ? e_hi - r_lo : RC;
-            const bool rmw = r_lo != e_lo;
+        // Passes.  The records' (run, index, walker, step) words wait at the end of the stream buffer while
+        // the stream is laid out at its start; a pass whose padded stream does not fit takes its records in
+        // several chunks (nb halved until it fits).
+        bool rmw = false;
+        for (unsigned pass = 0; pass < NP; ++pass) {
+          const unsigned first = it.k + Lv.K * pass;                     // record index of the pass's first record
+          const unsigned npass = n > first ? (n - first + stride - 1) / stride : 0u;
+          for (unsigned r_lo = 0; r_lo == 0 || r_lo < npass;) {
+            if (r_lo == 0 && pass > 0 && npass == 0) break;              // (nothing left for this pass)
+            unsigned nb = npass - r_lo < RC ? npass - r_lo : RC;
             unsigned Ltot;
             for (;;) {
                 for (unsigned i = lane; i < NB; i += 64) cnt[i] = 0;
@@ -606,7 +626,7 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                         const unsigned i = i0 + 64 * k;
                         w0[k] = 0; tg[k] = 0;
                         if (i < nb) {
-                            const unsigned e = r_lo + i;
+                            const unsigned e = first + (r_lo + i) * stride;
                             while (e >= runpre[rp + 1]) ++rp;
                             const unsigned idx = e - runpre[rp];
                             tg[k] = rp | (idx << 10);
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                 Ltot = __shfl(incl, 63);
                 ZIRA_WAVE_SYNC();
                 if (Ltot * NG + nb <= G.cap || nb <= 1) break;
-                nb >>= 1;  // (unbalanced tile) take fewer records in this pass
+                nb >>= 1;  // (unbalanced tile) take fewer records in this chunk
             }
             for (unsigned i = lane; i < Ltot * NG; i += 64) vis[i] = kIdleWord;
             for (unsigned i = lane; i < NB; i += 64) cnt[i] = 0;  // now the rank counters
@@ -818,10 +838,12 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
             // the steps that are left (they are empty or done), then the last pixel
             for (unsigned c = cur + 1; c <= tw + 1; ++c) transition(c);
             if (!rmw) WCLOCK(vt, 6);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a later pass re-reads what this one stored
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a later chunk re-reads what this one stored
             ZIRA_WAVE_SYNC();
+            rmw = true;
             r_lo += nb > 0 ? nb : 1;
             if (nb == 0) break;
+          }
         }
         WCLOCK(vt, 7);
     }
