@@ -1557,419 +1557,6 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
 }
 
 // ------------------------------------------------------------------------------------------
-// Sparse backward in ONE kernel ("slab scan"; decoder cross-attention: a few hundred queries).
-//
-// With Q*P samples per (head, level) in the thousands, routing contributions to the grad_value
-// rows does not need a sort kernel, a workspace or run descriptors: a block OWNS a slab -- the
-// t-th of T equal pixel ranges of one level of one head -- and simply scans all Q*P samples of its
-// (head, level), keeping the corners that fall into the slab.  Every level receives the same number
-// of samples, so slabs are balanced by samples whatever the level sizes.
-//   pass A  scan: entries per slab row (LDS histogram); the samples whose home pixel (the clamped
-//           top-left corner) lies in the slab get their grad_sampling_loc / grad_attn_weight here:
-//           a lane group gathers the four corner rows and the grad_out row and forms the dots
-//   prefix  rows -> entry offsets; rows are cut into batches of <= cap entries (normally one)
-//   pass B  scan again: entries {q << 12 | row, weight} go straight to their row-sorted place
-//   sums    the row sums of the sorted entries with rowsum_slices / rowsum_fold (registers, every row
-//           stored once, empty rows as zeros) -- the reducer of msda_bwd_tiles
-// A single row with more than cap entries (queries piled on one pixel) is summed in chunks that
-// read-modify-write it.  No atomics on global memory, no zero-fill pass, no scratch memory.
-// ------------------------------------------------------------------------------------------
-#ifndef ZIRA_SLAB_STAMPS
-#define ZIRA_SLAB_STAMPS 0   // 1: developer build with per-phase stamps (scripts/slab_stamps.py)
-#endif
-#if ZIRA_SLAB_STAMPS
-__device__ unsigned long long zira_slab_stamps[8 * 4096];
-#define SSTAMP(i)                                                                                     \
-    do {                                                                                              \
-        if (threadIdx.x == 0 && vb < 4096) zira_slab_stamps[vb * 8 + (i)] = wall_clock64();             \
-    } while (0)
-#else
-#define SSTAMP(i)
-#endif
-constexpr unsigned kSlabThreads = 256;
-constexpr unsigned kSlabHomeCap = 400;  // home samples (5 words each) collected before a block-wide dots round (>= 256 more fit)
-constexpr unsigned kSlabCandCap = 2048; // candidate samples of a slab kept in LDS (more: every pass scans all samples)
-#ifndef ZIRA_SLAB_CAP
-#define ZIRA_SLAB_CAP 1024              // entries sorted at a time (LDS)
-#endif
-#ifndef ZIRA_SLAB_MINWAVES
-#define ZIRA_SLAB_MINWAVES 4            // resident blocks per CU the register allocation must allow
-#endif
-#ifndef ZIRA_SLAB_U
-#define ZIRA_SLAB_U 8                   // grad_out rows in flight per lane in the row sums
-#endif
-#ifndef ZIRA_SLAB_BLOCKS
-#define ZIRA_SLAB_BLOCKS 1280           // slabs aimed at (5 resident blocks per CU: one round)
-#endif
-
-struct SlabSample {
-    bool valid;
-    int y0, x0;
-    float lw, lh, a;
-};
-__device__ __forceinline__ SlabSample slab_sample(const float *__restrict__ loc, const float *__restrict__ attn,
-                                                  size_t si, int H, int W)
-{
-#pragma clang fp contract(off)
-    SlabSample s;
-    const float2 xy = *reinterpret_cast<const float2 *>(loc + 2 * si);
-    s.a = attn[si];
-    const float Hf = (float)H, Wf = (float)W;
-    const float h_im = xy.y * Hf - 0.5f, w_im = xy.x * Wf - 0.5f;
-    s.valid = h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    s.lh = h_im - hf;
-    s.lw = w_im - wf;
-    s.y0 = s.valid ? (int)hf : 0;
-    s.x0 = s.valid ? (int)wf : 0;
-    return s;
-}
-
-template <int D>
-__global__ __launch_bounds__(kSlabThreads, ZIRA_SLAB_MINWAVES) void msda_bwd_slab(
-    const float *__restrict__ grad_out, const float *__restrict__ value,
-    const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-    const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv, unsigned Q,
-    FastDiv Pdiv, unsigned L, unsigned nvirt, unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, unsigned R,
-    unsigned cap, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn)
-{
-    constexpr unsigned NSLOT = 256 / D, NW = kSlabThreads / 64, U = ZIRA_SLAB_U, CQ = D / 4;
-    constexpr unsigned NGRP = kSlabThreads / CQ;  // lane groups of the home-dots rounds
-    extern __shared__ unsigned lds_slab[];
-    unsigned *rowcnt = lds_slab;                 // [R]     entries per row, later rank counters
-    unsigned *rowbase = rowcnt + R;              // [R + 1] exclusive prefix
-    unsigned *scratch = rowbase + R + 1;         // [16]    scan scratch (8), counters
-    uint2 *sorted = reinterpret_cast<uint2 *>(scratch + 16 + ((2 * R + 1 + 16) & 1));  // [cap] row-sorted entries
-    unsigned *part = reinterpret_cast<unsigned *>(sorted + cap);  // [NW * kRowsumPartWords]
-    unsigned *homes = reinterpret_cast<unsigned *>(sorted);       // [kSlabHomeCap][5] samples waiting for their dots:
-                                                                  // id, y0 << 16 | x0, lw, lh, attn (before anything
-                                                                  // is sorted: same memory)
-    unsigned *cand = part;                                        // [kSlabCandCap] candidate sample ids (until the
-                                                                  // first row sums use `part`)
-
-    unsigned vb;
-    if (!xcd_chunk_block(nvirt, per_xcd, vb)) return;
-    SSTAMP(0);
-    const unsigned M = Mdiv.d, P = Pdiv.d, T = Tdiv.d, LP = L * P;
-    const unsigned g = fast_div(vb, NTdiv), tile = vb - g * NTdiv.d;
-    const unsigned l = fast_div(tile, Tdiv), t = tile - l * T;
-    const unsigned b = fast_div(g, Mdiv), m = g - b * M;
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    const unsigned hw = (unsigned)H * (unsigned)W;
-    const unsigned st = (unsigned)start[l];
-    const unsigned span = tile_span(hw, Tdiv);
-    const unsigned p0 = t * span;
-    if (p0 >= hw) return;  // block-uniform: slab past the end of a small level
-    const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
-
-    const unsigned tid = threadIdx.x;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const unsigned slot = lane % NSLOT, cq = lane / NSLOT;
-    const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
-    float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
-    const size_t row_stride = (size_t)M * D;
-    const unsigned nsamp = Q * P;
-    const size_t si0 = ((size_t)b * Q * M + m) * LP + (size_t)l * P;  // + q * M * LP + p
-
-    // corners of a sample that fall into rows [ra, rb) of the slab: fn(row, weight)
-    auto for_corners = [&](const SlabSample &sm, unsigned ra, unsigned rb, auto fn) {
-        const float hh = 1.f - sm.lh, hwt = 1.f - sm.lw;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int dy = c >> 1, dx = c & 1;
-            const int y = sm.y0 + dy, x = sm.x0 + dx;
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-                const unsigned pix = (unsigned)y * (unsigned)W + (unsigned)x;
-                if (pix >= p0 + ra && pix < p0 + rb) fn(pix - p0, ((dy ? sm.lh : hh) * (dx ? sm.lw : hwt)) * sm.a);
-            }
-        }
-    };
-    auto sample_index = [&](unsigned i) {  // sample i of this (head, level) -> flat index into loc / attn
-        const unsigned q = fast_div(i, Pdiv);
-        return si0 + (size_t)q * M * LP + (i - q * P);
-    };
-    // grad_sampling_loc / grad_attn_weight of the collected home samples: a group of CQ lanes per sample,
-    // HB samples per round with all their row loads issued before the first use
-    auto push_home = [&](const SlabSample &sm, unsigned i) {
-        const unsigned at = atomicAdd(&scratch[8], 1u);
-        if (at < kSlabHomeCap) {
-            unsigned *h = homes + at * 5;
-            h[0] = i;
-            h[1] = ((unsigned)sm.y0 << 16) | ((unsigned)sm.x0 & 0xffffu);
-            h[2] = __float_as_uint(sm.lw);
-            h[3] = __float_as_uint(sm.lh);
-            h[4] = __float_as_uint(sm.a);
-        }
-    };
-    auto home_round = [&](unsigned nh) {
-        constexpr unsigned HB = 3;
-        const unsigned grp = tid / CQ, j = tid % CQ;
-        const float *vb0 = value + (((size_t)b * S + st) * M + m) * D + j * 4;
-        const float *gb0 = grad_out + ((size_t)b * Q * M + m) * D + j * 4;
-        for (unsigned i0 = grp; i0 < nh; i0 += HB * NGRP) {
-            unsigned id[HB];
-            int y0[HB], x0[HB];
-            float lw[HB], lh[HB], at[HB];
-            bool ok[HB];
-            float4 g4[HB], v[HB][4];
-            bool in[HB][4];
-#pragma unroll
-            for (unsigned u = 0; u < HB; ++u) {
-                ok[u] = i0 + u * NGRP < nh;
-                const unsigned *h = homes + (ok[u] ? i0 + u * NGRP : i0) * 5;
-                id[u] = h[0];
-                y0[u] = (int)h[1] >> 16;
-                x0[u] = (int)(short)(h[1] & 0xffffu);
-                lw[u] = __uint_as_float(h[2]); lh[u] = __uint_as_float(h[3]); at[u] = __uint_as_float(h[4]);
-                const unsigned q = fast_div(id[u], Pdiv);
-                g4[u] = *reinterpret_cast<const float4 *>(gb0 + (size_t)q * row_stride);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {  // unconditional loads from clamped pixels, zeroed when outside
-                    const int y = y0[u] + (c >> 1), x = x0[u] + (c & 1);
-                    in[u][c] = y >= 0 && y < H && x >= 0 && x < W;
-                    const unsigned yc = (unsigned)(y < 0 ? 0 : (y > H - 1 ? H - 1 : y));
-                    const unsigned xc = (unsigned)(x < 0 ? 0 : (x > W - 1 ? W - 1 : x));
-                    v[u][c] = *reinterpret_cast<const float4 *>(vb0 + (size_t)(yc * (unsigned)W + xc) * row_stride);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (unsigned u = 0; u < HB; ++u) {
-                float d[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float dd = v[u][c].x * g4[u].x;
-                    dd = fmaf(v[u][c].y, g4[u].y, dd);
-                    dd = fmaf(v[u][c].z, g4[u].z, dd);
-                    dd = fmaf(v[u][c].w, g4[u].w, dd);
-                    d[c] = in[u][c] ? dd : 0.f;
-                }
-                const float hh = 1.f - lh[u], hwt = 1.f - lw[u];
-                float ga = (hh * hwt) * d[0] + (hh * lw[u]) * d[1] + (lh[u] * hwt) * d[2] + (lh[u] * lw[u]) * d[3];
-                float gx = hh * (d[1] - d[0]) + lh[u] * (d[3] - d[2]);
-                float gy = hwt * (d[2] - d[0]) + lw[u] * (d[3] - d[1]);
-                ga = sum_over_row_lanes<CQ>(ga);
-                gx = sum_over_row_lanes<CQ>(gx);
-                gy = sum_over_row_lanes<CQ>(gy);
-                if (j == 0 && ok[u]) {
-                    const size_t si = sample_index(id[u]);
-                    grad_attn[si] = ga;
-                    *reinterpret_cast<float2 *>(grad_loc + 2 * si) = make_float2((float)W * at[u] * gx, (float)H * at[u] * gy);
-                }
-            }
-        }
-    };
-    // home pixel of a valid sample (its clamped top-left corner) inside this slab?
-    auto is_home = [&](const SlabSample &sm) {
-        const unsigned yh = (unsigned)(sm.y0 < 0 ? 0 : sm.y0), xh = (unsigned)(sm.x0 < 0 ? 0 : sm.x0);
-        const unsigned hp = yh * (unsigned)W + xh;  // (y0 <= H-1, x0 <= W-1 for a valid sample)
-        return hp >= p0 && hp < p0 + rows;
-    };
-
-    const unsigned nrounds = (nsamp + kSlabThreads - 1) / kSlabThreads;
-    auto sample_at = [&](unsigned rd) {  // the thread's sample of round rd
-        const unsigned i = rd * kSlabThreads + tid;
-        SlabSample sm = slab_sample(loc, attn, sample_index(i < nsamp ? i : 0u), H, W);
-        if (i >= nsamp) { sm.valid = false; sm.y0 = -100000; }  // (not a sample at all)
-        return sm;
-    };
-    // both passes walk the level's samples four rounds at a time: eight loads in flight per thread
-    auto for_samples = [&](auto fn) {
-        for (unsigned rd0 = 0; rd0 < nrounds; rd0 += 4) {
-            SlabSample sm[4];
-#pragma unroll
-            for (unsigned u = 0; u < 4; ++u) sm[u] = sample_at(rd0 + u);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (unsigned u = 0; u < 4; ++u) fn(sm[u], (rd0 + u) * kSlabThreads + tid);
-        }
-    };
-
-    // ---- candidates: the samples whose 2 x 2 footprint can touch the slab (one cheap test per sample; the
-    //      other T - 1 slabs of the level scan the same samples) ------------------------------------
-    for (unsigned i = tid; i < rows; i += kSlabThreads) rowcnt[i] = 0;
-    if (tid == 0) { scratch[8] = 0; scratch[10] = 0; }
-    __syncthreads();
-    for (unsigned rd0 = 0; rd0 < nrounds; rd0 += 16) {
-        float2 xy[16];
-#pragma unroll
-        for (unsigned u = 0; u < 16; ++u) {  // all of them in flight before the first test
-            const unsigned i = (rd0 + u) * kSlabThreads + tid;
-            xy[u] = *reinterpret_cast<const float2 *>(loc + 2 * sample_index(i < nsamp ? i : 0u));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (unsigned u = 0; u < 16; ++u) {
-#pragma clang fp contract(off)
-            const unsigned i = (rd0 + u) * kSlabThreads + tid;
-            if (i < nsamp) {
-                const float Hf = (float)H, Wf = (float)W;
-                const float h_im = xy[u].y * Hf - 0.5f, w_im = xy[u].x * Wf - 0.5f;
-                if (h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf) {
-                    const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
-                    const int lo = y0 * W + x0, hi = (y0 + 1) * W + x0 + 1;  // first / last pixel index of the footprint
-                    if (hi >= (int)p0 && lo < (int)(p0 + rows)) {
-                        const unsigned at = atomicAdd(&scratch[10], 1u);
-                        if (at < kSlabCandCap) cand[at] = i;
-                    }
-                } else if (t == 0) {  // contributes nothing anywhere (cuh:288): zero gradients, written by the
-                    const size_t si = sample_index(i);  // level's first slab
-                    grad_attn[si] = 0.f;
-                    *reinterpret_cast<float2 *>(grad_loc + 2 * si) = make_float2(0.f, 0.f);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned ncand = scratch[10];
-    bool listed = ncand <= kSlabCandCap;  // block-uniform; cleared once `part` is used for row sums
-    // both passes visit the candidates (two per thread and step), or every sample when the list overflowed
-    auto for_cands = [&](auto fn) {
-        if (listed) {
-            for (unsigned c0 = tid; c0 < ncand; c0 += 2 * kSlabThreads) {
-                SlabSample sm[2];
-                unsigned id[2];
-#pragma unroll
-                for (unsigned u = 0; u < 2; ++u) {
-                    const unsigned c = c0 + u * kSlabThreads;
-                    id[u] = cand[c < ncand ? c : c0];
-                    sm[u] = slab_sample(loc, attn, sample_index(id[u]), H, W);
-                    if (c >= ncand) { sm[u].valid = false; sm[u].y0 = -100000; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (unsigned u = 0; u < 2; ++u) fn(sm[u], id[u]);
-            }
-        } else {
-            for_samples(fn);
-        }
-    };
-
-    // ---- pass A: entries per row, home samples ----------------------------------------------
-    auto pass_a = [&](const SlabSample &sm, unsigned i) {
-        if (sm.valid) {
-            for_corners(sm, 0, rows, [&](unsigned row, float) { atomicAdd(&rowcnt[row], 1u); });
-            if (is_home(sm)) push_home(sm, i);
-        }
-    };
-    for_cands(pass_a);
-    __syncthreads();
-    SSTAMP(1);
-    {
-        const unsigned nh = scratch[8];
-#if ZIRA_SLAB_STAMPS
-        if (tid == 0 && vb < 4096) zira_slab_stamps[vb * 8 + 7] = ((unsigned long long)nh << 32) | l;
-#endif
-        if (nh <= kSlabHomeCap) {  // (block-uniform) the usual case: one round of dots
-            home_round(nh);
-        } else {                   // more home samples than the list holds: round by round
-            __syncthreads();
-            if (tid == 0) scratch[8] = 0;
-            __syncthreads();
-            for (unsigned rd = 0; rd < nrounds; ++rd) {
-                const SlabSample sm = sample_at(rd);
-                if (sm.valid && is_home(sm)) push_home(sm, rd * kSlabThreads + tid);
-                __syncthreads();
-                const unsigned n2 = scratch[8];
-                if (n2 + kSlabThreads > kSlabHomeCap || rd + 1 == nrounds) {  // block-uniform
-                    home_round(n2);
-                    __syncthreads();
-                    if (tid == 0) scratch[8] = 0;
-                    __syncthreads();
-                }
-            }
-        }
-    }
-    SSTAMP(2);
-    {   // exclusive prefix over the rows: each thread owns `rpt` consecutive rows
-        const unsigned rpt = (rows + kSlabThreads - 1) / kSlabThreads;
-        const unsigned r_a = tid * rpt;
-        const unsigned r_b = (r_a + rpt < rows) ? r_a + rpt : rows;
-        unsigned c = 0;
-        for (unsigned r = r_a; r < r_b; ++r) c += rowcnt[r];
-        unsigned tot;
-        unsigned ex = block_exclusive_scan(c, scratch, tot);
-        for (unsigned r = r_a; r < r_b; ++r) {
-            rowbase[r] = ex;
-            ex += rowcnt[r];
-        }
-        if (tid == 0) rowbase[rows] = tot;
-    }
-    __syncthreads();
-    SSTAMP(3);
-
-    // ---- batches of rows with <= cap entries -------------------------------------------------
-    for (unsigned ra = 0; ra < rows;) {
-        const unsigned base = rowbase[ra];
-        unsigned lo = ra, hi = rows;  // largest rb with rowbase[rb] - base <= cap (every thread: same LDS values)
-        while (lo < hi) {
-            const unsigned mid = (lo + hi + 1) >> 1;
-            if (rowbase[mid] - base <= cap) lo = mid; else hi = mid - 1;
-        }
-        const unsigned rb = lo;
-        if (rb > ra) {
-            const unsigned nb = rowbase[rb] - base;
-            for (unsigned r = ra + tid; r < rb; r += kSlabThreads) rowcnt[r] = 0;  // now the rank counters
-            __syncthreads();
-            for (unsigned r = ra + slot + NSLOT * wave; r < rb; r += NSLOT * NW)
-                if (rowbase[r + 1] == rowbase[r])  // rows nobody contributes to are stored as zeros
-                    *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nb) {  // block-uniform
-                auto pass_b = [&](const SlabSample &sm, unsigned i) {
-                    if (sm.valid) {
-                        const unsigned q = fast_div(i, Pdiv);
-                        for_corners(sm, ra, rb, [&](unsigned row, float w) {
-                            const unsigned at = rowbase[row] - base + atomicAdd(&rowcnt[row], 1u);
-                            sorted[at] = make_uint2((q << 12) | row, __float_as_uint(w));
-                        });
-                    }
-                };
-                for_cands(pass_b);
-                __syncthreads();
-                listed = false;  // (the row sums below overwrite the list)
-                SSTAMP(4);
-                rowsum_slices<NSLOT, U, NW, false>(sorted, nb, g_bm, gv_t, row_stride, kRowStore, wave, slot, cq, part);
-                __syncthreads();
-                SSTAMP(5);
-                if (wave == 0) rowsum_fold<NSLOT, NW>(part, gv_t, row_stride, kRowStore, slot, cq);
-            }
-            __syncthreads();
-            SSTAMP(6);
-            ra = rb;
-        } else {
-            // one row with more than cap entries: chunks of the sample list, read-modify-write after the first
-            listed = false;  // (the row sums below overwrite the candidate list)
-            bool first = true;
-            if (tid == 0) scratch[9] = 0;
-            __syncthreads();
-            for (unsigned rd = 0; rd < nrounds; ++rd) {
-                const SlabSample sm = sample_at(rd);
-                if (sm.valid) {
-                    const unsigned q = fast_div(rd * kSlabThreads + tid, Pdiv);
-                    for_corners(sm, ra, ra + 1, [&](unsigned row, float w) {
-                        sorted[atomicAdd(&scratch[9], 1u)] = make_uint2((q << 12) | row, __float_as_uint(w));
-                    });
-                }
-                __syncthreads();
-                const unsigned nc = scratch[9];
-                if (nc && (nc + kSlabThreads > cap || rd + 1 == nrounds)) {  // block-uniform (a round adds <= 256: one pixel)
-                    const int mode = first ? kRowStore : kRowRmw;
-                    rowsum_slices<NSLOT, U, NW, false>(sorted, nc, g_bm, gv_t, row_stride, mode, wave, slot, cq, part);
-                    __syncthreads();
-                    if (wave == 0) rowsum_fold<NSLOT, NW>(part, gv_t, row_stride, mode, slot, cq);
-                    __syncthreads();
-                    if (tid == 0) scratch[9] = 0;
-                    first = false;
-                    __syncthreads();
-                }
-            }
-            ra += 1;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // generic path: any D, float or double; one thread per (b, q, m, c)
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -2380,46 +1967,6 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     return (int)hipGetLastError();
 }
 
-// ---- slab-scan backward (sparse calls) ---------------------------------------------------------
-struct SlabPlan {
-    unsigned T, R, cap;
-    size_t lds;
-};
-inline bool make_slab_plan(int B, int S, int M, int D, int L, int Q, int P, SlabPlan &p)
-{
-    if (!(D == 16 || D == 32 || D == 64) || !lean_ok(B, S, M, D, L, Q, P)) return false;
-    const unsigned heads = (unsigned)B * M;
-    if ((unsigned long long)heads * Q >= 16 * 4096) return false;  // dense calls: the cell walk
-    if ((long long)Q * P > 16384 || Q >= (1 << 20)) return false;   // every block scans Q * P samples twice
-    unsigned T = ZIRA_SLAB_BLOCKS / (heads * (unsigned)L);
-    const unsigned t_min = ((unsigned)S + 2047) / 2048;            // <= 2048 rows per slab (12-bit row field)
-    if (T < t_min) T = t_min;
-    if (T < 1) T = 1;
-    if (T > (unsigned)S) T = (unsigned)S;
-    p.T = T;
-    p.R = ((unsigned)S + T - 1) / T;
-    p.cap = ZIRA_SLAB_CAP;
-    static_assert(kSlabCandCap <= (kSlabThreads / 64) * kRowsumPartWords, "the candidate list lives in the row-sum scratch");
-    if (2 * (size_t)ZIRA_SLAB_CAP < 5 * kSlabHomeCap) return false;  // the home list lives in the entry buffer
-    const size_t words = 2 * (size_t)p.R + 1 + 16 + 1 + 2 * (size_t)p.cap + (kSlabThreads / 64) * kRowsumPartWords;
-    p.lds = words * 4;
-    return p.lds <= 64 * 1024 && (unsigned long long)heads * L * T < (1ull << 31);
-}
-
-template <int D>
-int launch_bwd_slab(const SlabPlan &p, const float *grad_out, const float *value, const int64_t *shapes,
-                    const int64_t *start, const float *loc, const float *attn, int B, int S, int M, int L,
-                    int Q, int P, float *gv, float *gl, float *ga, hipStream_t st)
-{
-    const unsigned heads = (unsigned)B * M, NT = (unsigned)L * p.T;
-    const unsigned nvirt = heads * NT, per = (nvirt + 7) >> 3;
-    hipLaunchKernelGGL(msda_bwd_slab<D>, dim3(per * 8), dim3(kSlabThreads), p.lds, st, grad_out, value, shapes,
-                       start, loc, attn, (unsigned)S, make_fast_div((unsigned)M), (unsigned)Q,
-                       make_fast_div((unsigned)P), (unsigned)L, nvirt, per, make_fast_div(p.T),
-                       make_fast_div(NT), p.R, p.cap, gv, gl, ga);
-    return (int)hipGetLastError();
-}
-
 template <typename T>
 int fwd_generic(const T *value, const int64_t *shapes, const int64_t *start, const T *loc,
                 const T *attn, int B, int S, int M, int D, int L, int Q, int P, T *out,
@@ -2510,29 +2057,20 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
     return ZIRA_MSDA_EINVAL;
 }
 
-// Which backward serves a call of the workspace entry point: the cell walk (csrc/msda_cells.hip) for
-// dense calls (encoder self-attention: every pixel is a query), the one-kernel slab scan for sparse
-// ones (decoder cross-attention).  Developer switch for A/B runs: ZIRA_MSDA_BWD=cells | slab | tiled
-// forces one of them (tiled = the round-1 entry sort) where it applies.
-enum : int { kPathAuto = 0, kPathTiled = 1, kPathCells = 2, kPathSlab = 3 };
-static int forced_path()
+// Which sorted backward serves a call of the workspace entry point: the cell walk
+// (csrc/msda_cells.hip) for dense calls (encoder self-attention: every pixel is a query), the entry
+// sort below for sparse ones (decoder cross-attention).  Developer switch for A/B runs:
+// ZIRA_MSDA_BWD=cells | tiled forces one of them where it applies.
+static bool use_cells_path(int B, int M, int Q)
 {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("ZIRA_MSDA_BWD");
-        v = !e ? kPathAuto
-               : (strcmp(e, "tiled") == 0 ? kPathTiled
-                                          : (strcmp(e, "cells") == 0 ? kPathCells : (strcmp(e, "slab") == 0 ? kPathSlab : kPathAuto)));
+        v = !e ? 2 : (strcmp(e, "tiled") == 0 ? 0 : (strcmp(e, "cells") == 0 ? 1 : 2));
     }
-    return v;
-}
-static bool use_cells_path(int B, int M, int Q)
-{
-    const int f = forced_path();
-    if (f != kPathAuto) return f == kPathCells;
+    if (v != 2) return v == 1;
     return (unsigned long long)B * M * Q >= 16 * 4096;
 }
-static bool use_slab_path() { const int f = forced_path(); return f == kPathAuto || f == kPathSlab; }
 
 size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P)
 {
@@ -2542,8 +2080,6 @@ size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, i
         const size_t n = zira::cells_workspace_bytes(B, S, M, D, L, Q, P);
         if (n) return n;
     }
-    SlabPlan sp;
-    if (use_slab_path() && make_slab_plan(B, S, M, D, L, Q, P, sp)) return 256;  // (needs none: a token size keeps callers on this entry point)
     if (!make_tile_plan(B, S, M, D, L, Q, P, p)) return 0;
     return tile_workspace_bytes(p, B, M);
 }
@@ -2556,13 +2092,6 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
     if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv ||
         !gl || !ga)
         return ZIRA_MSDA_EINVAL;
-    SlabPlan sp;
-    if (use_slab_path() && make_slab_plan(B, S, M, D, L, Q, P, sp)) {
-        hipStream_t st = (hipStream_t)stream;
-        if (D == 16) return launch_bwd_slab<16>(sp, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
-        if (D == 32) return launch_bwd_slab<32>(sp, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
-        return launch_bwd_slab<64>(sp, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
-    }
     if (workspace && use_cells_path(B, M, Q) && !((uintptr_t)workspace & 15)) {
         const size_t need = zira::cells_workspace_bytes(B, S, M, D, L, Q, P);
         if (need && workspace_bytes >= need)
@@ -2606,13 +2135,6 @@ int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t
 int zira_dev_read_k2_stamps(unsigned long long *host, int n)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(zira_k2_stamps), sizeof(unsigned long long) * n);
-}
-#endif
-
-#if ZIRA_SLAB_STAMPS
-int zira_dev_read_slab_stamps(unsigned long long *host, int n)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(zira_slab_stamps), sizeof(unsigned long long) * n);
 }
 #endif
 

@@ -56,10 +56,10 @@
 #include "msda_internal.h"
 
 #ifndef ZIRA_WALK_DF
-#define ZIRA_WALK_DF 6       // walk: the record of stream element k + DF is requested while element k is processed
+#define ZIRA_WALK_DF 4       // walk: the record of stream element k + DF is requested while element k is processed
 #endif
 #ifndef ZIRA_WALK_DR
-#define ZIRA_WALK_DR 3       // ... and the grad_out row of element k + DR
+#define ZIRA_WALK_DR 2       // ... and the grad_out row of element k + DR
 #endif
 #ifndef ZIRA_WALK_MINWAVES
 #define ZIRA_WALK_MINWAVES 2 // walk: waves per SIMD the register allocation must allow
