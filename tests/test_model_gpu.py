@@ -17,12 +17,12 @@ from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch  # noqa: E4
 from ziragroundingdino_amd.transformer import build_transformer  # noqa: E402
 
 
-def small_model(dev="cuda"):
+def small_model(dev="cuda", drop_path_rate=0.0):
     torch.manual_seed(0)
     args = zira_swint_config(num_queries=50, enc_layers=2, dec_layers=2, dim_feedforward=128,
                              fusion_droppath=0.0, max_text_len=32)
     swin = zb.SwinTransformer(embed_dim=24, depths=(1, 1, 2, 1), num_heads=(1, 2, 4, 8), window_size=7,
-                              drop_path_rate=0.0, out_indices=(1, 2, 3))
+                              drop_path_rate=drop_path_rate, out_indices=(1, 2, 3))
     bb = zb.Joiner(swin, zb.PositionEmbeddingSineHW(128, 20, 20, normalize=True))
     bb.num_channels = swin.num_features[1:]
     tiny_bert = zbert.BertModel(zbert.BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
@@ -76,6 +76,45 @@ def test_frontend_graph_replay_matches_eager():
     loss_e = model(data)
     for k in loss_e:
         torch.testing.assert_close(loss_g[k], loss_e[k], rtol=2e-4, atol=2e-4)
+
+
+def test_frontend_graph_follows_mode_and_outputs_survive_replays():
+    """The captured front end must not leak across modes: stochastic depth (drop_path > 0) only runs
+    in training, so a graph captured while training is not the one replayed after .eval(), and eval
+    results are deterministic and equal to the eager front end.  The features handed out are copies:
+    a later replay (gradient accumulation, an eval pass before backward) leaves them intact."""
+    from ziragroundingdino_amd.utils import nested_tensor_from_tensor_list
+
+    model = small_model(drop_path_rate=0.3).train()
+    model.before_train()
+    data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+    samples = nested_tensor_from_tensor_list(model.preprocess_image(data))
+    model.use_frontend_graphs = True
+    f_train, _ = model.run_backbone(samples)            # capture in training mode (drop path active)
+    f_train = [f.tensors for f in f_train]
+    kept = [t.clone() for t in f_train]
+    f_train2, _ = model.run_backbone(samples)           # another replay: different drop-path draws
+    assert any(not torch.equal(a.tensors, b) for a, b in zip(f_train2, kept))
+    for a, b in zip(f_train, kept):                     # ... and the earlier outputs were not overwritten
+        assert torch.equal(a, b)
+    model.eval()
+    g1, _ = model.run_backbone(samples)
+    g2, _ = model.run_backbone(samples)
+    model.use_frontend_graphs = False
+    e, _ = model.run_backbone(samples)
+    for a, b, c in zip(g1, g2, e):
+        assert torch.equal(a.tensors, b.tensors)        # eval is deterministic under replay
+        torch.testing.assert_close(a.tensors, c.tensors, rtol=1e-4, atol=1e-4)
+    # autocast state is part of the key: an fp32 capture is not replayed under bf16 autocast
+    model.use_frontend_graphs = True
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h, _ = model.run_backbone(samples)
+    model.use_frontend_graphs = False
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        he, _ = model.run_backbone(samples)
+    for a, b in zip(h, he):
+        assert a.tensors.dtype == b.tensors.dtype
+        torch.testing.assert_close(a.tensors.float(), b.tensors.float(), rtol=2e-2, atol=2e-2)
 
 
 def test_eval_mode_returns_instances():

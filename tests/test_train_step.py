@@ -88,6 +88,12 @@ def test_two_training_steps_match_reference(msda_backend):
         def after_train(self):
             model.after_train()
 
+        def before_train(self):              # (after_train re-binds the bucket to the new `scaling` tensors)
+            model.before_train()
+
+        def named_parameters(self, *a, **k):
+            return model.named_parameters(*a, **k)
+
     trainer.model = _Wrapped()
     data = (inp, feats, poss, am, pid, c2t)
 
@@ -118,6 +124,14 @@ def test_two_training_steps_match_reference(msda_backend):
     for n, v in g["after_rep"].items():
         close(sd[n], v.to(dev), 1e-4, "after __rep__ " + n)
     assert "-fish-" in model.prompt_memory_pool and "fish" in model.learned_classes
+    # the trainer now trains the tensors __rep__ created (new `scaling` parameters), not the stale ones
+    now = dict(model.named_parameters())
+    assert sorted(trainer.names) == sorted(g["trainable_names"])
+    assert all(p is now[n] for n, p in zip(trainer.names, trainer.params))
+    trainer.run_step(data)                 # (and its bucket check passes)
+    model.zero_grad(set_to_none=True)       # detaches the gradient views from the bucket ...
+    with pytest.raises(RuntimeError, match="left the flat gradient bucket"):
+        trainer.run_step(data)              # ... which the trainer refuses to train through
 
 
 def _dp_worker(rank, world, port, path, out):

@@ -22,7 +22,7 @@ from .transformer import SMALL_ATTENTION_SCORES, Switches, _attention_small
 class BertConfig(SimpleNamespace):
     def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                  intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
-                 layer_norm_eps=1e-12):
+                 layer_norm_eps=1e-12, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1):
         super().__init__(**{k: v for k, v in locals().items() if k not in ("self", "__class__")})
 
 
@@ -33,11 +33,19 @@ class _Embeddings(nn.Module):
         self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
         self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
+        # checkpoints written by transformers < 4.31 carry `embeddings.position_ids`; it is not a
+        # parameter of the model: dropped on load so that strict loading of such checkpoints works
+        self._register_load_state_dict_pre_hook(self._drop_position_ids)
+
+    @staticmethod
+    def _drop_position_ids(state_dict, prefix, *_):
+        state_dict.pop(prefix + "position_ids", None)
 
     def forward(self, input_ids, token_type_ids, position_ids):
         x = (self.word_embeddings(input_ids) + self.token_type_embeddings(token_type_ids)
              + self.position_embeddings(position_ids))
-        return self.LayerNorm(x)
+        return self.dropout(self.LayerNorm(x))
 
 
 class _SelfAttention(nn.Module):
@@ -47,15 +55,17 @@ class _SelfAttention(nn.Module):
         self.query = nn.Linear(c.hidden_size, c.hidden_size)
         self.key = nn.Linear(c.hidden_size, c.hidden_size)
         self.value = nn.Linear(c.hidden_size, c.hidden_size)
+        self.p_drop = c.attention_probs_dropout_prob
 
     def forward(self, x, bias):
         B, T, C = x.shape
         split = lambda t: t.view(B, T, self.h, C // self.h).transpose(1, 2)
         q, k, v = split(self.query(x)), split(self.key(x)), split(self.value(x))
+        p_drop = self.p_drop if self.training else 0.0  # (HF BertSelfAttention drops attention probabilities)
         if Switches.small_attention and B * self.h * T * T <= SMALL_ATTENTION_SCORES:
-            o = _attention_small(q, k, v, bias)   # captions are <= 256 tokens: see transformer._attention_small
+            o = _attention_small(q, k, v, bias, p_drop)   # captions are <= 256 tokens: see transformer._attention_small
         else:
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, dropout_p=p_drop)
         return o.transpose(1, 2).reshape(B, T, C)
 
 
@@ -64,9 +74,10 @@ class _SelfOutput(nn.Module):
         super().__init__()
         self.dense = nn.Linear(in_features or c.hidden_size, c.hidden_size)
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.dropout = nn.Dropout(c.hidden_dropout_prob)
 
     def forward(self, h, residual):
-        return self.LayerNorm(self.dense(h) + residual)
+        return self.LayerNorm(self.dropout(self.dense(h)) + residual)
 
 
 class _Attention(nn.Module):

@@ -50,6 +50,7 @@ class SetCriterion(nn.Module):
         self.gamma = gamma
         self.eos_coef = eos_coef
         self.loss_class_type = loss_class_type
+        self.process_group = None  # ranks num_boxes is averaged over (None = the default group)
         if loss_class_type == "ce_loss":
             empty_weight = torch.ones(self.num_classes + 1)
             empty_weight[-1] = eos_coef
@@ -96,10 +97,13 @@ class SetCriterion(nn.Module):
         num_boxes = sum(len(t["labels"]) for t in targets)
         num_boxes = torch.as_tensor([num_boxes], dtype=torch.float,
                                     device=next(iter(outputs.values())).device)
+        world = 1
         if is_dist_avail_and_initialized():
-            dist.all_reduce(num_boxes)
+            group = getattr(self, "process_group", None)  # set by ZiraTrainer: the ranks the gradients are averaged over
+            dist.all_reduce(num_boxes, group=group)
+            world = dist.get_world_size(group)
         # kept on the device (0-dim): the reference's .item() here is one more host sync per step
-        return torch.clamp(num_boxes / get_world_size(), min=1)[0]
+        return torch.clamp(num_boxes / world, min=1)[0]
 
 
 class TwoStageCriterion(SetCriterion):

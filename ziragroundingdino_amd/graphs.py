@@ -5,8 +5,12 @@ launch cost on the host exceeds their run time on an MI355X; nothing in it depen
 and no gradient flows into it.  ``GraphedNoGrad`` captures such a callable once per input
 signature into a HIP graph (``torch.cuda.CUDAGraph``; random ops such as the backbone's
 stochastic depth keep working through the graph-safe Philox generator) and replays it with one
-launch.  Inputs are copied into static buffers; outputs are static tensors that stay valid until
-the next replay of the same signature.
+launch.  Inputs are copied into static buffers.  What a capture bakes in besides the shapes is part
+of the cache key: the train / eval mode of the wrapped modules (stochastic depth only runs in training)
+and the autocast state (an fp32 capture must not be replayed under bf16 autocast, or the reverse).
+The outputs handed back are copies of the graph's static output buffers, so features saved for a
+later backward (the side branches' weight gradients) survive further forwards -- gradient
+accumulation, or an evaluation pass between forward and backward.
 """
 import torch
 
@@ -23,19 +27,40 @@ def _flatten(obj, out):
     return out
 
 
+def _clone_tree(obj):
+    if torch.is_tensor(obj):
+        return obj.clone()
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_clone_tree(o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _clone_tree(v) for k, v in obj.items()}
+    return obj
+
+
 class GraphedNoGrad:
-    def __init__(self, fn, max_signatures=4, warmup=2):
+    """fn: tensor-in / tensor-out callable; modules: the nn.Modules it runs (their .training flags are
+    part of the cache key); clone_outputs=False hands out the static buffers themselves (valid until
+    the next replay of the same signature only)."""
+
+    def __init__(self, fn, modules=(), max_signatures=8, warmup=2, clone_outputs=True):
         self.fn = fn
+        self.modules = tuple(modules)
         self.max_signatures = max_signatures
         self.warmup = warmup
+        self.clone_outputs = clone_outputs
         self._cache = {}
+
+    def _mode_key(self):
+        training = tuple(bool(m.training) for m in self.modules)
+        autocast = (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else None)
+        return training, autocast
 
     def __call__(self, *args):
         tensors = _flatten(args, [])
         if not tensors or not tensors[0].is_cuda or torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
             with torch.no_grad():
                 return self.fn(*args)
-        key = tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors)
+        key = (tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors), self._mode_key())
         entry = self._cache.get(key)
         if entry is None:
             if len(self._cache) >= self.max_signatures:  # unbounded shape variety: stay eager
@@ -47,7 +72,7 @@ class GraphedNoGrad:
         for s, t in zip(static_in, tensors):
             s.copy_(t, non_blocking=True)
         graph.replay()
-        return static_out
+        return _clone_tree(static_out) if self.clone_outputs else static_out
 
     def _capture(self, args, tensors):
         static_in = [t.clone() for t in tensors]

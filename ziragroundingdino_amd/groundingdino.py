@@ -186,8 +186,8 @@ class GroundingDINO(nn.Module):
         self.use_project_tuning = use_project_tuning
         # hipGraph replay of the frozen front end (GPU only; see graphs.py)
         self.use_frontend_graphs = True
-        self._graphed_backbone = GraphedNoGrad(self._backbone_tensors)
-        self._graphed_bert = GraphedNoGrad(self._bert_hidden)
+        self._graphed_backbone = GraphedNoGrad(self._backbone_tensors, modules=(self.backbone,))
+        self._graphed_bert = GraphedNoGrad(self._bert_hidden, modules=(self.bert,))
         # hipGraph replay of transformer forward + backward (opt-in: fixed input sizes, frozen
         # transformer weights, training mode); see graphs.GraphedTransformer
         self.use_transformer_graph = False

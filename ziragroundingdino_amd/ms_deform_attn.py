@@ -8,16 +8,22 @@ Same public names and call signatures:
   batch_first)`` with parameters ``sampling_offsets / attention_weights / value_proj /
   output_proj`` and the same ``forward`` keyword arguments                 (reference :133-355)
 
-The sampling + aggregation itself always runs in the gfx950 kernels behind ``_C`` -- there is
-no Python/CPU fallback here (the reference's ``multi_scale_deformable_attn_pytorch`` lives on
-only as test infrastructure under ``oracle/``).
+* ``multi_scale_deformable_attn_pytorch(value, value_spatial_shapes, sampling_locations,
+  attention_weights)``: the pure-PyTorch restatement for CPU tensors          (reference :90-130)
+
+On GPU tensors the sampling + aggregation always runs in the gfx950 kernels behind ``_C`` and fails
+loudly if the HIP library is missing -- the PyTorch path is only ever taken for CPU tensors, as in
+the reference module (:326-348).  It is product code written from the op's arithmetic; the test
+oracle under ``oracle/`` is a separate C restatement and is never imported here.
 """
 import math
 import warnings
+import weakref
 from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -76,20 +82,71 @@ def sampling_locations_from_reference_points(reference_points, sampling_offsets,
         "Last dim of reference_points must be 2 or 4, but get {} instead.".format(last))
 
 
-_VERIFIED_LEVEL_TABLES = set()
+def multi_scale_deformable_attn_pytorch(value, value_spatial_shapes, sampling_locations,
+                                        attention_weights):
+    """Pure-PyTorch multi-scale deformable attention: the CPU path of the op (reference
+    ms_deform_attn.py:90-130, the fallback its module takes for non-CUDA tensors :326-348).
+
+    value ``[B,S,M,D]``, value_spatial_shapes ``[L,2]`` (H, W), sampling_locations
+    ``[B,Q,M,L,P,2]`` (x, y in [0, 1]), attention_weights ``[B,Q,M,L,P]`` -> ``[B,Q,M*D]``.
+    Per level: the head-major value map ``[B*M, D, H, W]`` is sampled bilinearly with zero padding
+    at ``2 * loc - 1`` (``align_corners=False``, i.e. pixel coordinate = loc * size - 0.5: the
+    arithmetic of the native kernels), then the L*P samples of a query are mixed with its attention
+    weights.  Differentiable through autograd in all three inputs."""
+    B, _, M, D = value.shape
+    _, Q, _, L, P, _ = sampling_locations.shape
+    sizes = [(int(h), int(w)) for h, w in value_spatial_shapes.tolist()]
+    grids = 2 * sampling_locations - 1
+    start, sampled = 0, []
+    for lvl, (h, w) in enumerate(sizes):
+        # [B, h*w, M, D] -> [B*M, D, h, w]
+        v = value[:, start:start + h * w].permute(0, 2, 3, 1).reshape(B * M, D, h, w)
+        start += h * w
+        # [B, Q, M, P, 2] -> [B*M, Q, P, 2]
+        g = grids[:, :, :, lvl].permute(0, 2, 1, 3, 4).reshape(B * M, Q, P, 2)
+        sampled.append(F.grid_sample(v, g, mode="bilinear", padding_mode="zeros", align_corners=False))
+    # [B*M, D, Q, L*P] weighted by [B*M, 1, Q, L*P]
+    weights = attention_weights.permute(0, 2, 1, 3, 4).reshape(B * M, 1, Q, L * P)
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * weights).sum(-1)
+    return out.view(B, M * D, Q).transpose(1, 2).contiguous()
 
 
-def _check_levels_cover_value(spatial_shapes, num_value):
+class _VerifiedLevels:
+    """Level tables whose sum(H*W) and level_start_index have been read back and checked once.
+    Keyed on the tensor OBJECTS (weak references, plus their versions): a recycled storage address
+    under a new tensor is a new entry, unlike a data_ptr() key."""
+
+    def __init__(self):
+        self._seen = {}
+
+    def check(self, spatial_shapes, level_start_index, num_value):
+        version = getattr(spatial_shapes, "_version", 0) if not spatial_shapes.is_inference() else 0
+        key = (id(spatial_shapes), id(level_start_index), int(num_value))
+        hit = self._seen.get(key)
+        if hit is not None and hit[0]() is spatial_shapes and hit[2] == version and \
+                (level_start_index is None or hit[1]() is level_start_index):
+            return
+        hw = spatial_shapes[:, 0] * spatial_shapes[:, 1]
+        assert int(hw.sum()) == num_value, "spatial_shapes do not cover the value tokens"
+        if level_start_index is not None:
+            want = torch.cat([hw.new_zeros(1), hw.cumsum(0)[:-1]])
+            assert torch.equal(level_start_index.to(want.dtype), want), \
+                "level_start_index is not the running sum of H*W"
+        if len(self._seen) > 256:
+            self._seen.clear()
+        self._seen[key] = (weakref.ref(spatial_shapes),
+                           weakref.ref(level_start_index) if level_start_index is not None else None, version)
+
+
+_VERIFIED_LEVELS = _VerifiedLevels()
+
+
+def _check_levels_cover_value(spatial_shapes, num_value, level_start_index=None):
     """The reference asserts sum(H*W) == num_value on every call (ms_deform_attn.py:284), which
-    reads a device tensor back (a host sync, 12x per step).  Same check here, but a given level
-    table (same storage, same version) is only read back once."""
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, spatial_shapes.device, int(num_value))
-    if key in _VERIFIED_LEVEL_TABLES:
-        return
-    assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
-    if len(_VERIFIED_LEVEL_TABLES) > 256:
-        _VERIFIED_LEVEL_TABLES.clear()
-    _VERIFIED_LEVEL_TABLES.add(key)
+    reads a device tensor back (a host sync, 12x per step).  Same check here (plus
+    level_start_index, the only guard of the kernels' row addressing), but a given pair of level
+    tensors is only read back once."""
+    _VERIFIED_LEVELS.check(spatial_shapes, level_start_index, num_value)
 
 
 class MultiScaleDeformableAttention(nn.Module):
@@ -182,7 +239,7 @@ class MultiScaleDeformableAttention(nn.Module):
         if not self.batch_first:
             query = query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
-        _check_levels_cover_value(spatial_shapes, value.shape[1])
+        _check_levels_cover_value(spatial_shapes, value.shape[1], level_start_index)
 
         value, loc, attn = self.project(query, value, key_padding_mask, reference_points,
                                         spatial_shapes)
@@ -190,9 +247,12 @@ class MultiScaleDeformableAttention(nn.Module):
         out_dtype = value.dtype
         if half:  # the native op is fp32/fp64 (reference :326-344 upcasts fp16 the same way)
             value, loc, attn = value.float(), loc.float(), attn.float()
-        output = MultiScaleDeformableAttnFunction.apply(
-            value.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
-            attn.contiguous(), self.im2col_step)
+        if value.is_cuda:
+            output = MultiScaleDeformableAttnFunction.apply(
+                value.contiguous(), spatial_shapes, level_start_index, loc.contiguous(),
+                attn.contiguous(), self.im2col_step)
+        else:  # CPU tensors: the pure-PyTorch path, as in the reference module (:345-348)
+            output = multi_scale_deformable_attn_pytorch(value, spatial_shapes, loc, attn)
         if half:
             output = output.to(out_dtype)
         output = self.output_proj(output)

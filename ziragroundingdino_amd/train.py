@@ -35,6 +35,21 @@ class ZiraTrainer:
             from . import tuned_gemm
 
             tuned_gemm.enable()  # per-shape GEMM kernel choices recorded for this step (see tuned_gemm.py)
+        self._lr, self._wd, self._betas = lr, weight_decay, betas
+        self.clip_max_norm, self.clip_norm_type = clip_max_norm, clip_norm_type
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.iter = 0
+        if hasattr(model, "criterion") and hasattr(model.criterion, "process_group"):
+            model.criterion.process_group = process_group  # num_boxes is averaged over the same ranks
+        self._bind()
+
+    def _bind(self):
+        """(Re)build the flat gradient bucket and the optimizer over the model's CURRENT trainable
+        tensors.  Called at construction and again after ``after_train``: the re-parameterisation
+        replaces every ``scaling`` parameter with a new tensor (as the reference does), which the old
+        bucket and optimizer would no longer train."""
+        model, lr, weight_decay, betas = self.model, self._lr, self._wd, self._betas
         model.before_train()  # freeze everything but the side branches
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.names = [n for n, _ in named]
@@ -54,14 +69,22 @@ class ZiraTrainer:
             by_lr.setdefault(lr * lr_factor(n), []).append(p)
         groups = [{"params": ps, "lr": g_lr, "weight_decay": weight_decay} for g_lr, ps in by_lr.items()]
         self.optimizer = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay)
-        self.clip_max_norm, self.clip_norm_type = clip_max_norm, clip_norm_type
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.iter = 0
+
+    def _check_bucket(self):
+        """The all-reduce, the clipping and the zeroing act on the flat bucket only: a ``.grad`` that no
+        longer lives in it (``zero_grad(set_to_none=True)``, a replaced parameter) would silently train on
+        raw local gradients."""
+        lo = self.flat_grad.data_ptr()
+        hi = lo + self.flat_grad.numel() * self.flat_grad.element_size()
+        for n, p in zip(self.names, self.params):
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                raise RuntimeError("[ZiraTrainer] .grad of %s left the flat gradient bucket "
+                                   "(zero_grad(set_to_none=True)?); call trainer._bind()" % n)
 
     def run_step(self, data) -> Dict[str, torch.Tensor]:
         """One optimisation step on one minibatch; returns the (detached) weighted loss dict."""
         assert self.model.training, "[ZiraTrainer] model was changed to eval mode!"
+        self._check_bucket()
         loss_dict = self.model(data)
         losses = sum(loss_dict.values())
         losses.backward()
@@ -81,6 +104,7 @@ class ZiraTrainer:
         """End of a task (reference Trainer.after_train :221-237)."""
         self.model.add_cls_prompt(list(class_names))
         self.model.after_train()
+        self._bind()  # __rep__ created new `scaling` parameters: train those in the next task
 
 
 def synthetic_batch(batch_size, height=800, width=1333, n_categories=7, boxes_per_image=5, seed=0,
