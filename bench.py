@@ -18,9 +18,19 @@ encoder shape (Q = S), forward / backward, and priced with the algorithmic bytes
 section 8(d).  The top-level object is the north-star kernel pair ("ms_deform_attn fwd+bwd at B=2,
 Q=900, L=4, M=8, P=4"); `kernels` lists all four groups, `dominant` names the one with the
 largest share of the step.
+`roofline.micro`: the kernel micro-benchmark of SURVEY.md section 8(d), outside the timed region:
+uniform / clustered sampling locations at the north-star shape and pixel-grid queries at the
+encoder shape; 20 warm-up + 200 timed launches (50 at the encoder shape) of forward, backward and
+the pair, replayed from a hipGraph so that the launches are back to back, timed with HIP events.
 `cpu_baseline` (rank 0, N = 1): the same training step on the host cores -- this package's
 model on CPU tensors with the two native MSDA entry points served by the CPU oracle (kind
-"port"; the reference's own Python cannot travel to the GPU box) -- on a bounded sample.
+"port"; the reference's own Python cannot travel to the GPU box) -- on a bounded sample; beside it
+`cpu_baseline.msda`: the op alone on the section 8(d) inputs, as the reference's fallback computes
+it (per-level F.grid_sample + autograd, the package's multi_scale_deformable_attn_pytorch, all host
+cores) and as the C restatement (oracle/msda_oracle.c, OpenMP) does.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (one
+process per GPU through torch.distributed.run on 127.0.0.1) before anything touches the GPU.
 """
 import argparse
 import json
@@ -60,6 +70,140 @@ def make_msda_inputs(B, Q, M, D, shapes, P, seed, device):
     sh = torch.tensor(shapes, dtype=torch.long)
     start = torch.cat([sh.new_zeros(1), (sh[:, 0] * sh[:, 1]).cumsum(0)[:-1]])
     return [t.to(device) for t in (value, sh, start, loc, attn, grad_out)]
+
+
+def graphed(fn, n):
+    """Capture n back-to-back calls into a hipGraph so that replay is device-bound (the Python shim
+    costs ~10 us of host time per call, more than the kernels take)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    return g.replay
+
+
+def timeit(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def encoder_loc(B, M, shapes, P, seed, dev):
+    """Pixel-grid reference points of every level (reference transformer_for_adapter.py:482-497)
+    + N(0, 2 px) offsets in each level's own pixels."""
+    g = torch.Generator().manual_seed(seed)
+    sh = torch.tensor(shapes, dtype=torch.float32)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in shapes])
+    S, L = ref.shape[0], len(shapes)
+    off = 2.0 * torch.randn(B, S, M, L, P, 2, generator=g)
+    norm = torch.stack([sh[:, 1], sh[:, 0]], -1)[None, None, None, :, None, :]
+    return (ref[None, :, None, None, None, :] + off / norm).contiguous().to(dev)
+
+
+def clustered_loc(B, Q, M, L, P, seed, dev):
+    """Decoder-like: box centres U(0.1, 0.9) + N(0, 0.05) offsets."""
+    g = torch.Generator().manual_seed(seed)
+    centre = torch.rand(B, Q, 1, 1, 1, 2, generator=g) * 0.8 + 0.1
+    return (centre + 0.05 * torch.randn(B, Q, M, L, P, 2, generator=g)).to(dev)
+
+
+def msda_micro(dev):
+    """forward, backward and pair on synthetic inputs, device-bound."""
+    from ziragroundingdino_amd import _C
+    B, M, D, P, shapes = 2, 8, 32, 4, NORTH_STAR_SHAPES
+    S, L = sum(h * w for h, w in shapes), len(shapes)
+    v, sh, st, loc, attn, go = make_msda_inputs(B, 900, M, D, shapes, P, 0, dev)
+    cases = [("northstar_uniform", (v, sh, st, loc, attn, go), 900, 200),
+             ("northstar_clustered", (v, sh, st, clustered_loc(B, 900, M, L, P, 1, dev), attn, go), 900, 200)]
+    ve, _, _, _, attne, goe = make_msda_inputs(B, S, M, D, shapes, P, 2, dev)
+    cases.append(("encoder_grid", (ve, sh, st, encoder_loc(B, M, shapes, P, 3, dev), attne, goe), S, 50))
+    out = {}
+    for name, (v, sh, st, loc, attn, go), Q, iters in cases:
+        fb, bb = msda_algorithmic_bytes(B, S, M, D, L, Q, P)
+        fwd = lambda: _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
+        bwd = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+        pair = lambda: (fwd(), bwd())
+        per = 10
+        res = {"Q": Q, "warmup": 20, "iters": iters}
+        for key, fn, nbytes in (("fwd", fwd, fb), ("bwd", bwd, bb), ("pair", pair, fb + bb)):
+            g = graphed(fn, per)
+            timeit(g, 2)  # 20 warm-up launches
+            us = timeit(g, max(1, iters // per)) / per
+            res[key + "_us"] = us
+            res[key + "_frac"] = nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        out[name] = res
+    return out
+
+
+def cpu_baseline_msda(threads):
+    """The op alone on the host cores, SURVEY.md section 8(d) inputs: the reference's fallback
+    formulation (per-level grid_sample + autograd; ziragroundingdino_amd's product-side function)
+    and the C restatement (test oracle), forward and forward+backward, bounded iteration counts."""
+    import numpy as np
+    from oracle import msda_oracle
+    from ziragroundingdino_amd import multi_scale_deformable_attn_pytorch as msda_torch
+
+    msda_oracle.build()
+    msda_oracle.set_num_threads(threads)
+    torch.set_num_threads(threads)
+    B, M, D, P, shapes = 2, 8, 32, 4, NORTH_STAR_SHAPES
+    S = sum(h * w for h, w in shapes)
+    out = {}
+    for name, Q, iters in (("northstar_B2_Q900", 900, 5), ("encoder_B2_Q22223", S, 2)):
+        v, sh, st, loc, attn, go = make_msda_inputs(B, Q, M, D, shapes, P, 0, "cpu")
+        if Q == S:
+            loc = encoder_loc(B, M, shapes, P, 3, "cpu")
+        vv, ll, aa = v.clone().requires_grad_(), loc.clone().requires_grad_(), attn.clone().requires_grad_()
+        msda_torch(vv, sh, ll, aa).backward(go)  # warm-up
+        tf = tb = 0.0
+        for _ in range(iters):
+            vv.grad = ll.grad = aa.grad = None
+            t0 = time.perf_counter()
+            o = msda_torch(vv, sh, ll, aa)
+            t1 = time.perf_counter()
+            o.backward(go)
+            t2 = time.perf_counter()
+            tf += t1 - t0
+            tb += t2 - t1
+        npv = [x.numpy() for x in (v, sh, st, loc, attn, go)]
+        msda_oracle.msda_forward(*npv[:5])
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            msda_oracle.msda_forward(*npv[:5])
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            msda_oracle.msda_backward(npv[5], *npv[:5])
+        t2 = time.perf_counter()
+        out[name] = {"grid_sample_fwd_ms": tf / iters * 1e3, "grid_sample_fwd_bwd_ms": (tf + tb) / iters * 1e3,
+                     "c_fwd_ms": (t1 - t0) / iters * 1e3, "c_fwd_bwd_ms": (t2 - t0) / iters * 1e3, "iters": iters}
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as a child job and exit
+    with its code.  Nothing here touches the GPU (device_count() does not initialise it)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline_step(height=800, width=1333, sample_div=2, threads=None):
@@ -152,8 +296,11 @@ def main():
                     help="replay encoder / decoder layers from hipGraphs (opt-in; same kernels, ~half the host time)")
     ap.add_argument("--cpu-sample-div", type=int, default=1,
                     help="cpu_baseline runs one step on an image with sides divided by this")
+    ap.add_argument("--no-micro", action="store_true", help="skip the section 8(d) kernel micro-benchmark")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])  # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -222,6 +369,8 @@ def main():
                                        "B=%d,S=%d,M=%d,D=%d,L=%d,Q=%d,P=%d" % tuple(f["dims_BSMDLQP"]),
                              "achieved": nbytes / t_pair / 1e9, "frac": nbytes / t_pair / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes": nbytes, "avg_us": t_pair * 1e6})
+        if not args.no_micro:
+            roofline["micro"] = msda_micro(dev)
         images = args.steps * args.batch * world
         line = {
             "metric": "images/sec fwd+bwd GroundingDINO-T+ZiRa @800x1333",
@@ -251,7 +400,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_img, el, cores, desc = cpu_baseline_step(args.height, args.width, args.cpu_sample_div)
             line["cpu_baseline"] = {"value": n_img / el, "unit": "images/s", "cores": cores,
-                                    "kind": "port", "sample": desc}
+                                    "kind": "port", "sample": desc, "msda": cpu_baseline_msda(cores)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

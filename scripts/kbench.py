@@ -8,44 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import NORTH_STAR_SHAPES, make_msda_inputs, msda_algorithmic_bytes  # noqa: E402
+from bench import (NORTH_STAR_SHAPES, encoder_loc, graphed, make_msda_inputs,  # noqa: E402
+                   msda_algorithmic_bytes, timeit)
 from ziragroundingdino_amd import _C  # noqa: E402
-
-
-def graphed(fn, n):
-    """Capture n back-to-back calls into a hipGraph so that replay is device-bound (the Python
-    shim costs ~10 us of host time per call, more than the kernels take)."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        fn()
-    torch.cuda.current_stream().wait_stream(s)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(n):
-            fn()
-    return g.replay
-
-
-def timeit(fn, iters):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
-
-
-def encoder_loc(B, M, shapes, P, seed, dev):
-    g = torch.Generator().manual_seed(seed)
-    sh = torch.tensor(shapes, dtype=torch.float32)
-    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
-                                                indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in shapes])
-    S, L = ref.shape[0], len(shapes)
-    off = 2.0 * torch.randn(B, S, M, L, P, 2, generator=g)
-    norm = torch.stack([sh[:, 1], sh[:, 0]], -1)[None, None, None, :, None, :]
-    return (ref[None, :, None, None, None, :] + off / norm).contiguous().to(dev)
 
 
 def main():

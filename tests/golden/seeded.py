@@ -21,3 +21,14 @@ def fill_by_name_(module, salt: str, scale: float = 0.15, overrides=None, prefix
                     s = val
             p.copy_(torch.randn(p.shape, generator=g) * s)
     return module
+
+
+def layernorm_weights_plus_one_(module):
+    """LayerNorm gains around 1 instead of around 0 (every 1-D `*.weight` whose name contains "norm"):
+    with gains ~ N(0, s) a deep random transformer collapses all tokens onto one direction, and the
+    two-stage selection degenerates into a tie between the (identical) invalid proposals."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "norm" in name and name.endswith(".weight") and p.dim() == 1:
+                p.add_(1.0)
+    return module

@@ -143,20 +143,34 @@ def test_hip_matches_oracle(oracle, case):
     _close(gl, want_gl, tol, "grad_sampling_loc")
 
 
-def test_encoder_shape_against_oracle(oracle):
-    """Q = S (every pixel is a query, reference transformer_for_adapter.py:893-900); B=1 to
-    keep the CPU side in seconds."""
+@pytest.mark.parametrize("pattern", ["gauss2px", "init_grid"])
+def test_encoder_shape_against_oracle(oracle, pattern):
+    """Q = S (every pixel is a query, reference transformer_for_adapter.py:893-900) at the
+    benchmarked batch size B = 2 (the grid and the per-XCD split differ from B = 1).  Two location
+    patterns: pixel-grid reference points + N(0, 2 px) offsets, and the module's own
+    initial offsets -- head m points along direction m, point p at (p + 1) pixels, identical for
+    every query (reference ms_deform_attn.py:194-217) -- which is what a freshly built model feeds the
+    op and is as regular as inputs get (every sample of a head / point lands on the same sub-pixel
+    phase; whole rows of queries hit the same cells)."""
     shapes = NORTH_STAR_SHAPES
     sh = np.asarray(shapes, dtype=np.int64)
     S = int((sh[:, 0] * sh[:, 1]).sum())
-    B, M, D, L, P = 1, 8, 32, 4, 4
+    B, M, D, L, P = 2, 8, 32, 4, 4
     rng = np.random.default_rng(5)
     value, _, start, _, attn, go = _random_case(B, S, M, D, shapes, P, seed=5)
     # reference points = pixel centres of every level's grid, replicated over levels
     ref = np.concatenate([
         np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2)
         for h, w in shapes]).astype(np.float32)                                  # [S,2] (x,y)
-    off_px = 2.0 * rng.standard_normal((B, S, M, L, P, 2)).astype(np.float32)
+    if pattern == "gauss2px":
+        off_px = 2.0 * rng.standard_normal((B, S, M, L, P, 2)).astype(np.float32)
+    else:
+        theta = np.arange(M, dtype=np.float32) * (2.0 * np.pi / M)
+        d = np.stack([np.cos(theta), np.sin(theta)], -1)
+        d = d / np.abs(d).max(-1, keepdims=True)
+        off_px = (d[None, None, :, None, None, :] * np.arange(1, P + 1, dtype=np.float32)[None, None, None, None, :, None])
+        off_px = np.broadcast_to(off_px, (B, S, M, L, P, 2)).astype(np.float32)
+        attn = np.full_like(attn, 1.0 / (L * P))
     norm = np.stack([sh[:, 1], sh[:, 0]], -1).astype(np.float32)[None, None, None, :, None, :]
     loc = (ref[None, :, None, None, None, :] + off_px / norm).astype(np.float32)
     want_out = oracle.msda_forward(value, sh, start, loc, attn)
