@@ -25,8 +25,10 @@ def small_model(dev="cuda", drop_path_rate=0.0):
                               drop_path_rate=drop_path_rate, out_indices=(1, 2, 3))
     bb = zb.Joiner(swin, zb.PositionEmbeddingSineHW(128, 20, 20, normalize=True))
     bb.num_channels = swin.num_features[1:]
+    # (no dropout in the text encoder: several tests compare two forward passes of a model in training mode)
     tiny_bert = zbert.BertModel(zbert.BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
-                                                 intermediate_size=128))
+                                                 intermediate_size=128, hidden_dropout_prob=0.0,
+                                                 attention_probs_dropout_prob=0.0))
     model = GroundingDINO(bb, build_transformer(args), num_queries=50, aux_loss=True, iter_update=True,
                           query_dim=4, num_feature_levels=4, nheads=8, two_stage_type="standard",
                           two_stage_bbox_embed_share=False, two_stage_class_embed_share=False,

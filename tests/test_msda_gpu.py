@@ -172,7 +172,8 @@ def test_encoder_shape_against_oracle(oracle, pattern):
         off_px = np.broadcast_to(off_px, (B, S, M, L, P, 2)).astype(np.float32)
         attn = np.full_like(attn, 1.0 / (L * P))
     norm = np.stack([sh[:, 1], sh[:, 0]], -1).astype(np.float32)[None, None, None, :, None, :]
-    loc = (ref[None, :, None, None, None, :] + off_px / norm).astype(np.float32)
+    loc = np.ascontiguousarray((ref[None, :, None, None, None, :] + off_px / norm).astype(np.float32))
+    attn = np.ascontiguousarray(attn)
     want_out = oracle.msda_forward(value, sh, start, loc, attn)
     want = oracle.msda_backward(go, value, sh, start, loc, attn)
     t = lambda a: torch.from_numpy(a).to(DEV)
