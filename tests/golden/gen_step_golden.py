@@ -56,61 +56,78 @@ def build_inputs(g):
                 input_ids=ids, bert_hidden=hidden, targets=targets)
 
 
-def main():
-    torch.set_num_threads(1)
-    ref = ref_import.load()
-    Z, T_, U, C, B = (ref["groundingdino_dual_zero_rep_branch"], ref["transformer_for_adapter"],
-                      ref["utils"], ref["criterion"], ref["bertwarper"])
-    d = CFG["hidden_dim"]
-    tr = T_.Transformer(
-        d_model=d, nhead=CFG["nheads"], num_queries=CFG["num_queries"], num_encoder_layers=CFG["enc_layers"],
-        num_decoder_layers=CFG["dec_layers"], dim_feedforward=CFG["dim_feedforward"], dropout=0.0,
-        return_intermediate_dec=True, query_dim=4, num_feature_levels=4, enc_n_points=2, dec_n_points=2,
-        learnable_tgt_init=True, two_stage_type="standard", embed_init_tgt=True, use_text_enhancer=True,
-        use_fusion_layer=True, use_text_cross_attention=True, text_dropout=0.0, fusion_dropout=0.0,
-        fusion_droppath=0.1, use_adapter=False)
-    bbox = U.MLP(d, d, 4, 3)
-    cls = U.ContrastiveEmbed(max_text_len=CFG["max_text_len"])
-    bbox_list = nn.ModuleList([bbox for _ in range(CFG["dec_layers"])])
-    tr.decoder.bbox_embed = bbox_list
-    tr.decoder.class_embed = nn.ModuleList([cls for _ in range(CFG["dec_layers"])])
-    tr.enc_out_bbox_embed = U.MLP(d, d, 4, 3)          # two_stage_bbox_embed_share = False
-    tr.enc_out_class_embed = cls
-    feat_map = nn.Linear(CFG["bert_hidden"], d)
-    rep_lin = Z.RepZeroLinear(CFG["bert_hidden"], d)
-    chans = CFG["channels"]
-    input_proj = nn.ModuleList(
-        [nn.Sequential(nn.Conv2d(c, d, 1), nn.GroupNorm(32, d)) for c in chans]
-        + [nn.Sequential(nn.Conv2d(chans[-1], d, 3, stride=2, padding=1), nn.GroupNorm(32, d))])
-    adapters = nn.ModuleList([Z.RepZeroConv2d(c, d, kernel_size=1) for c in chans]
-                             + [Z.RepZeroConv2d(chans[-1], d, kernel_size=3, stride=2, padding=1)])
-    fill_by_name_(tr, SALT, 0.05, SCALES, prefix="transformer.")
-    fill_by_name_(feat_map, SALT, 0.05, SCALES, prefix="feat_map.")
-    fill_by_name_(rep_lin, SALT, 0.05, SCALES, prefix="rep_linear_adapter.")
-    fill_by_name_(input_proj, SALT, 0.05, SCALES, prefix="input_proj.")
-    fill_by_name_(adapters, SALT, 0.05, SCALES, prefix="input_proj_conv_adapter.")
-    for m in (tr, feat_map, rep_lin, input_proj, adapters):
-        m.train()
-    for m in (tr, feat_map, input_proj):                  # before_train(): freeze all but "adapter"
-        for p in m.parameters():
-            p.requires_grad_(False)
-    crit = C.build_criterion(SimpleNamespace(aux_loss=True, dec_layers=CFG["dec_layers"],
-                                             max_text_len=CFG["max_text_len"]))
+class Slice:
+    """The reference's modules for the slice, under the parameter names of the full model."""
 
-    g = torch.Generator().manual_seed(17)
-    inp = build_inputs(g)
-    am, pid, c2t = B.generate_masks_with_special_tokens_and_transfer_map(
-        {"input_ids": inp["input_ids"]}, [101, 102, 1012, 1029], None)
-    text_token_mask = torch.ones_like(inp["input_ids"]).bool()
+    def __init__(self, ref, seeded=True):
+        Z, T_, U, C = (ref["groundingdino_dual_zero_rep_branch"], ref["transformer_for_adapter"],
+                       ref["utils"], ref["criterion"])
+        self.ref, self.U = ref, U
+        d = CFG["hidden_dim"]
+        tr = T_.Transformer(
+            d_model=d, nhead=CFG["nheads"], num_queries=CFG["num_queries"], num_encoder_layers=CFG["enc_layers"],
+            num_decoder_layers=CFG["dec_layers"], dim_feedforward=CFG["dim_feedforward"], dropout=0.0,
+            return_intermediate_dec=True, query_dim=4, num_feature_levels=4, enc_n_points=2, dec_n_points=2,
+            learnable_tgt_init=True, two_stage_type="standard", embed_init_tgt=True, use_text_enhancer=True,
+            use_fusion_layer=True, use_text_cross_attention=True, text_dropout=0.0, fusion_dropout=0.0,
+            fusion_droppath=0.1, use_adapter=False)
+        bbox = U.MLP(d, d, 4, 3)
+        cls = U.ContrastiveEmbed(max_text_len=CFG["max_text_len"])
+        self.bbox_list = nn.ModuleList([bbox for _ in range(CFG["dec_layers"])])
+        tr.decoder.bbox_embed = self.bbox_list
+        tr.decoder.class_embed = nn.ModuleList([cls for _ in range(CFG["dec_layers"])])
+        tr.enc_out_bbox_embed = U.MLP(d, d, 4, 3)          # two_stage_bbox_embed_share = False
+        tr.enc_out_class_embed = cls
+        self.tr, self.cls = tr, cls
+        self.feat_map = nn.Linear(CFG["bert_hidden"], d)
+        self.rep_lin = Z.RepZeroLinear(CFG["bert_hidden"], d)
+        chans = CFG["channels"]
+        self.input_proj = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(c, d, 1), nn.GroupNorm(32, d)) for c in chans]
+            + [nn.Sequential(nn.Conv2d(chans[-1], d, 3, stride=2, padding=1), nn.GroupNorm(32, d))])
+        self.adapters = nn.ModuleList([Z.RepZeroConv2d(c, d, kernel_size=1) for c in chans]
+                                      + [Z.RepZeroConv2d(chans[-1], d, kernel_size=3, stride=2, padding=1)])
+        self.parts = {"transformer.": tr, "feat_map.": self.feat_map, "rep_linear_adapter.": self.rep_lin,
+                      "input_proj.": self.input_proj, "input_proj_conv_adapter.": self.adapters}
+        if seeded:
+            for prefix, m in self.parts.items():
+                fill_by_name_(m, SALT, 0.05, SCALES, prefix=prefix)
+        for m in self.parts.values():
+            m.train()
+        for m in (tr, self.feat_map, self.input_proj):        # before_train(): freeze all but "adapter"
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.crit = C.build_criterion(SimpleNamespace(aux_loss=True, dec_layers=CFG["dec_layers"],
+                                                      max_text_len=CFG["max_text_len"]))
 
-    named = ([("rep_linear_adapter." + n, p) for n, p in rep_lin.named_parameters()]
-             + [("input_proj_conv_adapter." + n, p) for n, p in adapters.named_parameters()])
-    opt = torch.optim.AdamW([{"params": [p], "lr": 1e-3 * (0.2 if "freeze" in n else 1.0), "weight_decay": 1e-4}
-                             for n, p in named], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    def named_trainable(self):
+        return ([("rep_linear_adapter." + n, p) for n, p in self.rep_lin.named_parameters()]
+                + [("input_proj_conv_adapter." + n, p) for n, p in self.adapters.named_parameters()])
 
-    def forward():
-        encoded_text = feat_map(inp["bert_hidden"])
-        rep_out, loss_lin = rep_lin(inp["bert_hidden"])
+    def optimizer(self):
+        return torch.optim.AdamW(
+            [{"params": [p], "lr": 1e-3 * (0.2 if "freeze" in n else 1.0), "weight_decay": 1e-4}
+             for n, p in self.named_trainable()], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+
+    def state_dict(self):
+        return {prefix + n: v for prefix, m in self.parts.items() for n, v in m.state_dict().items()}
+
+    def load_state_dict(self, sd):
+        for prefix, m in self.parts.items():
+            m.load_state_dict({n[len(prefix):]: v for n, v in sd.items() if n.startswith(prefix)}, strict=True)
+
+    def rep(self):
+        for m in list(self.adapters) + [self.rep_lin]:
+            m.__rep__()
+
+    def forward(self, inp):
+        import groundingdino.util.misc as misc
+        U, tr, cls, crit, adapters, input_proj = self.U, self.tr, self.cls, self.crit, self.adapters, self.input_proj
+        am, pid, c2t = self.ref["bertwarper"].generate_masks_with_special_tokens_and_transfer_map(
+            {"input_ids": inp["input_ids"]}, [101, 102, 1012, 1029], None)
+        text_token_mask = torch.ones_like(inp["input_ids"]).bool()
+        encoded_text = self.feat_map(inp["bert_hidden"])
+        rep_out, loss_lin = self.rep_lin(inp["bert_hidden"])
         encoded_text = rep_out + encoded_text
         text_dict = {"encoded_text": encoded_text, "text_token_mask": text_token_mask,
                      "position_ids": pid, "text_self_attention_masks": am}
@@ -127,9 +144,8 @@ def main():
         masks = inp["masks"] + [mask3]
         poss = inp["poss"] + [inp["pos_extra"]]
         hs, reference, hs_enc, ref_enc, init_box, _ = tr(srcs, masks, None, poss, None, None, text_dict)
-        import groundingdino.util.misc as misc
         coords = torch.stack([(bb(h) + misc.inverse_sigmoid(r)).sigmoid()
-                              for r, bb, h in zip(reference[:-1], bbox_list, hs)])
+                              for r, bb, h in zip(reference[:-1], self.bbox_list, hs)])
         classes = torch.stack([U.recover_to_cls_logits(cls(h, text_dict), c2t, for_fill=-100.0) for h in hs])
         out = {"pred_logits": classes[-1], "pred_boxes": coords[-1],
                "aux_outputs": [{"pred_logits": a_, "pred_boxes": b_} for a_, b_ in zip(classes[:-1], coords[:-1])]}
@@ -142,6 +158,16 @@ def main():
         loss_dict["loss_conv_adapter"] = loss_conv * 0.1
         loss_dict["loss_linear_adapter"] = loss_lin * 0.1
         return loss_dict
+
+
+def main():
+    torch.set_num_threads(1)
+    S = Slice(ref_import.load())
+    g = torch.Generator().manual_seed(17)
+    inp = build_inputs(g)
+    named = S.named_trainable()
+    opt = S.optimizer()
+    forward = lambda: S.forward(inp)
 
     steps = []
     for it in range(2):
@@ -158,10 +184,9 @@ def main():
                           grads=grads if it == 0 else None,
                           params_after={n: p.detach().clone() for n, p in named} if it == 1 else None))
     # end of task: merge the branches
-    for m in list(adapters) + [rep_lin]:
-        m.__rep__()
-    after_rep = {"rep_linear_adapter." + n: v.clone() for n, v in rep_lin.state_dict().items()}
-    after_rep.update({"input_proj_conv_adapter." + n: v.clone() for n, v in adapters.state_dict().items()})
+    S.rep()
+    after_rep = {"rep_linear_adapter." + n: v.clone() for n, v in S.rep_lin.state_dict().items()}
+    after_rep.update({"input_proj_conv_adapter." + n: v.clone() for n, v in S.adapters.state_dict().items()})
     path = os.path.join(HERE, "step_zira_slice.pt")
     torch.save(dict(cfg=CFG, salt=SALT, scales=SCALES, inputs=inp, steps=steps, after_rep=after_rep,
                     trainable_names=[n for n, _ in named]), path)

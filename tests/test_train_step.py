@@ -34,7 +34,7 @@ class _StubBackbone(nn.Sequential):
         self.num_channels = num_channels
 
 
-def build_slice_model(g, dev):
+def build_slice_model(g, dev, cls=GroundingDINO, seeded=True):
     c = g["cfg"]
     args = zira_swint_config(hidden_dim=c["hidden_dim"], nheads=c["nheads"], num_queries=c["num_queries"],
                              enc_layers=c["enc_layers"], dec_layers=c["dec_layers"],
@@ -43,13 +43,14 @@ def build_slice_model(g, dev):
                              fusion_droppath=0.0)  # stochastic depth off for parity
     tiny_bert = zbert.BertModel(zbert.BertConfig(vocab_size=64, hidden_size=c["bert_hidden"], num_hidden_layers=1,
                                                  num_attention_heads=4, intermediate_size=32))
-    model = GroundingDINO(
+    model = cls(
         _StubBackbone(c["channels"]), build_transformer(args), num_queries=c["num_queries"], aux_loss=True,
         iter_update=True, query_dim=4, num_feature_levels=4, nheads=c["nheads"], two_stage_type="standard",
         dec_pred_bbox_embed_share=True, two_stage_bbox_embed_share=False, two_stage_class_embed_share=False,
         max_text_len=c["max_text_len"], criterion=build_criterion(args), freeze_all=True, use_cet=True,
         use_project_adapter=True, loss_adapter_weight=0.1, device=dev, bert=tiny_bert)
-    fill_by_name_(model, g["salt"], 0.05, g["scales"])
+    if seeded:
+        fill_by_name_(model, g["salt"], 0.05, g["scales"])
     return model.to(dev).train()
 
 
