@@ -296,6 +296,10 @@ def main():
                     help="replay encoder / decoder layers from hipGraphs (opt-in; same kernels, ~half the host time)")
     ap.add_argument("--cpu-sample-div", type=int, default=1,
                     help="cpu_baseline runs one step on an image with sides divided by this")
+    ap.add_argument("--backbone", default="swin_T_224_1k",
+                    help="swin_B_384_22k = BASELINE configs[3] (GroundingDINO-B); a separately labelled line")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: GEMMs under bf16 autocast around the fp32 native ops (configs[3])")
     ap.add_argument("--no-micro", action="store_true", help="skip the section 8(d) kernel micro-benchmark")
     args = ap.parse_args()
 
@@ -318,9 +322,9 @@ def main():
 
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
-    model = build_model(zira_swint_config(device=str(dev))).to(dev).train()
+    model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
     model.use_transformer_graph = args.transformer_graph
-    trainer = ZiraTrainer(model)
+    trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard
 
     for _ in range(args.warmup):
@@ -372,8 +376,10 @@ def main():
         if not args.no_micro:
             roofline["micro"] = msda_micro(dev)
         images = args.steps * args.batch * world
+        flagship = args.backbone == "swin_T_224_1k" and args.dtype == "f32"
+        size = "T" if args.backbone.startswith("swin_T") else "B"
         line = {
-            "metric": "images/sec fwd+bwd GroundingDINO-T+ZiRa @800x1333",
+            "metric": "images/sec fwd+bwd GroundingDINO-%s+ZiRa @800x1333" % size,
             "value": images / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -383,12 +389,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: GroundingDINO-T (Swin-T + BERT-base, random init) frozen-backbone "
+                "workload": ("configs[1]: GroundingDINO-T (Swin-T + BERT-base, random init) frozen-backbone "
+                             if flagship else
+                             "configs[3] variant (%s, %s GEMMs; NOT the headline config): GroundingDINO-%s frozen-backbone "
+                             % (args.backbone, args.dtype, size)) +
                             "ZiRa side-branch fine-tune step, %d x %dx%d images per GPU, 900 queries, "
                             "full fwd+loss+bwd+clip+AdamW" % (args.batch, args.height, args.width),
+                "backbone": args.backbone,
                 "images_per_gpu": args.batch,
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world, "transformer_graph": bool(args.transformer_graph),
@@ -397,7 +407,7 @@ def main():
             },
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and flagship:
             n_img, el, cores, desc = cpu_baseline_step(args.height, args.width, args.cpu_sample_div)
             line["cpu_baseline"] = {"value": n_img / el, "unit": "images/s", "cores": cores,
                                     "kind": "port", "sample": desc, "msda": cpu_baseline_msda(cores)}

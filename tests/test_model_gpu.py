@@ -245,3 +245,44 @@ def test_transformer_graph_path_matches_eager_and_survives_replays():
     assert all(torch.isfinite(torch.tensor(graphed)))
     for a, b in zip(eager, graphed):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (eager, graphed)
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ["ZIRA_ROOT"], "tests")); sys.path.insert(0, os.environ["ZIRA_ROOT"])
+from test_model_gpu import small_model
+from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+solo = ZiraTrainer(small_model().train())
+solo.model.criterion.process_group = None
+a = [solo.run_step(data) for _ in range(2)]
+group = dist.new_group([0])
+tr = ZiraTrainer(small_model().train(), process_group=group)
+tr.always_reduce = True          # world size 1: issue the RCCL all-reduce of the flat bucket anyway
+b = [tr.run_step(data) for _ in range(2)]
+for x, y in zip(a, b):
+    for k in x:
+        torch.testing.assert_close(x[k], y[k], rtol=1e-4, atol=1e-5, msg=k)
+for p, q in zip(solo.params, tr.params):
+    torch.testing.assert_close(p, q, rtol=1e-3, atol=1e-5)   # (grad_value sums are not order-stable run to run)
+dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+
+
+def test_one_rank_rccl_step_matches_no_collective():
+    """The N>1 code path on the hardware at hand: a one-rank RCCL ("nccl" backend) process group, the
+    criterion's num_boxes all-reduce and the flat side-branch bucket all-reduce issued on it, two steps;
+    same losses and weights as the trainer without a process group.  (Own process: the group must not
+    leak into the other tests.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), ZIRA_ROOT=root,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

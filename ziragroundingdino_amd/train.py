@@ -29,8 +29,13 @@ def lr_factor(name: str) -> float:
 
 class ZiraTrainer:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), clip_max_norm=0.1,
-                 clip_norm_type=2.0, process_group=None, tuned_gemms=True):
+                 clip_norm_type=2.0, process_group=None, tuned_gemms=True, amp_dtype=None):
         self.model = model
+        # ``train.amp.enabled`` of the reference's configs (Trainer.run_step :170-174 wraps the forward in
+        # autocast); here the dtype is named.  bf16 needs no GradScaler.  The native fp32 ops (MSDA, side
+        # branch epilogue, LayerNorm) keep computing in fp32 inside the autocast region.
+        assert amp_dtype in (None, torch.bfloat16), "fp16 autocast would need a GradScaler; use bf16"
+        self.amp_dtype = amp_dtype
         if tuned_gemms and next(model.parameters()).is_cuda:
             from . import tuned_gemm
 
@@ -40,6 +45,7 @@ class ZiraTrainer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.iter = 0
+        self.always_reduce = False  # tests: issue the collective on a one-rank group too
         if hasattr(model, "criterion") and hasattr(model.criterion, "process_group"):
             model.criterion.process_group = process_group  # num_boxes is averaged over the same ranks
         self._bind()
@@ -85,10 +91,14 @@ class ZiraTrainer:
         """One optimisation step on one minibatch; returns the (detached) weighted loss dict."""
         assert self.model.training, "[ZiraTrainer] model was changed to eval mode!"
         self._check_bucket()
-        loss_dict = self.model(data)
+        if self.amp_dtype is not None:
+            with torch.autocast(self.flat_grad.device.type, dtype=self.amp_dtype):
+                loss_dict = self.model(data)
+        else:
+            loss_dict = self.model(data)
         losses = sum(loss_dict.values())
         losses.backward()
-        if self.world > 1:  # single RCCL all-reduce of the side-branch gradients
+        if self.world > 1 or self.always_reduce:  # single RCCL all-reduce of the side-branch gradients
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)
         if self.clip_max_norm is not None:
