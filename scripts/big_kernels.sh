@@ -4,7 +4,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/kt_big
 min=${1:-25}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro > /dev/null 2>&1
 python3 - "$out" "$min" <<'PY'
 import csv, glob, sys, re, collections
 rows = []

@@ -9,7 +9,7 @@ out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command (fewer steps: the trace inflates host time)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro > $out/bench_under_rocprof.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, re
 out = sys.argv[1]
@@ -19,7 +19,7 @@ for f in glob.glob(out + "/bench_trace/**/*kernel_stats.csv", recursive=True):
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(out + "/bench_kernel_stats.txt", "w") as fh:
-    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline\n")
+    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro\n")
     fh.write("total kernel time %.1f ms over %d kernel names (13 steps incl. warm-up)\n" % (tot / 1e6, len(rows)))
     fh.write("%7s %11s %8s %12s  %s\n" % ("share", "total_ms", "calls", "avg_us", "kernel"))
     for r in rows[:60]:

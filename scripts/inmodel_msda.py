@@ -21,14 +21,19 @@ def hook(value, sh, st, loc, attn, go, step):
     key = "enc" if loc.shape[1] == value.shape[1] else "dec"
     captured.setdefault(key, []).append([t.detach().clone() for t in (value, sh, st, loc, attn, go)])
     return orig_b(value, sh, st, loc, attn, go, step)
-for i in range(3):
-    if i == 2:
+cap_step = int(os.environ.get("ZIRA_CAPTURE_STEP", "2"))
+for i in range(cap_step + 1):
+    if i == cap_step:
         _C.ms_deform_attn_backward = hook
     trainer.run_step(data)
 _C.ms_deform_attn_backward = orig_b
 torch.cuda.synchronize()
 if os.environ.get("ZIRA_SAVE_INPUTS"):
-    torch.save({k: [t.cpu() for t in c[0]] for k, c in captured.items()}, os.environ["ZIRA_SAVE_INPUTS"])
+    out = {k: [t.cpu() for t in c[0]] for k, c in captured.items()}
+    if os.environ.get("ZIRA_SAVE_ALL_DEC"):      # every decoder layer's call (backward order: last layer first)
+        for i, c in enumerate(captured["dec"][1:], 1):
+            out["dec%d" % i] = [t.cpu() for t in c]
+    torch.save(out, os.environ["ZIRA_SAVE_INPUTS"])
     if os.environ.get("ZIRA_SAVE_ONLY"):
         sys.exit(0)
 for key, calls in captured.items():

@@ -39,7 +39,7 @@ def main():
     if os.environ.get("ZIRA_INPUTS"):  # MSDA inputs captured from a model step (scripts/inmodel_msda.py)
         for key, t in torch.load(os.environ["ZIRA_INPUTS"]).items():
             t = [x.to(dev) for x in t]
-            cfgs.append(("inmodel_" + key, tuple(t), t[3].shape[1], 200 if key == "dec" else 20))
+            cfgs.append(("inmodel_" + key, tuple(t), t[3].shape[1], 20 if key == "enc" else 200))
     only = os.environ.get("CASES")
     for name, (v, sh, st, loc, attn, go), Q, iters in cfgs:
         if only and not any(o in name for o in only.split(",")):

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_msda_cases, load_npz
+from conftest import GOLDEN, golden_msda_cases, load_npz
 
 pytestmark = pytest.mark.gpu
 
@@ -69,7 +69,8 @@ def test_hip_matches_reference_golden(path):
     _close(gl, ref_gl, tol, "grad_sampling_loc")
 
 
-def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1, clustered=False, hot=False):
+def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1, clustered=False, hot=False,
+                 inmodel=False):
     rng = np.random.default_rng(seed)
     L = len(shapes)
     S = sum(h * w for h, w in shapes)
@@ -77,7 +78,8 @@ def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1,
     if hot:  # every query looks at one of three spots: a few tiles receive thousands of entries
         spots = rng.uniform(0.2, 0.8, (3, 2))
         centre = spots[rng.integers(0, 3, (B, Q))][:, :, None, None, None, :]
-        loc = (centre + 0.01 * rng.standard_normal((B, Q, M, L, P, 2))).astype(dtype)
+        # hot == 2: exactly AT the spots -- a dozen grad_value rows per head and level take all entries
+        loc = (centre + (0.01 if hot == 1 else 0.0) * rng.standard_normal((B, Q, M, L, P, 2))).astype(dtype)
     elif clustered:  # decoder-like: box centre + small offsets
         centre = rng.uniform(0.1, 0.9, (B, Q, 1, 1, 1, 2))
         loc = (centre + 0.05 * rng.standard_normal((B, Q, M, L, P, 2))).astype(dtype)
@@ -86,6 +88,11 @@ def _random_case(B, Q, M, D, shapes, P, seed, dtype=np.float32, lo=-0.1, hi=1.1,
     logits = rng.standard_normal((B, Q, M, L * P))
     attn = np.exp(logits - logits.max(-1, keepdims=True))
     attn = (attn / attn.sum(-1, keepdims=True)).reshape(B, Q, M, L, P).astype(dtype)
+    if inmodel:  # sampling locations / attention weights captured from a training step of the full-size model
+        # at random init (last decoder layer, scripts/inmodel_msda.py): 8 % of the backward's tiles are heavy
+        with np.load(os.path.join(GOLDEN, "inmodel_decoder_locations.npz")) as z:
+            loc, attn = z["loc"].astype(dtype), z["attn"].astype(dtype)
+        assert loc.shape == (B, Q, M, L, P, 2)
     go = rng.standard_normal((B, Q, M * D)).astype(dtype)
     sh = np.asarray(shapes, dtype=np.int64)
     start = np.concatenate([[0], np.cumsum(sh[:, 0] * sh[:, 1])[:-1]]).astype(np.int64)
@@ -109,7 +116,10 @@ CASES = [
     ("northstar_decoder", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(lo=0.0, hi=1.0)),
     ("northstar_clustered", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(clustered=True)),
     ("northstar_hot_tiles", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(hot=True)),
+    ("northstar_pinpoint", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(hot=2)),
+    ("northstar_inmodel", 2, 900, 8, 32, NORTH_STAR_SHAPES, 4, dict(inmodel=True)),
     ("d16_hot_tiles", 2, 700, 8, 16, [(40, 61), (20, 31)], 4, dict(hot=True)),
+    ("d64_pinpoint", 1, 700, 4, 64, [(40, 61), (20, 31)], 4, dict(hot=2)),
     ("d64_hot_tiles", 1, 700, 4, 64, [(40, 61), (20, 31)], 4, dict(hot=True)),
     ("oob_heavy", 2, 333, 8, 32, [(20, 31), (10, 16), (5, 8), (3, 4)], 4, dict(lo=-0.5, hi=1.5)),
     ("lp_not_16", 3, 57, 4, 32, [(12, 9), (6, 5), (3, 3), (2, 2), (1, 1)], 5, {}),
