@@ -169,6 +169,26 @@ int zira_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta
 int zira_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
                            const float *rstd, int64_t rows, int C, float *dx, void *stream);
 
+/* ---- Batched linear sum assignment (Hungarian matching) -------------------------------------
+ * Replaces the per-image scipy.optimize.linear_sum_assignment calls of
+ * groundingdino/models/GroundingDINO/matcher/matcher.py:105-151 (HungarianMatcher.forward: `C.cpu()`
+ * followed by one scipy call per image), for `nsets` prediction sets at once.
+ *   cost   [nsets, B, Q, Ttot] float32, device: image b's targets are columns meta[b] .. meta[b+1]-1
+ *   meta   [2 * (B + 1)] int32, device: target-column offsets, then match offsets
+ *          (moff[b+1] - moff[b] = min(Q, n_b)); Tmax = largest n_b, Mtot = moff[B]
+ *   q_idx, t_idx [nsets, Mtot] int64, device: scipy's (row_ind, col_ind) of image b at
+ *          [moff[b], moff[b+1]); t_global != 0 adds meta[b] to col_ind (index into the concatenated targets)
+ *   status optional int32 on the device, OR-ed with 1 when a cost matrix is infeasible (inf / NaN:
+ *          scipy raises ValueError there); never cleared by the call
+ * Same assignment as scipy for the same float32 costs, ties included.  Nothing is copied to the host.
+ * zira_lsap_workspace_bytes() is 0 while the per-problem state fits in LDS (max(Q, Tmax) <~ 2000). */
+size_t zira_lsap_workspace_bytes(int nsets, int B, int Q, int Tmax);
+
+int zira_lsap_f32(const float *cost, int nsets, int B, int Q, int Ttot, int Tmax, const int32_t *meta,
+                  int64_t *q_idx, int64_t *t_idx, int Mtot, int t_global, int32_t *status, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -230,6 +230,30 @@ def test_criterion_and_matcher(dev):
     close(gl, g["grad_pred_logits"], TOL, "grad logits")
     close(gb, g["grad_pred_boxes"], TOL, "grad boxes")
 
+    # the step's path: all sets stacked; on the GPU the assignments are solved on the device (no scipy call)
+    aux = out["aux_outputs"]
+    logits = torch.stack([a["pred_logits"] for a in aux] + [out["pred_logits"], out["enc_outputs"]["pred_logits"]])
+    boxes = torch.stack([a["pred_boxes"] for a in aux] + [out["pred_boxes"], out["enc_outputs"]["pred_boxes"]])
+    suffixes = ["_%d" % i for i in range(len(aux))] + ["", "_enc"]
+    if dev == "cuda":
+        import scipy.optimize as so
+        import ziragroundingdino_amd.matcher as zm
+
+        def no_scipy(*a, **k):
+            raise AssertionError("linear_sum_assignment called on the GPU path")
+        orig, zm.linear_sum_assignment = zm.linear_sum_assignment, no_scipy
+    try:
+        fast, fidx = crit(dict(out, stacked=(logits, boxes, suffixes)), g["targets"], return_indices=True)
+    finally:
+        if dev == "cuda":
+            zm.linear_sum_assignment = orig
+    same(fidx["indices"], g["indices"]["indices"])
+    for a, b in zip(fidx["aux_outputs"], g["indices"]["aux_outputs"]):
+        same(a, b)
+    same(fidx["enc_outputs"][0], g["indices"]["enc_outputs"][0])
+    for k in fast:
+        close(fast[k], g["losses"][k], TOL, "stacked " + k)
+
 
 @pytest.mark.parametrize("dev", DEVICES)
 def test_bi_attention_block(dev):
@@ -377,11 +401,15 @@ def test_stacked_criterion_equals_per_set_loop(dev):
     loop, loop_idx = crit(out, targets, return_indices=True)
     fast, fast_idx = crit(dict(out, stacked=(logits, boxes, suffixes)), targets, return_indices=True)
     assert set(loop) == set(fast) and len(fast) == 21
+    # (on the GPU the fast path's assignments come from the device-side solver, the loop's from scipy)
     for (a, b), (c_, d) in zip(loop_idx["indices"] + loop_idx["enc_outputs"][0], fast_idx["indices"] + fast_idx["enc_outputs"][0]):
-        assert torch.equal(a, c_) and torch.equal(b, d)
+        assert torch.equal(a.cpu(), c_.cpu()) and torch.equal(b.cpu(), d.cpu())
     for la, fa in zip(loop_idx["aux_outputs"], fast_idx["aux_outputs"]):
         for (a, b), (c_, d) in zip(la, fa):
-            assert torch.equal(a, c_) and torch.equal(b, d)
+            assert torch.equal(a.cpu(), c_.cpu()) and torch.equal(b.cpu(), d.cpu())
+    if dev == "cuda":
+        assert all(i.is_cuda for pair in fast_idx["indices"] for i in pair)
+        crit.matcher.check()
     for k in loop:
         close(fast[k], loop[k], 1e-6, k)
     w = crit.weight_dict

@@ -17,6 +17,7 @@ SYMBOLS = (
     "zira_xty_workspace_floats", "zira_xty_f32",
     "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32",
+    "zira_lsap_workspace_bytes", "zira_lsap_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -70,6 +71,10 @@ def load():
     lib.zira_layernorm_fwd_f32.restype = i
     lib.zira_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, i, vp, vp]
     lib.zira_layernorm_bwd_f32.restype = i
+    lib.zira_lsap_workspace_bytes.argtypes = [i, i, i, i]
+    lib.zira_lsap_workspace_bytes.restype = sz
+    lib.zira_lsap_f32.argtypes = [vp, i, i, i, i, i, vp, vp, vp, i, i, vp, vp, sz, vp]
+    lib.zira_lsap_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

@@ -114,6 +114,23 @@ class TwoStageCriterion(SetCriterion):
                          alpha, gamma)
         self.two_stage_binary_cls = two_stage_binary_cls
 
+    _index_cache = {}
+
+    @classmethod
+    def _set_and_image_index(cls, S, sizes, Q, dev):
+        """(set index, image index) of every matched pair in the device solver's [S, M] layout -- known from
+        the shapes alone (min(Q, targets) pairs per image), built once per combination of target counts."""
+        key = (S, tuple(sizes), Q, str(dev))
+        hit = cls._index_cache.get(key)
+        if hit is None:
+            per_image = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor([min(n, Q) for n in sizes]))
+            M = per_image.numel()
+            s_i = torch.arange(S).repeat_interleave(M)
+            if len(cls._index_cache) > 256:
+                cls._index_cache.clear()
+            hit = cls._index_cache[key] = (s_i.to(dev), per_image.repeat(S).to(dev))
+        return hit
+
     def _forward_stacked(self, outputs, targets, return_indices):
         """All prediction sets of the step at once.  ``outputs["stacked"]`` = (logits [S, B, Q, C],
         boxes [S, B, Q, 4], suffixes) as the model's heads produce them: one cost computation and
@@ -123,25 +140,32 @@ class TwoStageCriterion(SetCriterion):
         logits, boxes, suffixes = outputs["stacked"]
         S, B, Q, C = logits.shape
         dev = logits.device
-        all_indices = self.matcher.forward_stacked(logits, boxes, targets)
-        num_boxes = self._num_boxes({"pred_logits": logits}, targets)
-
         sizes = [len(t["labels"]) for t in targets]
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
-        s_idx, b_idx, q_idx, t_idx, counts = [], [], [], [], []
-        for s, per_image in enumerate(all_indices):
-            n_s = 0
-            for b, (src, tgt) in enumerate(per_image):
-                s_idx.append(torch.full_like(src, s))
-                b_idx.append(torch.full_like(src, b))
-                q_idx.append(src)
-                t_idx.append(tgt + offs[b])
-                n_s += len(src)
-            counts.append(n_s)
-        idx = torch.stack([torch.cat(s_idx), torch.cat(b_idx), torch.cat(q_idx), torch.cat(t_idx)]).to(dev)
-        s_i, b_i, q_i, t_i = idx[0], idx[1], idx[2], idx[3]
+        if logits.is_cuda and hasattr(self.matcher, "forward_stacked_device"):
+            # assignments solved on the device: no copy to the host, no synchronisation
+            q_dev, t_dev = self.matcher.forward_stacked_device(logits, boxes, targets)
+            s_i, b_i = self._set_and_image_index(S, sizes, Q, dev)
+            q_i, t_i = q_dev.reshape(-1), t_dev.reshape(-1)
+            counts = [q_dev.shape[1]] * S
+            all_indices = None
+        else:
+            all_indices = self.matcher.forward_stacked(logits, boxes, targets)
+            s_idx, b_idx, q_idx, t_idx, counts = [], [], [], [], []
+            for s, per_image in enumerate(all_indices):
+                n_s = 0
+                for b, (src, tgt) in enumerate(per_image):
+                    s_idx.append(torch.full_like(src, s))
+                    b_idx.append(torch.full_like(src, b))
+                    q_idx.append(src)
+                    t_idx.append(tgt + offs[b])
+                    n_s += len(src)
+                counts.append(n_s)
+            idx = torch.stack([torch.cat(s_idx), torch.cat(b_idx), torch.cat(q_idx), torch.cat(t_idx)]).to(dev)
+            s_i, b_i, q_i, t_i = idx[0], idx[1], idx[2], idx[3]
+        num_boxes = self._num_boxes({"pred_logits": logits}, targets)
         labels_all = torch.cat([t["labels"] for t in targets])
         boxes_all = torch.cat([t["boxes"] for t in targets])
 
@@ -178,6 +202,12 @@ class TwoStageCriterion(SetCriterion):
                 losses["loss_bbox" + suf] = l1_s[s]
                 losses["loss_giou" + suf] = giou_s[s]
         if return_indices:
+            if all_indices is None:   # device path: per set and image (query_idx, target_idx) views, still on the device
+                moff = [0]
+                for n in sizes:
+                    moff.append(moff[-1] + min(n, Q))
+                all_indices = [[(q_dev[s, moff[b]:moff[b + 1]], t_dev[s, moff[b]:moff[b + 1]] - offs[b])
+                                for b in range(B)] for s in range(S)]
             by = dict(zip(suffixes, all_indices))
             return losses, {"indices": by.get(""), "aux_outputs": [by[k] for k in suffixes if k not in ("", "_enc")],
                             "enc_outputs": [by["_enc"]] if "_enc" in by else []}

@@ -2,9 +2,11 @@
 groundingdino/models/GroundingDINO/matcher/matcher.py:27-151; ``build_matcher`` uses the
 defaults, i.e. weights 1/1/1, matcher/__init__.py:20-21).
 
-The assignment itself is scipy's ``linear_sum_assignment`` (rectangular Jonker-Volgenant), as
-in the reference, on a single device->host copy of the whole batch's cost matrix; the index
-results are therefore bit-identical whenever the cost matrix is.
+On GPU tensors the criterion uses ``forward_stacked_device``: the assignments of all prediction sets
+are solved on the device (csrc/lsap.hip, scipy's algorithm and tie-breaking) and nothing is copied to
+the host.  The host paths (``forward`` / ``forward_many`` / ``forward_stacked``) keep scipy's
+``linear_sum_assignment`` on one device->host copy, as in the reference; the index results are
+bit-identical whenever the cost matrix is.
 """
 import torch
 import torch.nn as nn
@@ -72,6 +74,37 @@ class HungarianMatcher(nn.Module):
             results.append([(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64))
                             for i, j in indices])
         return results
+
+    @torch.no_grad()
+    def forward_stacked_device(self, logits, boxes, targets):
+        """``forward_stacked`` without leaving the GPU: the S*B assignments are solved by the device-side
+        solver (csrc/lsap.hip: scipy's algorithm and tie-breaking, one wavefront per problem), so the
+        criterion has no device->host copy and no host synchronisation left.  Returns
+        (q_idx, t_idx) int64 ``[S, M]`` device tensors, M = sum over images of min(Q, targets): set s
+        matches query ``q_idx[s, k]`` of image ``image_of[k]`` with target ``t_idx[s, k]`` of the
+        CONCATENATED targets.  The xyxy-order assertion of ``generalized_box_iou`` (a host sync of its own
+        in the reference) is kept as a device flag: ``check()`` raises if it ever failed."""
+        from .lsap import linear_sum_assignment_batched
+
+        S, B, Q = logits.shape[:3]
+        flat = {"pred_logits": logits.reshape(1, S * B * Q, -1), "pred_boxes": boxes.reshape(1, S * B * Q, 4)}
+        C, ok = self.cost_matrix(flat, targets, check=False)
+        bad = getattr(self, "_bad_boxes", None)
+        self._bad_boxes = ~ok if bad is None or bad.device != ok.device else bad | ~ok
+        sizes = [len(v["boxes"]) for v in targets]
+        return linear_sum_assignment_batched(C.view(S, B, Q, -1), sizes, global_targets=True)
+
+    def check(self):
+        """Raise if a prediction / target box of any device-side matching so far was not in xyxy order, or a
+        cost matrix was infeasible (the reference asserts / scipy raises on the spot; this reads two flags
+        back and therefore synchronises -- call it at the end of a task, not in the step)."""
+        from .lsap import infeasible
+
+        bad = getattr(self, "_bad_boxes", None)
+        if bad is not None:
+            assert not bool(bad), "boxes not in xyxy order"
+            if infeasible(bad.device):
+                raise ValueError("cost matrix is infeasible")
 
     @torch.no_grad()
     def forward(self, outputs, targets):
