@@ -292,8 +292,13 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--transformer-graph", action="store_true",
-                    help="replay encoder / decoder layers from hipGraphs (opt-in; same kernels, ~half the host time)")
+    ap.add_argument("--no-transformer-graph", dest="transformer_graph", action="store_false",
+                    help="launch the transformer's kernels eagerly instead of replaying encoder / decoder layers from "
+                         "hipGraphs (same kernels either way; eager, the step time follows the host's jitter)")
+    ap.add_argument("--transformer-graph", dest="transformer_graph", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(transformer_graph=True)
+    ap.add_argument("--kernel-timing-steps", type=int, default=4,
+                    help="eager steps after the timed region with HIP events around every MSDA call (roofline.kernels)")
     ap.add_argument("--cpu-sample-div", type=int, default=1,
                     help="cpu_baseline runs one step on an image with sides divided by this")
     ap.add_argument("--backbone", default="swin_T_224_1k",
@@ -323,6 +328,8 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
+    if args.dtype == "bf16":   # make_graphed_callables under autocast needs its weight-cast cache off: stay eager
+        args.transformer_graph = False
     model.use_transformer_graph = args.transformer_graph
     trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard
@@ -343,6 +350,21 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     records, _C.TIMING = _C.TIMING, None
+    timing_source = "HIP events around every native MSDA call of the timed steps"
+    if args.transformer_graph and args.kernel_timing_steps > 0:   # (every rank: the steps hold collectives)
+        # graph replays hide the launches from event timing: the same step, launched eagerly, right after
+        model.use_transformer_graph = False
+        trainer.run_step(data)
+        torch.cuda.synchronize()
+        _C.TIMING = []
+        for _ in range(args.kernel_timing_steps):
+            trainer.run_step(data)
+        torch.cuda.synchronize()
+        records, _C.TIMING = _C.TIMING, None
+        model.use_transformer_graph = True
+        timing_source = ("HIP events around every native MSDA call of %d eager steps run right after the timed "
+                         "region (its steps replay the transformer from hipGraphs, which hides the launches)"
+                         % args.kernel_timing_steps)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,18 +372,19 @@ def main():
 
     if rank == 0:
         groups = summarize_timing(records, args.batch)
+        timed_steps = args.kernel_timing_steps if (args.transformer_graph and args.kernel_timing_steps > 0) else args.steps
         kernels = {}
         for key, (calls, avg_s, dims) in sorted(groups.items()):
             fb, bb = msda_algorithmic_bytes(*dims)
             nbytes = fb if key.startswith("fwd") else bb
-            kernels[key] = {"calls_per_step": calls / args.steps, "avg_us": avg_s * 1e6,
+            kernels[key] = {"calls_per_step": calls / timed_steps, "avg_us": avg_s * 1e6,
                             "algorithmic_bytes": nbytes, "achieved": nbytes / avg_s / 1e9,
                             "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
-                            "share_of_step": calls * avg_s / elapsed,
+                            "share_of_step": (calls / timed_steps) * avg_s / (elapsed / args.steps),
                             "dims_BSMDLQP": list(dims)}
         dominant = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                    "kernels": kernels, "dominant": dominant}
+                    "kernels": kernels, "dominant": dominant, "timing_source": timing_source}
         pmc = pmc_traffic()
         if pmc:
             roofline.update(pmc)

@@ -186,7 +186,8 @@ class GraphedTransformer:
     graph_encoder = True   # class-level switches: which pieces are graphed (developer bisection)
     graph_decoder = True
     graph_fusion = False     # True: each fusion block replays from its own graph pair as well (300-step soak passes; no faster: the step is GPU-bound by then)
-    graph_selection = True   # False: two-stage query selection runs eagerly (with torch.topk), decoder layers graphed
+    graph_selection = False  # two-stage query selection runs eagerly with torch.topk -- the indices the eager path and the
+                             # reference pick, ties included; True: inside the decoder's graph, as the first k of a stable sort
 
     def __init__(self, transformer, max_signatures=2):
         self.transformer = transformer
@@ -196,7 +197,8 @@ class GraphedTransformer:
     def __call__(self, srcs, masks, poss, text_dict, no_padding=False):
         t = self.transformer
         key = (tuple((tuple(x.shape), x.requires_grad) for x in srcs),
-               tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad, bool(no_padding))
+               tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad, bool(no_padding),
+               torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))   # a capture bakes the dtype path in
         if key not in self._cache and len(self._cache) >= self.max_signatures:
             hs, refs, hs_enc, ref_enc, init_box, _ = t(srcs, masks, None, poss, None, None, text_dict,
                                                        no_padding=no_padding)
