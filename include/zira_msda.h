@@ -63,16 +63,20 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
                       float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                       void *stream);
 
-/* Sorted ("tiled") float32 backward: same results up to summation order, 2-6x faster than the
- * plain entry point (no fp32 atomics on the common path).
+/* Sorted float32 backward: same results up to summation order, 2-6x faster than the plain entry
+ * point (no fp32 atomics on the common path).  Dense calls (B*M*Q >= 65536: encoder self-attention,
+ * every pixel a query) take the cell walk -- samples binned by the 2x2 pixel block they touch, tiles
+ * walked with the window's accumulators in registers, three kernels, bit-stable from run to run --,
+ * sparse calls (decoder cross-attention) the entry sort -- per-block counting sort of corner
+ * contributions, per-tile row sums, and a short launch that adds the slices of overfull tiles with
+ * fp32 atomics.
  * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions
- * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 347 MB at Q=S), or 0 when that path does
+ * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 692 MB at Q=S), or 0 when that path does
  * not apply (the plain entry point is then the only one).  The workspace is caller-owned
  * DEVICE memory, 16-byte aligned, needs no initialisation and may be reused by later calls
  * on the same stream; with workspace == NULL or too small the call degrades to
- * zira_msda_bwd_f32.  Two or three kernels are enqueued on `stream` (sort by tile, reduce
- * tiles, and for sparse calls a short launch that adds the slices of overfull tiles with
- * fp32 atomics); every element of grad_value is written by them, it is never pre-zeroed.
+ * zira_msda_bwd_f32.  Every element of grad_value, grad_sampling_loc and grad_attn_weight is
+ * written by the call, none needs pre-zeroing.
  * Extra precondition: the levels tile [0, S) exactly (level_start_index[l] + H_l*W_l ==
  * level_start_index[l+1], last one == S), which the reference module asserts
  * (ms_deform_attn.py:284). */

@@ -2145,8 +2145,8 @@ const char *zira_msda_variant_f32(int D)
     // D = 16 / 32 / 64 take the lean kernels (and, with a workspace, the tiled backward) whenever
     // the call passes lean_ok(); the other specialised widths use the row-per-group kernels
     if (D == 16 || D == 32 || D == 64)
-        return "fwd msda_fwd_lean; bwd msda_bwd_items + msda_bwd_tiles[_wave] (atomic-free, workspace) "
-               "or msda_bwd_lean_atomic";
+        return "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_walk + msda_bwd_fold (dense calls) / "
+               "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic";
     switch (lpr_for(D)) {
         case 1: return "rows<1>";
         case 2: return "rows<2>";
