@@ -122,6 +122,37 @@ def gen_rsb(ref):
             out_eval=out_eval.detach(), zl_eval=zl_eval.detach(), state_after_rep=sd(conv)))
 
 
+def gen_rsb_multilayer(ref):
+    """The multilayer-branch ablation's modules (groundingdino_dual_zero_rep_multilayer_branch.py:62-226)."""
+    g = torch.Generator().manual_seed(21)
+    Z = ref["groundingdino_dual_zero_rep_multilayer_branch"]
+
+    def record(mod, x, zl_weight, **extra):
+        init = sd(mod)
+        randomize_(mod, g, 0.4)
+        mod.train()
+        out, zl = mod(x)
+        go = torch.randn(out.shape, generator=g)
+        total = (out * go).sum() + zl_weight * zl
+        params = dict(mod.named_parameters())
+        grads = torch.autograd.grad(total, [x] + list(params.values()))
+        mod.eval()
+        out_eval, zl_eval = mod(x)
+        before = sd(mod)
+        mod.__rep__()
+        return dict(init_state=init, state=before, x=x.detach(), out=out.detach(), zl=zl.detach(), grad_out=go,
+                    zl_weight=zl_weight, grad_x=grads[0], grad_params=dict(zip(params.keys(), grads[1:])),
+                    out_eval=out_eval.detach(), zl_eval=zl_eval.detach(), state_after_rep=sd(mod), **extra)
+
+    x = (torch.randn(2, 7, 24, generator=g) * 3).requires_grad_(True)
+    save("ml_rep_zero_linear", record(Z.RepZeroLinear(24, 16), x, 0.7))
+    for name, kw in (("1x1", dict(kernel_size=1)), ("3x3s2", dict(kernel_size=3, stride=2, padding=1))):
+        x = (torch.randn(2, 12, 9, 11, generator=g) * 2).requires_grad_(True)
+        save("ml_rep_zero_conv_gn_" + name, record(Z.RepZeroConv2dGN(12, 32, **kw), x, 1.3, kwargs=kw))
+    x = torch.randn(9, 2, 32, generator=g).requires_grad_(True)
+    save("ml_rep_zero_transformer_layer", record(Z.RepZeroTransformerLayer(32, nhead=4, down_dim=48, output_dim=16), x, 0.9))
+
+
 def fake_tokens(gen, bs, caps):
     """input_ids in BERT style: [CLS]=101 words... '.'=1012 ... [SEP]=102, right-padded with 0."""
     rows = []
@@ -359,6 +390,7 @@ def main():
     ref = ref_import.load()
     gen_msda_module(ref)
     gen_rsb(ref)
+    gen_rsb_multilayer(ref)
     gen_text_and_logits(ref)
     gen_criterion(ref)
     gen_encoder_neighbours(ref)

@@ -66,5 +66,6 @@ def load():
         sys.modules[pkg] = m
     base = "groundingdino.models.GroundingDINO."
     names = ("ms_deform_attn", "transformer_for_adapter", "groundingdino_dual_zero_rep_branch",
-             "criterion", "utils", "bertwarper", "fuse_modules", "transformer_vanilla")
+             "groundingdino_dual_zero_rep_multilayer_branch", "criterion", "utils", "bertwarper", "fuse_modules",
+             "transformer_vanilla")
     return {n: importlib.import_module(base + n) for n in names}

@@ -561,3 +561,77 @@ def test_sampling_locations_addcdiv_is_bit_identical_on_cpu():
         m.FUSED_LOCATIONS = True
     assert torch.equal(outs[0], outs[1])
     assert torch.allclose(grads[0], grads[1], rtol=1e-6, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------
+# multilayer-branch ablation (reference groundingdino_dual_zero_rep_multilayer_branch.py:62-226)
+def _check_branch_module(mod, g, dev, tol=TOL):
+    assert set(mod.state_dict()) == set(g["init_state"])
+    for k, v in mod.state_dict().items():           # constructor contract (deterministic parts)
+        if "freeze" in k or k == "scaling" or k.startswith("free_") or k == "weight":
+            if not ("freeze_self_attn" in k or "freeze_linear1" in k or "freeze_norm" in k):
+                close(v, g["init_state"][k], 1e-7, "init " + k)
+    mod.load_state_dict(g["state"])
+    mod.to(dev).train()
+    x = g["x"].clone().requires_grad_(True)
+    out, zl = mod(x)
+    close(out, g["out"], tol, "out")
+    close(zl, g["zl"], tol, "zero-interference loss")
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad((out * g["grad_out"]).sum() + g["zl_weight"] * zl, [x] + list(params.values()))
+    close(grads[0], g["grad_x"], tol, "grad x")
+    for (k, _), gr in zip(params.items(), grads[1:]):
+        close(gr, g["grad_params"][k], tol, "grad " + k)
+    mod.eval()
+    out_eval, zl_eval = mod(x)
+    close(out_eval, g["out_eval"], tol, "eval out")
+    assert float(zl_eval) == 0.0
+    mod.__rep__()
+    for k, v in mod.state_dict().items():
+        close(v, g["state_after_rep"][k], tol, "after __rep__ " + k)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_multilayer_branch_modules(dev):
+    from ziragroundingdino_amd import rsb_multilayer as ml
+
+    _check_branch_module(ml.RepZeroLinear(24, 16), to(load("ml_rep_zero_linear"), dev), dev)
+    for name in ("1x1", "3x3s2"):
+        g = to(load("ml_rep_zero_conv_gn_" + name), dev)
+        conv = ml.RepZeroConv2dGN(12, 32, **g["kwargs"])
+        assert torch.all(conv.freeze_gn.weight == 1e-8) and torch.all(conv.freeze_gn.bias == 1e-8)
+        _check_branch_module(conv, g, dev)
+    _check_branch_module(ml.RepZeroTransformerLayer(32, nhead=4, down_dim=48, output_dim=16),
+                         to(load("ml_rep_zero_transformer_layer"), dev), dev)
+
+
+def test_multilayer_branch_model_wiring():
+    """Registry name, state-dict names and loss keys of the ablation model (reference :322-323, :384-391, :575-576,
+    :665-668): the language branch is ``rep_language_adapter`` / ``loss_language_adapter``, every conv branch carries a
+    ``freeze_gn`` that trains (its name contains "adapter") with the 0.2 learning-rate factor ("freeze")."""
+    from ziragroundingdino_amd.groundingdino import MODULE_BUILD_FUNCS
+    from ziragroundingdino_amd.train import lr_factor
+    from test_train_step import build_slice_model, run_slice_step, slice_inputs
+    from ziragroundingdino_amd.groundingdino import GroundingDINO
+
+    assert "dualzerorepmultilayerbranchgroundingdino" in MODULE_BUILD_FUNCS
+    g = torch.load(os.path.join(GOLDEN, "step_zira_slice.pt"), weights_only=False)
+
+    class Variant(GroundingDINO):
+        def __init__(self, *a, **k):
+            super().__init__(*a, side_branch="multilayer", **k)
+
+    model = build_slice_model(g, "cpu", Variant)
+    names = set(model.state_dict())
+    assert "rep_language_adapter.freeze_linear.weight" in names and "rep_linear_adapter.weight" not in names
+    assert "input_proj_conv_adapter.3.freeze_gn.weight" in names
+    model.before_train()
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert all("adapter" in n for n in trainable) and "input_proj_conv_adapter.0.freeze_gn.bias" in trainable
+    assert lr_factor("input_proj_conv_adapter.0.freeze_gn.bias") == 0.2
+    losses = run_slice_step(model, *slice_inputs(g, model, "cpu"))
+    assert "loss_language_adapter" in losses and "loss_conv_adapter" in losses and "loss_linear_adapter" not in losses
+    sum(losses.values()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if p.requires_grad)
+    model.after_train()
+    assert float(model.rep_language_adapter.scaling.detach()) == 1.0

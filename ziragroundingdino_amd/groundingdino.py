@@ -78,7 +78,7 @@ class GroundingDINO(nn.Module):
                  use_cls_linear=False, use_prompt_tuning=False, use_prompt_memory_output=True,
                  use_project_tuning=False, use_project_adapter=True,
                  use_zero_inter_loss_for_conv=True, use_learned_names=False,
-                 bert=None, tokenizer=None, **_unused):
+                 bert=None, tokenizer=None, side_branch="rep", **_unused):
         super().__init__()
         assert query_dim == 4 and iter_update, "GroundingDINO uses 4-d queries with iterative update"
         assert not use_cls_linear, "use_cls_linear (linear probing ablation) is outside the ZiRa path"
@@ -113,8 +113,19 @@ class GroundingDINO(nn.Module):
         self.use_prompt_tuning = use_prompt_tuning
         self.use_learned_names = use_learned_names
         self.use_prompt_memory_output = use_prompt_memory_output
-        if use_cet:  # RSB #1: language side branch beside feat_map
-            self.rep_linear_adapter = RepZeroLinear(self.bert.config.hidden_size, hidden_dim)
+        # "rep": the ZiRa model (groundingdino_dual_zero_rep_branch.py); "multilayer": its multilayer-branch
+        # ablation (groundingdino_dual_zero_rep_multilayer_branch.py, rsb_multilayer.py)
+        assert side_branch in ("rep", "multilayer")
+        self.side_branch = side_branch
+        if side_branch == "multilayer":  # unconditional language branch, its own name (reference :322-323)
+            from . import rsb_multilayer
+
+            self.rep_language_adapter = rsb_multilayer.RepZeroLinear(self.bert.config.hidden_size, hidden_dim)
+            conv_branch = rsb_multilayer.RepZeroConv2dGN
+        else:
+            conv_branch = RepZeroConv2d
+            if use_cet:  # RSB #1: language side branch beside feat_map
+                self.rep_linear_adapter = RepZeroLinear(self.bert.config.hidden_size, hidden_dim)
         self.specical_tokens = self.tokenizer.convert_tokens_to_ids(["[CLS]", "[SEP]", ".", "?"])
 
         # input projections (frozen) and RSB #2: one zero-initialised conv branch beside each
@@ -124,16 +135,16 @@ class GroundingDINO(nn.Module):
         if num_feature_levels > 1:
             for c in chans:
                 proj.append(nn.Sequential(nn.Conv2d(c, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
-                adapters.append(RepZeroConv2d(c, hidden_dim, kernel_size=1))
+                adapters.append(conv_branch(c, hidden_dim, kernel_size=1))
             for _ in range(num_feature_levels - len(chans)):
                 proj.append(nn.Sequential(nn.Conv2d(in_channels, hidden_dim, kernel_size=3, stride=2, padding=1),
                                           nn.GroupNorm(32, hidden_dim)))
-                adapters.append(RepZeroConv2d(in_channels, hidden_dim, kernel_size=3, stride=2, padding=1))
+                adapters.append(conv_branch(in_channels, hidden_dim, kernel_size=3, stride=2, padding=1))
                 in_channels = hidden_dim
         else:
             assert two_stage_type == "no"
             proj.append(nn.Sequential(nn.Conv2d(chans[-1], hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
-            adapters.append(RepZeroConv2d(chans[-1], hidden_dim, kernel_size=1))
+            adapters.append(conv_branch(chans[-1], hidden_dim, kernel_size=1))
         self.input_proj = nn.ModuleList(proj)
         self.use_project_adapter = use_project_adapter
         self.use_zero_inter_loss_for_conv = use_zero_inter_loss_for_conv
@@ -238,6 +249,8 @@ class GroundingDINO(nn.Module):
         if not self.use_project_adapter:
             return self.input_proj[l][1](main), None
         branch, zero_loss = self.input_proj_conv_adapter[l](feat)
+        if self.side_branch == "multilayer":   # the branch carries its own GroupNorm (reference :575-576)
+            return self.input_proj[l][1](main) + branch, zero_loss
         return self.input_proj[l][1](main + branch), zero_loss
 
     def encode_text(self, captions, device):
@@ -284,7 +297,10 @@ class GroundingDINO(nn.Module):
         L = self.max_text_len
         encoded_text = self.feat_map(bert_hidden)
         loss_linear_adapter = None
-        if self.use_cet:
+        if self.side_branch == "multilayer":
+            rep_out, loss_linear_adapter = self.rep_language_adapter(bert_hidden)
+            encoded_text = rep_out + encoded_text
+        elif self.use_cet:
             rep_out, loss_linear_adapter = self.rep_linear_adapter(bert_hidden)
             encoded_text = rep_out + encoded_text
         if encoded_text.shape[1] > L:
@@ -429,7 +445,8 @@ class GroundingDINO(nn.Module):
             if self.use_project_adapter and self.use_zero_inter_loss_for_conv:
                 loss_dict["loss_conv_adapter"] = loss_conv_adapter * self.loss_adapter_weight
             if self.use_cet and self.use_zero_inter_loss:
-                loss_dict["loss_linear_adapter"] = loss_linear_adapter * self.loss_adapter_weight
+                key = "loss_language_adapter" if self.side_branch == "multilayer" else "loss_linear_adapter"
+                loss_dict[key] = loss_linear_adapter * self.loss_adapter_weight
             return loss_dict
         return out
 
@@ -535,7 +552,7 @@ class GroundingDINO(nn.Module):
 
 
 @MODULE_BUILD_FUNCS.registe_with_name(module_name="dualzerorepbranchgroundingdino")
-def build_dual_zero_rep_branch_groundingdino(args, bert=None, tokenizer=None):
+def build_dual_zero_rep_branch_groundingdino(args, bert=None, tokenizer=None, side_branch="rep"):
     backbone = build_backbone(args)
     transformer = build_transformer(args)
     criterion = build_criterion(args)
@@ -559,7 +576,15 @@ def build_dual_zero_rep_branch_groundingdino(args, bert=None, tokenizer=None):
         use_project_adapter=args.use_project_adapter,
         use_zero_inter_loss_for_conv=args.use_zero_inter_loss_for_conv,
         use_learned_names=args.use_learned_names, device=getattr(args, "device", "cuda"),
-        bert=bert, tokenizer=tokenizer)
+        bert=bert, tokenizer=tokenizer, side_branch=side_branch)
+
+
+@MODULE_BUILD_FUNCS.registe_with_name(module_name="dualzerorepmultilayerbranchgroundingdino")
+def build_dual_zero_rep_multi_layer_branch_groundingdino(args, bert=None, tokenizer=None):
+    """The multilayer-branch ablation (reference groundingdino_dual_zero_rep_multilayer_branch.py:971-1020):
+    same constructor arguments, other side-branch modules (rsb_multilayer.py)."""
+    model = build_dual_zero_rep_branch_groundingdino(args, bert=bert, tokenizer=tokenizer, side_branch="multilayer")
+    return model
 
 
 def build_model(args, **kw):
