@@ -188,9 +188,35 @@ int zira_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, 
  * zira_lsap_workspace_bytes() is 0 while the per-problem state fits in LDS (max(Q, Tmax) <~ 2000). */
 size_t zira_lsap_workspace_bytes(int nsets, int B, int Q, int Tmax);
 
+/* The matching cost in front of it (matcher.py:105-141 with cost_class_type "focal_loss_cost", box_ops.py:39-66):
+ *   cost[n, t] = w_bbox * |box_n - tbox_t|_1 + w_class * (pos - neg) + w_giou * (-GIoU(box_n, tbox_t))
+ * logits [N, C], boxes [N, 4] and tgt_boxes [T, 4] (cx, cy, w, h), tgt_ids [T] int64 -> cost [N, T] float32, all on
+ * the device; every product and sum rounded separately, in the order of the reference's chain of PyTorch kernels.
+ * status (optional, device int32) is OR-ed with 2 if a box has x1 < x0 or y1 < y0 (the reference asserts there). */
+int zira_match_cost_f32(const float *logits, const float *boxes, const int64_t *tgt_ids, const float *tgt_boxes,
+                        int N, int C, int T, float w_class, float w_bbox, float w_giou, float alpha, float gamma,
+                        float *cost, int32_t *status, void *stream);
+
 int zira_lsap_f32(const float *cost, int nsets, int B, int Q, int Ttot, int Tmax, const int32_t *meta,
                   int64_t *q_idx, int64_t *t_idx, int Mtot, int t_global, int32_t *status, void *workspace,
                   size_t workspace_bytes, void *stream);
+
+
+/* ---- Token logits -> category logits ---------------------------------------------------------
+ * Replaces recover_to_cls_logits (groundingdino/models/GroundingDINO/utils.py:312-320):
+ *   out[r, c] = max over the tokens t < n_tok[b] with cat_token_mask[b, c, t] of logits[r, t]   for c < n_cat[b],
+ *   for_fill elsewhere (also for a category without tokens or with -inf logits only);  b = (r / Q) % B.
+ * logits / out / grad_* [rows, T] float32 with rows a multiple of B * Q (leading dims = stacked prediction
+ * sets); cat_token_mask [B, Cmax, Tmax] uint8 (the per-image category x token masks of
+ * bertwarper.generate_masks_with_special_tokens_and_transfer_map, zero-padded); n_cat, n_tok [B] int32;
+ * argmax [rows, Cmax] int32 is written by the forward (first arg-max token, -1 = none) and read by the backward,
+ * which sends each category's gradient to that token.  Everything on the device. */
+int zira_cat_logits_fwd_f32(const float *logits, const uint8_t *cat_token_mask, const int32_t *n_cat,
+                            const int32_t *n_tok, long long rows, int B, int Q, int T, int Cmax, int Tmax,
+                            float for_fill, float *out, int32_t *argmax, void *stream);
+
+int zira_cat_logits_bwd_f32(const float *grad_out, const int32_t *argmax, const int32_t *n_cat, long long rows, int B,
+                            int Q, int T, int Cmax, float *grad_logits, void *stream);
 
 
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */

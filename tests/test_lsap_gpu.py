@@ -72,3 +72,55 @@ def test_no_targets_and_infeasible_flag():
     linear_sum_assignment_batched(bad.cuda(), [3])
     assert infeasible(torch.device("cuda", torch.cuda.current_device()), reset=True)
     assert not infeasible(torch.device("cuda", torch.cuda.current_device()))
+
+
+def test_fused_matching_cost_equals_the_pytorch_chain():
+    """zira_match_cost_f32 against HungarianMatcher.cost_matrix (the reference's chain of PyTorch ops,
+    matcher.py:105-141): the same float32 numbers to within 2e-6 (the L1 part bit for bit) and identical assignments."""
+    from ziragroundingdino_amd.lsap import bad_boxes, matching_cost
+    from ziragroundingdino_amd.matcher import HungarianMatcher
+
+    g = torch.Generator().manual_seed(3)
+    N, C, T = 3 * 900, 256, 23
+    logits = (torch.randn(N, C, generator=g) * 3).cuda()
+    boxes = torch.cat([torch.rand(N, 2, generator=g) * 0.6 + 0.2, torch.rand(N, 2, generator=g) * 0.3 + 0.01], -1).cuda()
+    tgt = [{"labels": torch.randint(0, C, (T,), generator=g).cuda(),
+            "boxes": torch.cat([torch.rand(T, 2, generator=g) * 0.5 + 0.25, torch.rand(T, 2, generator=g) * 0.3 + 0.1], -1).cuda()}]
+    m = HungarianMatcher(cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
+    want = m.cost_matrix({"pred_logits": logits[None], "pred_boxes": boxes[None]}, tgt)[0]
+    got = matching_cost(logits, boxes, tgt[0]["labels"], tgt[0]["boxes"], 2.0, 5.0, 2.0, m.alpha, m.gamma)
+    torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-6)   # (last-bit differences in exp / log / divide remain)
+    for a, b in zip(linear_sum_assignment(got.view(3, 900, T)[1].cpu().numpy()), linear_sum_assignment(want.view(3, 900, T)[1].cpu().numpy())):
+        assert np.array_equal(a, b)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    assert not bad_boxes(dev)
+    boxes[5, 2] = -0.1                      # negative width: x1 < x0
+    matching_cost(logits, boxes, tgt[0]["labels"], tgt[0]["boxes"])
+    assert bad_boxes(dev, reset=True) and not bad_boxes(dev)
+
+
+def test_category_logits_kernel_equals_pytorch_path():
+    """zira_cat_logits_{fwd,bwd}_f32 against the PyTorch formulation of recover_to_cls_logits (CPU tensors take it):
+    stacked leading dims, images with different numbers of categories / tokens, a category without tokens, a category
+    whose tokens are all -inf (padding), exact ties between two tokens of a category."""
+    from ziragroundingdino_amd.utils import recover_to_cls_logits
+
+    g = torch.Generator().manual_seed(5)
+    R, B, Q, T = 3, 2, 5, 16
+    logits = torch.randn(R, B, Q, T, generator=g)
+    logits[..., 12:] = float("-inf")                         # beyond the caption: masked token logits
+    logits[:, 0, :, 2] = logits[:, 0, :, 1]                  # a tie inside category 0 of image 0
+    m0 = torch.zeros(4, 14, dtype=torch.bool)
+    m0[0, 1:3] = True; m0[1, 4:7] = True; m0[3, 12:14] = True     # category 2: no tokens; category 3: only -inf tokens
+    m1 = torch.zeros(2, 9, dtype=torch.bool)
+    m1[0, 1] = True; m1[1, 3:8] = True
+    masks = [m0, m1]
+    go = torch.randn(R, B, Q, T, generator=g)
+    want_in = logits.clone().requires_grad_(True)
+    want = recover_to_cls_logits(want_in, masks, for_fill=-100.0)
+    (want_g,) = torch.autograd.grad(want, want_in, go)
+    got_in = logits.cuda().requires_grad_(True)
+    got = recover_to_cls_logits(got_in, [m.cuda() for m in masks], for_fill=-100.0)
+    (got_g,) = torch.autograd.grad(got, got_in, go.cuda())
+    assert torch.equal(got.cpu(), want)
+    torch.testing.assert_close(got_g.cpu(), want_g, rtol=0, atol=0)

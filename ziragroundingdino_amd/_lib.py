@@ -17,7 +17,8 @@ SYMBOLS = (
     "zira_xty_workspace_floats", "zira_xty_f32",
     "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32",
-    "zira_lsap_workspace_bytes", "zira_lsap_f32",
+    "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
+    "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -75,6 +76,14 @@ def load():
     lib.zira_lsap_workspace_bytes.restype = sz
     lib.zira_lsap_f32.argtypes = [vp, i, i, i, i, i, vp, vp, vp, i, i, vp, vp, sz, vp]
     lib.zira_lsap_f32.restype = i
+    f32 = ctypes.c_float
+    lib.zira_match_cost_f32.argtypes = [vp, vp, vp, vp, i, i, i, f32, f32, f32, f32, f32, vp, vp, vp]
+    lib.zira_match_cost_f32.restype = i
+    ll = ctypes.c_longlong
+    lib.zira_cat_logits_fwd_f32.argtypes = [vp, vp, vp, vp, ll, i, i, i, i, i, f32, vp, vp, vp]
+    lib.zira_cat_logits_fwd_f32.restype = i
+    lib.zira_cat_logits_bwd_f32.argtypes = [vp, vp, vp, ll, i, i, i, i, vp, vp]
+    lib.zira_cat_logits_bwd_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

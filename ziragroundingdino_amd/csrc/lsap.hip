@@ -165,6 +165,59 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ cost
     }
 }
 
+// ---- matching cost ------------------------------------------------------------------------------
+// cost[n, t] = w_bbox * L1(box_n, tbox_t) + w_class * (pos - neg)(sigmoid(logit[n, id_t])) + w_giou * (-GIoU)
+// (reference matcher.py:105-141, util/box_ops.py:9-66), one thread per (prediction, target).  Every
+// product and sum is rounded on its own, in the order the reference's chain of PyTorch kernels rounds
+// them (no fma contraction), so that the assignments computed from it are the reference's.
+__device__ __forceinline__ float mulr(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float addr(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float subr(float a, float b) { return __fsub_rn(a, b); }
+
+__device__ __forceinline__ float divr(float a, float b) { return a / b; }   // IEEE divide (rcp-based forms are further from ATen's)
+
+constexpr int kBadBoxes = 2;
+
+__global__ __launch_bounds__(256) void match_cost_kernel(const float *__restrict__ logits, const float *__restrict__ boxes,
+                                                         const int64_t *__restrict__ tgt_ids,
+                                                         const float *__restrict__ tgt_boxes, int N, int C, int T,
+                                                         float w_class, float w_bbox, float w_giou, float alpha,
+                                                         float gamma, float *__restrict__ cost, int *__restrict__ status)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * T) return;
+    const int n = idx / T, t = idx - n * T;
+    // classification: focal-style cost on the target's class probability
+    const float x = logits[(size_t)n * C + tgt_ids[t]];
+    const float p = divr(1.0f, addr(1.0f, expf(-x)));
+    const float q = subr(1.0f, p);
+    const float pg = gamma == 2.0f ? mulr(p, p) : powf(p, gamma);
+    const float qg = gamma == 2.0f ? mulr(q, q) : powf(q, gamma);
+    const float neg = mulr(mulr(subr(1.0f, alpha), pg), -logf(addr(q, 1e-8f)));
+    const float pos = mulr(mulr(alpha, qg), -logf(addr(p, 1e-8f)));
+    const float cost_class = subr(pos, neg);
+    // boxes: L1 on (cx, cy, w, h); GIoU on the corners
+    const float4 a = reinterpret_cast<const float4 *>(boxes)[n], b = reinterpret_cast<const float4 *>(tgt_boxes)[t];
+    const float d0 = fabsf(subr(a.x, b.x)), d1 = fabsf(subr(a.y, b.y)), d2 = fabsf(subr(a.z, b.z)), d3 = fabsf(subr(a.w, b.w));
+    const float cost_bbox = addr(addr(d0, d2), addr(d1, d3));    // the pairing of torch.cdist's shuffle reduction
+    const float ax0 = subr(a.x, mulr(0.5f, a.z)), ay0 = subr(a.y, mulr(0.5f, a.w));
+    const float ax1 = addr(a.x, mulr(0.5f, a.z)), ay1 = addr(a.y, mulr(0.5f, a.w));
+    const float bx0 = subr(b.x, mulr(0.5f, b.z)), by0 = subr(b.y, mulr(0.5f, b.w));
+    const float bx1 = addr(b.x, mulr(0.5f, b.z)), by1 = addr(b.y, mulr(0.5f, b.w));
+    if (status && (!(ax1 >= ax0) || !(ay1 >= ay0) || !(bx1 >= bx0) || !(by1 >= by0))) atomicOr(status, kBadBoxes);
+    const float area_a = mulr(subr(ax1, ax0), subr(ay1, ay0)), area_b = mulr(subr(bx1, bx0), subr(by1, by0));
+    const float iw = fmaxf(subr(fminf(ax1, bx1), fmaxf(ax0, bx0)), 0.0f);
+    const float ih = fmaxf(subr(fminf(ay1, by1), fmaxf(ay0, by0)), 0.0f);
+    const float inter = mulr(iw, ih);
+    const float uni = subr(addr(area_a, area_b), inter);
+    const float iou = divr(inter, addr(uni, 1e-6f));
+    const float ew = fmaxf(subr(fmaxf(ax1, bx1), fminf(ax0, bx0)), 0.0f);
+    const float eh = fmaxf(subr(fmaxf(ay1, by1), fminf(ay0, by0)), 0.0f);
+    const float earea = mulr(ew, eh);
+    const float giou = subr(iou, divr(subr(earea, uni), addr(earea, 1e-6f)));
+    cost[idx] = addr(addr(mulr(w_bbox, cost_bbox), mulr(w_class, cost_class)), mulr(w_giou, -giou));
+}
+
 inline size_t problem_bytes(int Q, int Tmax)
 {
     const size_t nc = (size_t)(Q > Tmax ? Q : Tmax), nr = (size_t)(Q > Tmax ? Tmax : Q);
@@ -197,6 +250,19 @@ int zira_lsap_f32(const float *cost, int nsets, int B, int Q, int Ttot, int Tmax
     hipLaunchKernelGGL(lsap_kernel, dim3(nsets * B), dim3(64), use_lds ? per : 0, (hipStream_t)stream, cost, B, Q,
                        Ttot, meta, q_idx, t_idx, Mtot, t_global, reinterpret_cast<char *>(workspace), per, use_lds,
                        status);
+    return (int)hipGetLastError();
+}
+
+int zira_match_cost_f32(const float *logits, const float *boxes, const int64_t *tgt_ids, const float *tgt_boxes,
+                        int N, int C, int T, float w_class, float w_bbox, float w_giou, float alpha, float gamma,
+                        float *cost, int32_t *status, void *stream)
+{
+    if (N < 0 || C <= 0 || T < 0 || (long long)N * T >= (1ll << 31)) return ZIRA_MSDA_EINVAL;
+    if (N == 0 || T == 0) return 0;
+    if (!logits || !boxes || !tgt_ids || !tgt_boxes || !cost) return ZIRA_MSDA_EINVAL;
+    const int total = N * T;
+    hipLaunchKernelGGL(match_cost_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, boxes,
+                       tgt_ids, tgt_boxes, N, C, T, w_class, w_bbox, w_giou, alpha, gamma, cost, status);
     return (int)hipGetLastError();
 }
 

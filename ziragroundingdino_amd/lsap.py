@@ -74,3 +74,39 @@ def linear_sum_assignment_batched(cost: torch.Tensor, sizes: Sequence[int], glob
     if rc != 0:
         raise RuntimeError("zira_lsap_f32 failed with code %d" % rc)
     return q_idx, t_idx
+
+
+def _status(dev):
+    st = _state.get(str(dev))
+    if st is None:
+        st = _state[str(dev)] = {"status": torch.zeros(1, dtype=torch.int32, device=dev),
+                                 "ws": torch.empty(16, dtype=torch.uint8, device=dev)}
+    return st["status"]
+
+
+def bad_boxes(device, reset: bool = False) -> bool:
+    """True if ``matching_cost`` met a box with x1 < x0 or y1 < y0 (the reference asserts there; synchronises)."""
+    st = _state.get(str(torch.device(device)))
+    hit = bool(st is not None and int(st["status"].item()) & 2)
+    if reset and st is not None:
+        st["status"].bitwise_and_(~2)
+    return hit
+
+
+def matching_cost(logits, boxes, tgt_ids, tgt_boxes, w_class=1.0, w_bbox=1.0, w_giou=1.0, alpha=0.25, gamma=2.0):
+    """Fused focal + L1 + GIoU matching cost (C ABI ``zira_match_cost_f32``; reference matcher.py:105-141):
+    logits [N, C], boxes [N, 4], tgt_ids [T], tgt_boxes [T, 4] -> [N, T] float32."""
+    assert logits.is_cuda and logits.dtype == torch.float32 and boxes.dtype == torch.float32
+    lib = _lib.load()
+    logits, boxes = logits.contiguous(), boxes.contiguous()
+    tgt_ids, tgt_boxes = tgt_ids.contiguous().to(torch.int64), tgt_boxes.contiguous().float()
+    N, C = logits.shape
+    T = tgt_ids.numel()
+    cost = torch.empty((N, T), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        rc = lib.zira_match_cost_f32(logits.data_ptr(), boxes.data_ptr(), tgt_ids.data_ptr(), tgt_boxes.data_ptr(), N, C, T,
+                                     w_class, w_bbox, w_giou, alpha, gamma, cost.data_ptr(),
+                                     _status(logits.device).data_ptr(), _stream(logits.device))
+    if rc != 0:
+        raise RuntimeError("zira_match_cost_f32 failed with code %d" % rc)
+    return cost

@@ -84,26 +84,35 @@ class HungarianMatcher(nn.Module):
         matches query ``q_idx[s, k]`` of image ``image_of[k]`` with target ``t_idx[s, k]`` of the
         CONCATENATED targets.  The xyxy-order assertion of ``generalized_box_iou`` (a host sync of its own
         in the reference) is kept as a device flag: ``check()`` raises if it ever failed."""
-        from .lsap import linear_sum_assignment_batched
+        from .lsap import linear_sum_assignment_batched, matching_cost
 
         S, B, Q = logits.shape[:3]
-        flat = {"pred_logits": logits.reshape(1, S * B * Q, -1), "pred_boxes": boxes.reshape(1, S * B * Q, 4)}
-        C, ok = self.cost_matrix(flat, targets, check=False)
-        bad = getattr(self, "_bad_boxes", None)
-        self._bad_boxes = ~ok if bad is None or bad.device != ok.device else bad | ~ok
         sizes = [len(v["boxes"]) for v in targets]
+        self._device = logits.device
+        if self.cost_class_type == "focal_loss_cost" and logits.dtype == torch.float32 and sum(sizes):
+            # one kernel for the whole cost (csrc/lsap.hip), rounded like the chain of ~30 PyTorch kernels below
+            C = matching_cost(logits.detach().reshape(S * B * Q, -1), boxes.detach().reshape(S * B * Q, 4).float(),
+                              torch.cat([v["labels"] for v in targets]), torch.cat([v["boxes"] for v in targets]),
+                              self.cost_class, self.cost_bbox, self.cost_giou, self.alpha, self.gamma)
+        else:
+            flat = {"pred_logits": logits.reshape(1, S * B * Q, -1), "pred_boxes": boxes.reshape(1, S * B * Q, 4)}
+            C, ok = self.cost_matrix(flat, targets, check=False)
+            bad = getattr(self, "_bad_boxes", None)
+            self._bad_boxes = ~ok if bad is None or bad.device != ok.device else bad | ~ok
         return linear_sum_assignment_batched(C.view(S, B, Q, -1), sizes, global_targets=True)
 
     def check(self):
         """Raise if a prediction / target box of any device-side matching so far was not in xyxy order, or a
         cost matrix was infeasible (the reference asserts / scipy raises on the spot; this reads two flags
         back and therefore synchronises -- call it at the end of a task, not in the step)."""
-        from .lsap import infeasible
+        from .lsap import bad_boxes, infeasible
 
         bad = getattr(self, "_bad_boxes", None)
-        if bad is not None:
-            assert not bool(bad), "boxes not in xyxy order"
-            if infeasible(bad.device):
+        assert bad is None or not bool(bad), "boxes not in xyxy order"
+        dev = getattr(self, "_device", None)
+        if dev is not None:
+            assert not bad_boxes(dev), "boxes not in xyxy order"
+            if infeasible(dev):
                 raise ValueError("cost matrix is infeasible")
 
     @torch.no_grad()

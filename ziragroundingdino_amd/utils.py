@@ -154,11 +154,79 @@ class ContrastiveEmbed(nn.Module):
         return res
 
 
+_mask_pack_cache = {}
+
+
+def _packed_category_masks(masks: List[Tensor], device):
+    """(mask uint8 [B, Cmax, Tmax], n_cat int32 [B], n_tok int32 [B], Cmax, Tmax) on ``device`` for the native
+    kernel; remembered per list object (the model caches the list per caption batch)."""
+    key = (id(masks), str(device))
+    hit = _mask_pack_cache.get(key)
+    if hit is not None and hit[0] is masks:
+        return hit[1]
+    cmax = max([m.shape[0] for m in masks] + [0])
+    tmax = max([m.shape[1] for m in masks] + [0])
+    packed = torch.zeros((len(masks), cmax, tmax), dtype=torch.uint8)
+    for b, m in enumerate(masks):
+        packed[b, :m.shape[0], :m.shape[1]] = m.to("cpu", torch.uint8)
+    val = (packed.to(device), torch.tensor([m.shape[0] for m in masks], dtype=torch.int32).to(device),
+           torch.tensor([m.shape[1] for m in masks], dtype=torch.int32).to(device), cmax, tmax)
+    if len(_mask_pack_cache) > 64:
+        _mask_pack_cache.clear()
+    _mask_pack_cache[key] = (masks, val)
+    return val
+
+
+class _CategoryLogits(torch.autograd.Function):
+    """recover_to_cls_logits on the GPU through the C ABI (csrc/catlogits.hip): one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, logits, packed, n_cat, n_tok, cmax, tmax, for_fill):
+        from . import _lib
+
+        lib = _lib.load()
+        logits = logits.contiguous()
+        B, Q, T = logits.shape[-3:]
+        rows = logits.numel() // T
+        out = torch.empty_like(logits)
+        arg = torch.empty((rows, max(cmax, 1)), dtype=torch.int32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = lib.zira_cat_logits_fwd_f32(logits.data_ptr(), packed.data_ptr(), n_cat.data_ptr(), n_tok.data_ptr(), rows,
+                                             B, Q, T, cmax, tmax, float(for_fill), out.data_ptr(), arg.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_cat_logits_fwd_f32 failed with code %d" % rc)
+        ctx.save_for_backward(arg, n_cat)
+        ctx.dims = (rows, B, Q, T, cmax)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        from . import _lib
+
+        lib = _lib.load()
+        arg, n_cat = ctx.saved_tensors
+        rows, B, Q, T, cmax = ctx.dims
+        grad_out = grad_out.contiguous()
+        grad = torch.empty_like(grad_out)
+        with torch.cuda.device(grad_out.device):
+            rc = lib.zira_cat_logits_bwd_f32(grad_out.data_ptr(), arg.data_ptr(), n_cat.data_ptr(), rows, B, Q, T, cmax,
+                                             grad.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_cat_logits_bwd_f32 failed with code %d" % rc)
+        return grad, None, None, None, None, None, None
+
+
 def recover_to_cls_logits(logits: Tensor, cate_to_token_mask_list: List[Tensor],
                           for_fill=float("-inf")) -> Tensor:
     """token logits -> category logits: new[b, q, c] = max over the tokens of category c,
     ``for_fill`` elsewhere; same shape as ``logits`` (reference utils.py:312-320)."""
     assert logits.shape[-3] == len(cate_to_token_mask_list)    # [..., B, Q, T]: leading dims = stacked sets
+    if (logits.is_cuda and logits.dtype == torch.float32
+            and all(m.shape[1] <= logits.shape[-1] and m.shape[0] <= logits.shape[-1] for m in cate_to_token_mask_list)):
+        packed, n_cat, n_tok, cmax, tmax = _packed_category_masks(cate_to_token_mask_list, logits.device)
+        return _CategoryLogits.apply(logits, packed, n_cat, n_tok, cmax, tmax, for_fill)
     new_logits = torch.full(logits.shape, for_fill, device=logits.device, dtype=logits.dtype)
     for bid, mask in enumerate(cate_to_token_mask_list):          # mask: [n_cat, n_token] bool
         n_cat, n_tok = mask.shape
