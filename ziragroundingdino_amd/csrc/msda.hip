@@ -1322,6 +1322,9 @@ constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #ifndef ZIRA_K2W_U
 #define ZIRA_K2W_U 4   // grad_out rows per lane and batch; two batches are in flight (helpers: half)
 #endif
+#ifndef ZIRA_K2W_UH
+#define ZIRA_K2W_UH (ZIRA_K2W_U / 2)   // ... of the slice launch
+#endif
 #ifndef ZIRA_K2W_MINWAVES
 #define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
 #endif
@@ -1339,7 +1342,7 @@ constexpr unsigned kDenseWaveEntries = ZIRA_DENSE_WAVE_ENTRIES;
 #define ZIRA_K2W_HEAVY 512
 #endif
 #ifndef ZIRA_K2W_SLICE
-#define ZIRA_K2W_SLICE 512
+#define ZIRA_K2W_SLICE 320
 #endif
 constexpr unsigned kWaveTileCap = ZIRA_K2W_CAP;    // LDS sort capacity of a wave (entries)
 constexpr unsigned kHeavyTile = ZIRA_K2W_HEAVY;    // tiles above this many entries are sliced
@@ -1377,7 +1380,7 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
     unsigned *__restrict__ queue, float *__restrict__ grad_value)
 {
     constexpr unsigned NSLOT = 256 / D;
-    constexpr unsigned U = kHelpers ? ZIRA_K2W_U / 2 : ZIRA_K2W_U;
+    constexpr unsigned U = kHelpers ? ZIRA_K2W_UH : ZIRA_K2W_U;
     constexpr unsigned EPL = kWaveTileCap / 64;  // entries per lane and slice
     constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
     extern __shared__ unsigned lds_k2w[];
