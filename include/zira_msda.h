@@ -219,6 +219,18 @@ int zira_cat_logits_bwd_f32(const float *grad_out, const int32_t *argmax, const 
                             int Q, int T, int Cmax, float *grad_logits, void *stream);
 
 
+/* ---- (Shifted-)window attention of the frozen Swin backbone, forward only ---------------------
+ * Replaces WindowAttention.forward together with the pad / roll / window_partition / window_reverse / crop around
+ * it in SwinTransformerBlock.forward (backbone/swin_transformer.py:128-160, :222-270):
+ *   qkv      [B, H, W, 3, heads, 32]  output of the block's qkv projection on the un-partitioned token map
+ *   qkv_bias [3 * heads * 32]         that projection's bias (= q, k, v of a padding token)
+ *   bias_t   [heads, N, N]            relative position bias, transposed: bias_t[h, j, i] = table[index[i, j], h]
+ *   out      [B, H, W, heads * 32]    attention output in token order (input of the block's proj)
+ * window = window size (N = window^2 tokens), shift = 0 or window / 2, scale = 32^-0.5.  Device pointers. */
+int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *bias_t, int B, int H, int W, int heads,
+                         int head_dim, int window, int shift, float scale, float *out, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

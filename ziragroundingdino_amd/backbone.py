@@ -69,6 +69,37 @@ class WindowAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
+    def _bias_transposed(self):
+        """[heads, N, N] relative position bias with the key index first (bias_t[h, j, i]), as the native kernel
+        reads it; rebuilt when the (frozen) table changes."""
+        t = self.relative_position_bias_table
+        key = (t._version, t.device, t.data_ptr())
+        if getattr(self, "_bias_t_key", None) != key:
+            N = self.ws * self.ws
+            with torch.no_grad():
+                self._bias_t = t[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 1, 0).contiguous().float()
+            self._bias_t_key = key
+        return self._bias_t
+
+    def forward_native(self, xn, H, W, shift):
+        """``proj(window attention(qkv(xn)))`` for the normalised token map ``xn [B, H*W, C]`` through the C ABI
+        (csrc/winattn.hip): pad, shift, window partition / reverse and crop are index arithmetic inside the kernel.
+        Forward only (the backbone is frozen)."""
+        from . import _lib
+
+        lib = _lib.load()
+        B, L, C = xn.shape
+        qkv = self.qkv(xn).contiguous()                    # [B, H, W, 3, heads, 32]
+        out = torch.empty((B, L, C), dtype=torch.float32, device=xn.device)
+        hd = C // self.num_heads
+        with torch.cuda.device(xn.device):
+            rc = lib.zira_window_attn_f32(qkv.data_ptr(), self.qkv.bias.data_ptr(), self._bias_transposed().data_ptr(),
+                                          B, H, W, self.num_heads, hd, self.ws, shift, float(hd) ** -0.5, out.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_window_attn_f32 failed with code %d" % rc)
+        return self.proj(out)
+
     def forward(self, x, mask=None):
         Bw, N, C = x.shape
         qkv = self.qkv(x).reshape(Bw, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
@@ -82,6 +113,8 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
+    native_attention = True   # no-grad fp32 GPU forwards: window attention through the C ABI (csrc/winattn.hip)
+
     def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, drop_path):
         super().__init__()
         self.window_size, self.shift_size = window_size, shift_size
@@ -95,6 +128,11 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         ws = self.window_size
         shortcut = x
+        if (self.native_attention and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled() and C // self.attn.num_heads == 32 and ws <= 16
+                and self.attn.qkv.bias is not None and self.attn.qkv.weight.dtype == torch.float32):
+            x = shortcut + self.drop_path(self.attn.forward_native(self.norm1(x), H, W, self.shift_size))
+            return x + self.drop_path(self.mlp(self.norm2(x)))
         x = self.norm1(x).view(B, H, W, C)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
