@@ -124,15 +124,23 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x, H, W, mask_matrix):
+    def _residual(self, x, branch, scale):
+        """x + drop_path(branch); ``scale`` [B, 1, 1] is a pre-drawn keep / keep_prob factor (SwinTransformer.forward
+        draws the factors of all blocks with four launches instead of three per use)."""
+        if scale is None:
+            return x + self.drop_path(branch)
+        return torch.addcmul(x, branch, scale)
+
+    def forward(self, x, H, W, mask_matrix, dp=None):
         B, L, C = x.shape
         ws = self.window_size
         shortcut = x
+        dp0, dp1 = (dp[0], dp[1]) if dp is not None else (None, None)
         if (self.native_attention and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
                 and not torch.is_autocast_enabled() and C // self.attn.num_heads == 32 and ws <= 16
                 and self.attn.qkv.bias is not None and self.attn.qkv.weight.dtype == torch.float32):
-            x = shortcut + self.drop_path(self.attn.forward_native(self.norm1(x), H, W, self.shift_size))
-            return x + self.drop_path(self.mlp(self.norm2(x)))
+            x = self._residual(shortcut, self.attn.forward_native(self.norm1(x), H, W, self.shift_size), dp0)
+            return self._residual(x, self.mlp(self.norm2(x)), dp1)
         x = self.norm1(x).view(B, H, W, C)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
@@ -147,8 +155,8 @@ class SwinTransformerBlock(nn.Module):
         if self.shift_size > 0:
             x = torch.roll(x, shifts=(self.shift_size, self.shift_size), dims=(1, 2))
         x = x[:, :H, :W, :].reshape(B, H * W, C)
-        x = shortcut + self.drop_path(x)
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        x = self._residual(shortcut, x, dp0)
+        return self._residual(x, self.mlp(self.norm2(x)), dp1)
 
 
 class PatchMerging(nn.Module):
@@ -174,7 +182,7 @@ class BasicLayer(nn.Module):
                                  mlp_ratio, drop_path[i]) for i in range(depth)])
         self.downsample = PatchMerging(dim) if downsample else None
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, dp=None):
         ws, ss = self.window_size, self.shift_size
         Hp, Wp = int(math.ceil(H / ws)) * ws, int(math.ceil(W / ws)) * ws
         img_mask = torch.zeros((1, Hp, Wp, 1), device=x.device)
@@ -186,8 +194,8 @@ class BasicLayer(nn.Module):
         mw = window_partition(img_mask, ws).view(-1, ws * ws)
         attn_mask = mw.unsqueeze(1) - mw.unsqueeze(2)
         attn_mask = attn_mask.masked_fill(attn_mask != 0, -100.0).masked_fill(attn_mask == 0, 0.0)
-        for blk in self.blocks:
-            x = blk(x, H, W, attn_mask)
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, H, W, attn_mask, None if dp is None else dp[i])
         if self.downsample is not None:
             return x, H, W, self.downsample(x, H, W), (H + 1) // 2, (W + 1) // 2
         return x, H, W, x, H, W
@@ -204,10 +212,14 @@ class PatchEmbed(nn.Module):
         _, _, H, W = x.shape
         p = self.patch_size
         x = F.pad(x, (0, (p - W % p) % p, 0, (p - H % p) % p))  # 1333 -> 1336 (reference :482-489)
-        x = conv_module_as_gemm(self.proj, x)  # 4x4/4 patches: reshape + GEMM
-        Wh, Ww = x.shape[2], x.shape[3]
-        x = self.norm(x.flatten(2).transpose(1, 2))
-        return x, Wh, Ww
+        B, C, H, W = x.shape
+        Wh, Ww = H // p, W // p
+        # 4x4/4 patches as ONE token-major GEMM [B*L, C*p*p] x [C*p*p, E] (+ bias): no NCHW round trip
+        # (the conv-shaped result cost a 51 MB transpose in front of the LayerNorm)
+        cols = x.view(B, C, Wh, p, Ww, p).permute(0, 2, 4, 1, 3, 5).reshape(B * Wh * Ww, C * p * p)
+        w = self.proj.weight.view(self.proj.out_channels, -1)
+        x = torch.addmm(self.proj.bias, cols, w.t()) if self.proj.bias is not None else cols @ w.t()
+        return self.norm(x.view(B, Wh * Ww, -1)), Wh, Ww
 
 
 class SwinTransformer(nn.Module):
@@ -218,6 +230,8 @@ class SwinTransformer(nn.Module):
         self.num_layers = len(depths)
         self.patch_embed = PatchEmbed(4, 3, embed_dim)
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self._drop_probs = list(dpr)
+        self.register_buffer("_keep_probs", 1.0 - torch.tensor(dpr, dtype=torch.float32), persistent=False)
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
         self.layers = nn.ModuleList([
             BasicLayer(self.num_features[i], depths[i], num_heads[i], window_size, mlp_ratio,
@@ -226,11 +240,24 @@ class SwinTransformer(nn.Module):
         for i in self.out_indices:
             self.add_module(f"norm{i}", LayerNorm(self.num_features[i]))
 
+    def _stochastic_depth_scales(self, B, device, dtype):
+        """keep / keep_prob factors [blocks, 2, B, 1, 1] of every residual branch, drawn at once (training mode with
+        stochastic depth only): same distribution as one bernoulli_ per use (timm DropPath), 4 launches instead of 66."""
+        if not self.training or max(self._drop_probs) == 0.0:
+            return None
+        keep = self._keep_probs.view(-1, 1, 1)              # (a buffer: no host-to-device copy inside graph capture)
+        u = torch.rand((keep.shape[0], 2, B), device=device)
+        return ((u < keep).to(dtype) / keep.to(dtype)).view(keep.shape[0], 2, B, 1, 1)
+
     def forward(self, tensor_list: NestedTensor):
         x, Wh, Ww = self.patch_embed(tensor_list.tensors)
         outs = {}
+        scales = self._stochastic_depth_scales(x.shape[0], x.device, x.dtype)
+        first = 0
         for i, layer in enumerate(self.layers):
-            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
+            n = len(layer.blocks)
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww, None if scales is None else scales[first:first + n])
+            first += n
             if i in self.out_indices:
                 x_out = getattr(self, f"norm{i}")(x_out)
                 out = x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
