@@ -122,3 +122,76 @@ def test_resume_continues_from_periodic_checkpoint(tmp_path, oracle):
     # a finished task is not trained again
     assert run_task(spec("cut", 3), build, None, resume=True, on_step=lambda *a: seen.append("again")) == final
     assert seen == [2]
+
+
+def _chain_worker(rank, world, port, gpath, out_dir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g = torch.load(gpath, weights_only=False)
+    built = []
+
+    def build_model():
+        built.append(build_slice_model(g, "cpu", _SliceModel, seeded=not built))
+        return built[-1]
+
+    specs = []
+    for t in g["tasks"]:
+        inp, feats, poss, am, pid, c2t = slice_inputs({"inputs": t["inputs"]}, None, "cpu")
+        if world > 1:       # each rank trains on one image of the two-image minibatch
+            sl = slice(rank, rank + 1)
+            inp = dict(inp, bert_hidden=inp["bert_hidden"][sl], input_ids=inp["input_ids"][sl],
+                       img_mask=inp["img_mask"][sl], targets=inp["targets"][sl])
+            from ziragroundingdino_amd.utils import NestedTensor
+            feats = [NestedTensor(f.tensors[sl], f.mask[sl]) for f in feats]
+            poss, am, pid, c2t = [p[sl] for p in poss], am[sl], pid[sl], c2t[sl]
+        data = (inp, feats, poss, am, pid, c2t)
+        task = t["task"]
+        specs.append(TaskSpec(name=task["name"], categories_names=task["categories"],
+                              data=lambda start, d=data: itertools.repeat(d), max_iter=task["max_iter"],
+                              output_dir=os.path.join(out_dir, task["name"]),
+                              lr_multiplier=multistep_lr_multiplier(task["decay_iter"])))
+    finals = run_tasks(specs, build_model, device="cpu")
+    assert all(os.path.exists(f) for f in finals)          # rank 0 wrote them before the barrier released us
+    dist.destroy_process_group()
+
+
+def test_task_chain_two_ranks_gloo(tmp_path):
+    """The chain under data parallelism (world_size 2, gloo, one image per rank): rank 0 writes the checkpoints,
+    every rank starts the next task from them, and the merged weights equal the one-process run on both images
+    (the averaged side-branch gradients are those of the whole minibatch)."""
+    import torch.multiprocessing as mp
+
+    gpath = os.path.join(GOLDEN, "tasks_zira_slice.pt")
+    port = 29800 + os.getpid() % 1500
+    mp.spawn(_chain_worker, args=(2, port, gpath, str(tmp_path / "w2")), nprocs=2, join=True)
+    g = torch.load(gpath, weights_only=False)
+    for t in g["tasks"]:
+        ck = torch.load(tmp_path / "w2" / t["task"]["name"] / "model_final.pth", weights_only=False)["model"]
+        for n, want in t["merged"].items():
+            close(ck[n], want, 2e-4, "2-rank %s merged %s" % (t["task"]["name"], n))
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun hands over to torch.distributed.run on 127.0.0.1 before anything
+    touches the GPU (reference train_multidatasets.py:573-580 launches its ranks itself too)."""
+    import subprocess
+    import sys
+
+    import bench
+
+    calls = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(4, ["--gpus", "4", "--steps", "3"])
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    with pytest.raises(SystemExit, match="only 4 GPU"):
+        bench.spawn_ranks(8, [])
