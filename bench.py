@@ -334,8 +334,19 @@ def main():
     trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard
 
-    for _ in range(args.warmup):
-        trainer.run_step(data)
+    try:
+        for _ in range(args.warmup):
+            trainer.run_step(data)
+    except RuntimeError as e:   # graph capture refused (memory, an op that cannot be captured): the eager launch path
+        if not args.transformer_graph:
+            raise
+        print("[bench] transformer graph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0],
+              file=sys.stderr, flush=True)
+        args.transformer_graph = False
+        model.use_transformer_graph = False
+        trainer.flat_grad.zero_()
+        for _ in range(args.warmup):
+            trainer.run_step(data)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
