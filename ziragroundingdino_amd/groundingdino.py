@@ -202,6 +202,8 @@ class GroundingDINO(nn.Module):
         # hipGraph replay of transformer forward + backward (opt-in: fixed input sizes, frozen
         # transformer weights, training mode); see graphs.GraphedTransformer
         self.use_transformer_graph = False
+        self.overlap_text_and_image = True   # frozen BERT replayed on a side stream while the frozen Swin runs
+        self._text_stream = None
         self._graphed_transformer = GraphedTransformer(self.transformer)
 
     def _backbone_tensors(self, images, mask):
@@ -253,7 +255,7 @@ class GroundingDINO(nn.Module):
             return self.input_proj[l][1](main) + branch, zero_loss
         return self.input_proj[l][1](main + branch), zero_loss
 
-    def encode_text(self, captions, device):
+    def encode_text(self, captions, device, defer=False):
         # Tokenisation, the sub-sentence masks and their upload are a pure function of the caption
         # strings, and a task trains on one category list for thousands of steps: remembered per
         # (captions, device) instead of redone every step (2.5 ms of host time, five blocking copies).
@@ -280,17 +282,35 @@ class GroundingDINO(nn.Module):
             cached = self._text_cache[key] = (tokenized, masks, position_ids, cate_to_token_mask_list, dict(enc_in))
         tokenized, masks, position_ids, cate_to_token_mask_list, enc_in = cached
         enc_in = dict(enc_in)
+        side = None
         if self._frozen(self.bert):
             if self.use_frontend_graphs and enc_in["input_ids"].is_cuda:
-                hidden = self._graphed_bert(enc_in)
+                if defer and self.overlap_text_and_image:
+                    # the frozen BERT (a graph of ~300 launch-bound kernels) runs beside the frozen Swin: its replay
+                    # goes to a side stream here and is joined in finish(), after the caller has queued the backbone
+                    if self._text_stream is None:
+                        self._text_stream = torch.cuda.Stream(device=device)
+                    side = self._text_stream
+                    side.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(side):
+                        hidden = self._graphed_bert(enc_in)
+                else:
+                    hidden = self._graphed_bert(enc_in)
             else:
                 with torch.no_grad():
                     hidden = self._bert_hidden(enc_in)
         else:
             hidden = self._bert_hidden(enc_in)
-        text_dict, loss_linear_adapter = self.project_text(
-            hidden, tokenized["attention_mask"].bool(), position_ids, masks)
-        return text_dict, cate_to_token_mask_list, loss_linear_adapter
+
+        def finish():
+            if side is not None:
+                torch.cuda.current_stream(device).wait_stream(side)
+                hidden.record_stream(torch.cuda.current_stream(device))
+            text_dict, loss_linear_adapter = self.project_text(
+                hidden, tokenized["attention_mask"].bool(), position_ids, masks)
+            return text_dict, cate_to_token_mask_list, loss_linear_adapter
+
+        return (finish, cate_to_token_mask_list) if defer else finish()
 
     def project_text(self, bert_hidden, text_token_mask, position_ids, text_self_attention_masks):
         """feat_map + language side branch (reference :459-476): BERT states -> text_dict."""
@@ -328,7 +348,7 @@ class GroundingDINO(nn.Module):
                 if not captions[i].endswith("."):
                     captions[i] += "."
 
-        text_dict, cate_to_token_mask_list, loss_linear_adapter = self.encode_text(captions, samples.device)
+        finish_text, cate_to_token_mask_list = self.encode_text(captions, samples.device, defer=True)
 
         targets = None
         if self.training:
@@ -336,6 +356,7 @@ class GroundingDINO(nn.Module):
             targets = self.prepare_targets(gt_instances, cate_to_token_mask_list, names_list)
 
         features, poss = self.run_backbone(samples)
+        text_dict, cate_to_token_mask_list, loss_linear_adapter = finish_text()
 
         out_or_loss = self.forward_features(features, poss, samples.mask, text_dict,
                                             cate_to_token_mask_list, loss_linear_adapter, targets,

@@ -587,18 +587,45 @@ class TransformerEncoder(nn.Module):
             output, memory_text = self.fusion_layers[layer_id](
                 v=output, l=memory_text, attention_mask_v=key_padding_mask,
                 attention_mask_l=text_attention_mask)
-        if self.text_layers:
-            memory_text = self.text_layers[layer_id](
-                src=memory_text.transpose(0, 1),
+        def text_layer(mt):
+            return self.text_layers[layer_id](
+                src=mt.transpose(0, 1),
                 src_mask=~text_self_attention_masks,  # True = do not attend
                 src_key_padding_mask=text_attention_mask,
                 pos=(pos_text.transpose(0, 1) if pos_text is not None else None),
             ).transpose(0, 1)
+
+        side = None
+        if self.text_layers:
+            if self.overlap_text_layer and output.is_cuda:
+                # The text enhancer (~60 launch-bound kernels on <= 256 tokens) and the deformable image layer are
+                # independent inside an encoder layer: the text side goes to a second stream (captured as a parallel
+                # branch when the layer is replayed from a hipGraph; autograd runs its backward on that stream too).
+                cur = torch.cuda.current_stream(output.device)
+                side = self._text_stream(output.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    memory_text = text_layer(memory_text)
+            else:
+                memory_text = text_layer(memory_text)
         output, _ = self.layers[layer_id](src=output, pos=pos, reference_points=reference_points,
                                           spatial_shapes=spatial_shapes,
                                           level_start_index=level_start_index,
                                           key_padding_mask=key_padding_mask)
+        if side is not None:
+            cur.wait_stream(side)
+            memory_text.record_stream(cur)
         return output, memory_text
+
+    overlap_text_layer = True
+    _side_streams = {}
+
+    @classmethod
+    def _text_stream(cls, device):
+        s = cls._side_streams.get(device)
+        if s is None:
+            s = cls._side_streams[device] = torch.cuda.Stream(device=device)
+        return s
 
 
 class TransformerDecoder(nn.Module):
