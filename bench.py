@@ -239,7 +239,7 @@ def cpu_baseline_step(height=800, width=1333, sample_div=2, threads=None):
         h, w = height // sample_div, width // sample_div
         data = synthetic_batch(1, h, w, device="cpu")
         t0 = time.perf_counter()
-        trainer.run_step(data)
+        trainer.run_step(data, next_data=data if args.prefetch else None)
         el = time.perf_counter() - t0
         desc = ("1 full training step at batch 1 on a %dx%d image (1/%d of the %dx%d pixels; counted as "
                 "that fraction of an image) on the host: this package's model on CPU tensors (torch CPU "
@@ -297,6 +297,10 @@ def main():
                          "hipGraphs (same kernels either way; eager, the step time follows the host's jitter)")
     ap.add_argument("--transformer-graph", dest="transformer_graph", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(transformer_graph=True)
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="do not queue the frozen front end (Swin + BERT) of the next minibatch on a second stream "
+                         "while the current step runs (same work per step either way)")
+    ap.set_defaults(prefetch=True)
     ap.add_argument("--kernel-timing-steps", type=int, default=4,
                     help="eager steps after the timed region with HIP events around every MSDA call (roofline.kernels)")
     ap.add_argument("--cpu-sample-div", type=int, default=1,
@@ -336,7 +340,7 @@ def main():
 
     try:
         for _ in range(args.warmup):
-            trainer.run_step(data)
+            trainer.run_step(data, next_data=data if args.prefetch else None)
     except RuntimeError as e:   # graph capture refused (memory, an op that cannot be captured): the eager launch path
         if not args.transformer_graph:
             raise
@@ -346,7 +350,7 @@ def main():
         model.use_transformer_graph = False
         trainer.flat_grad.zero_()
         for _ in range(args.warmup):
-            trainer.run_step(data)
+            trainer.run_step(data, next_data=data if args.prefetch else None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -354,7 +358,7 @@ def main():
     _C.TIMING = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.run_step(data)
+        trainer.run_step(data, next_data=data if args.prefetch else None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -365,11 +369,11 @@ def main():
     if args.transformer_graph and args.kernel_timing_steps > 0:   # (every rank: the steps hold collectives)
         # graph replays hide the launches from event timing: the same step, launched eagerly, right after
         model.use_transformer_graph = False
-        trainer.run_step(data)
+        trainer.run_step(data, next_data=data if args.prefetch else None)
         torch.cuda.synchronize()
         _C.TIMING = []
         for _ in range(args.kernel_timing_steps):
-            trainer.run_step(data)
+            trainer.run_step(data, next_data=data if args.prefetch else None)
         torch.cuda.synchronize()
         records, _C.TIMING = _C.TIMING, None
         model.use_transformer_graph = True
@@ -436,6 +440,7 @@ def main():
                 "images_per_gpu": args.batch,
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world, "transformer_graph": bool(args.transformer_graph),
+                "frontend_prefetch": bool(args.prefetch),
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "msda_kernel_variant": _lib.variant_f32(32),
             },

@@ -286,3 +286,26 @@ def test_one_rank_rccl_step_matches_no_collective():
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_frontend_prefetch_gives_the_same_steps():
+    """ZiraTrainer.run_step(data, next_data=...) queues the frozen front end of the next minibatch on a second stream
+    and the next step picks it up: same losses and weights as without (no stochastic depth / dropout in this model)."""
+    a_model, b_model = small_model().train(), small_model().train()
+    a, b = ZiraTrainer(a_model), ZiraTrainer(b_model)
+    batches = [synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, seed=s, device="cuda") for s in range(3)]
+    seq = [batches[0], batches[1], batches[1], batches[2]]
+    for i, data in enumerate(seq):
+        la = a.run_step(data)
+        nxt = seq[i + 1] if i + 1 < len(seq) else None
+        lb = b.run_step(data, next_data=nxt)
+        if nxt is not None:
+            assert b._prefetched is not None and b._prefetched["inputs"] is nxt
+        for k in la:
+            torch.testing.assert_close(la[k], lb[k], rtol=1e-4, atol=1e-5, msg=k)
+    for p, q in zip(a.params, b.params):
+        torch.testing.assert_close(p, q, rtol=1e-3, atol=1e-5)
+    # a handle for another minibatch is ignored (the step computes its own front end)
+    b._prefetched = b_model.prefetch_frontend(batches[0])
+    lb = b.run_step(batches[2])
+    assert all(torch.isfinite(v) for v in lb.values())

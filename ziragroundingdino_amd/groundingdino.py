@@ -17,6 +17,7 @@ backbone and text encoder are stock PyTorch-ROCm and are evaluated without build
 autograd graph (nothing upstream of the side branches needs gradients).
 """
 import copy
+import os
 import random
 from typing import List
 
@@ -204,6 +205,7 @@ class GroundingDINO(nn.Module):
         self.use_transformer_graph = False
         self.overlap_text_and_image = True   # frozen BERT replayed on a side stream while the frozen Swin runs
         self._text_stream = None
+        self._prefetch_stream = None
         self._graphed_transformer = GraphedTransformer(self.transformer)
 
     def _backbone_tensors(self, images, mask):
@@ -255,7 +257,7 @@ class GroundingDINO(nn.Module):
             return self.input_proj[l][1](main) + branch, zero_loss
         return self.input_proj[l][1](main + branch), zero_loss
 
-    def encode_text(self, captions, device, defer=False):
+    def encode_text(self, captions, device, defer=False, hidden_only=False):
         # Tokenisation, the sub-sentence masks and their upload are a pure function of the caption
         # strings, and a task trains on one category list for thousands of steps: remembered per
         # (captions, device) instead of redone every step (2.5 ms of host time, five blocking copies).
@@ -306,6 +308,8 @@ class GroundingDINO(nn.Module):
             if side is not None:
                 torch.cuda.current_stream(device).wait_stream(side)
                 hidden.record_stream(torch.cuda.current_stream(device))
+            elif hidden_only and hidden.is_cuda:   # computed on a prefetch stream; the caller has waited for it
+                hidden.record_stream(torch.cuda.current_stream(device))
             text_dict, loss_linear_adapter = self.project_text(
                 hidden, tokenized["attention_mask"].bool(), position_ids, masks)
             return text_dict, cate_to_token_mask_list, loss_linear_adapter
@@ -332,10 +336,7 @@ class GroundingDINO(nn.Module):
                      "text_self_attention_masks": text_self_attention_masks}
         return text_dict, loss_linear_adapter
 
-    def forward(self, batched_inputs, **kw):
-        images = self.preprocess_image(batched_inputs)
-        samples = nested_tensor_from_tensor_list(images)
-
+    def _captions(self, batched_inputs):
         captions = [x["captions"] for x in batched_inputs]
         names_list = [x["captions"][:-1].split(".") for x in batched_inputs]
         if (self.use_add_names and not self.training) or (self.use_learned_names and self.training):
@@ -347,7 +348,62 @@ class GroundingDINO(nn.Module):
                 captions[i] = caption + ".".join(extra)
                 if not captions[i].endswith("."):
                     captions[i] += "."
+        return captions, names_list
 
+    def can_prefetch_frontend(self):
+        return (self.training and self.use_frontend_graphs and self._frozen(self.backbone) and self._frozen(self.bert)
+                and next(self.parameters()).is_cuda)
+
+    def prefetch_frontend(self, batched_inputs):
+        """Queue the FROZEN front end (image normalisation, Swin, position encodings, BERT) of a minibatch on a second
+        stream and return a handle for ``forward(batched_inputs, frontend=handle)``.  Nothing in it depends on the
+        trainable weights, so a trainer can queue the next minibatch's front end while the current step's launch-bound
+        phases (fusion blocks, decoder, criterion, backward) leave most of the GPU idle.  The work per step is the
+        same; only its place in time changes."""
+        assert self.can_prefetch_frontend()
+        dev = self.device if isinstance(self.device, torch.device) else torch.device(self.device)
+        cur = torch.cuda.current_stream(dev)
+        if self._prefetch_stream is None:
+            # default (= lowest) priority.  Measured: a high-priority prefetch stream costs 20 % (36 vs 45 images/s), and
+            # putting the step itself on a high-priority stream instead loses as well (39-40)
+            self._prefetch_stream = torch.cuda.Stream(device=dev)
+        side = self._prefetch_stream
+        side.wait_stream(cur)          # (the inputs may have been produced on the current stream)
+        with torch.cuda.stream(side), torch.no_grad():
+            images = self.preprocess_image(batched_inputs)
+            samples = nested_tensor_from_tensor_list(images)
+            captions, names_list = self._captions(batched_inputs)
+            overlap, self.overlap_text_and_image = self.overlap_text_and_image, False   # already off the main stream
+            try:
+                finish_text, cate_list = self.encode_text(captions, samples.device, defer=True, hidden_only=True)
+            finally:
+                self.overlap_text_and_image = overlap
+            features, poss = self.run_backbone(samples)
+            done = torch.cuda.Event()
+            done.record(side)
+        return {"inputs": batched_inputs, "images": images, "samples": samples, "names_list": names_list,
+                "finish_text": finish_text, "cate_list": cate_list, "features": features, "poss": poss, "done": done,
+                "stream": side}
+
+    def forward(self, batched_inputs, frontend=None, **kw):
+        if frontend is not None and frontend["inputs"] is batched_inputs:
+            cur = torch.cuda.current_stream(frontend["samples"].tensors.device)
+            cur.wait_event(frontend["done"])
+            images, samples, names_list = frontend["images"], frontend["samples"], frontend["names_list"]
+            features, poss, cate_to_token_mask_list = frontend["features"], frontend["poss"], frontend["cate_list"]
+            for t in [samples.tensors, samples.mask] + [f.tensors for f in features] + [f.mask for f in features] + list(poss):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+            targets = None
+            if self.training:
+                gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+                targets = self.prepare_targets(gt_instances, cate_to_token_mask_list, names_list)
+            text_dict, cate_to_token_mask_list, loss_linear_adapter = frontend["finish_text"]()
+            return self._forward_rest(batched_inputs, images, samples, features, poss, text_dict, cate_to_token_mask_list,
+                                      loss_linear_adapter, targets)
+        images = self.preprocess_image(batched_inputs)
+        samples = nested_tensor_from_tensor_list(images)
+        captions, names_list = self._captions(batched_inputs)
         finish_text, cate_to_token_mask_list = self.encode_text(captions, samples.device, defer=True)
 
         targets = None
@@ -357,7 +413,11 @@ class GroundingDINO(nn.Module):
 
         features, poss = self.run_backbone(samples)
         text_dict, cate_to_token_mask_list, loss_linear_adapter = finish_text()
+        return self._forward_rest(batched_inputs, images, samples, features, poss, text_dict, cate_to_token_mask_list,
+                                  loss_linear_adapter, targets)
 
+    def _forward_rest(self, batched_inputs, images, samples, features, poss, text_dict, cate_to_token_mask_list,
+                      loss_linear_adapter, targets):
         out_or_loss = self.forward_features(features, poss, samples.mask, text_dict,
                                             cate_to_token_mask_list, loss_linear_adapter, targets,
                                             no_padding=getattr(samples, "no_padding", False))

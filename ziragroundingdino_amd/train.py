@@ -46,6 +46,7 @@ class ZiraTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.iter = 0
         self.always_reduce = False  # tests: issue the collective on a one-rank group too
+        self._prefetched = None     # front end of the next minibatch, queued by run_step(..., next_data=)
         if hasattr(model, "criterion") and hasattr(model.criterion, "process_group"):
             model.criterion.process_group = process_group  # num_boxes is averaged over the same ranks
         self._bind()
@@ -87,15 +88,26 @@ class ZiraTrainer:
                 raise RuntimeError("[ZiraTrainer] .grad of %s left the flat gradient bucket "
                                    "(zero_grad(set_to_none=True)?); call trainer._bind()" % n)
 
-    def run_step(self, data) -> Dict[str, torch.Tensor]:
-        """One optimisation step on one minibatch; returns the (detached) weighted loss dict."""
+    def run_step(self, data, next_data=None) -> Dict[str, torch.Tensor]:
+        """One optimisation step on one minibatch; returns the (detached) weighted loss dict.
+        ``next_data``: the minibatch of the NEXT step, if the caller has it already (a data loader with prefetch
+        does): its frozen front end is queued on a second stream as soon as this step's forward has been launched,
+        and picked up by the next ``run_step(next_data, ...)`` (see GroundingDINO.prefetch_frontend)."""
         assert self.model.training, "[ZiraTrainer] model was changed to eval mode!"
         self._check_bucket()
+        kw = {}
+        pre = self._prefetched
+        self._prefetched = None
+        if pre is not None and pre["inputs"] is data:
+            kw["frontend"] = pre
         if self.amp_dtype is not None:
             with torch.autocast(self.flat_grad.device.type, dtype=self.amp_dtype):
-                loss_dict = self.model(data)
+                loss_dict = self.model(data, **kw)
         else:
-            loss_dict = self.model(data)
+            loss_dict = self.model(data, **kw)
+        if (next_data is not None and self.amp_dtype is None and hasattr(self.model, "can_prefetch_frontend")
+                and self.model.can_prefetch_frontend()):
+            self._prefetched = self.model.prefetch_frontend(next_data)
         losses = sum(loss_dict.values())
         losses.backward()
         if self.world > 1 or self.always_reduce:  # single RCCL all-reduce of the side-branch gradients
