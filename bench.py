@@ -239,7 +239,7 @@ def cpu_baseline_step(height=800, width=1333, sample_div=2, threads=None):
         h, w = height // sample_div, width // sample_div
         data = synthetic_batch(1, h, w, device="cpu")
         t0 = time.perf_counter()
-        trainer.run_step(data, next_data=data if args.prefetch else None)
+        trainer.run_step(data)
         el = time.perf_counter() - t0
         desc = ("1 full training step at batch 1 on a %dx%d image (1/%d of the %dx%d pixels; counted as "
                 "that fraction of an image) on the host: this package's model on CPU tensors (torch CPU "
@@ -369,11 +369,11 @@ def main():
     if args.transformer_graph and args.kernel_timing_steps > 0:   # (every rank: the steps hold collectives)
         # graph replays hide the launches from event timing: the same step, launched eagerly, right after
         model.use_transformer_graph = False
-        trainer.run_step(data, next_data=data if args.prefetch else None)
+        trainer.run_step(data)          # (no prefetch here: a concurrent Swin would sit inside the event brackets)
         torch.cuda.synchronize()
         _C.TIMING = []
         for _ in range(args.kernel_timing_steps):
-            trainer.run_step(data, next_data=data if args.prefetch else None)
+            trainer.run_step(data)
         torch.cuda.synchronize()
         records, _C.TIMING = _C.TIMING, None
         model.use_transformer_graph = True
