@@ -111,6 +111,15 @@ def test_two_training_steps_match_reference(msda_backend):
     close(torch.linalg.vector_norm(trainer.flat_grad), want["grad_norm"], 1e-4, "grad norm")
     trainer.flat_grad.zero_()
 
+    # the model's own total (what the trainer back-propagates) is the sum of the entries, value and gradients
+    ld = run_slice_step(model, *data)
+    assert ld.total is not None
+    close(ld.total, sum(ld.values()).reshape(()), 1e-6, "LossDict.total")
+    ga = torch.autograd.grad(ld.total, [named[n] for n in g["trainable_names"]], retain_graph=True)
+    gb = torch.autograd.grad(sum(ld.values()), [named[n] for n in g["trainable_names"]])
+    for n, x, y in zip(g["trainable_names"], ga, gb):
+        close(x, y, 1e-6, "grad via total " + n)
+
     # two optimizer steps through the harness
     for it in range(2):
         out = trainer.run_step(data)

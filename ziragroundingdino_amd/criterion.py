@@ -36,6 +36,15 @@ def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: f
     return loss.mean(1).sum() / num_boxes
 
 
+class LossDict(dict):
+    """A plain loss dict that also carries how its entries were made: ``stacked[name] = (vector [S], suffixes)`` says
+    that ``self[name + suffixes[s]]`` is ``vector[s]``.  A caller that only needs the weighted SUM can take it from the
+    vectors (three products and sums) instead of from 21 scalar entries (a multiply, an add and a select-backward
+    each).  Everything else treats it as the dict it is."""
+    stacked = None
+    total = None
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, losses: List[str] = ["class", "boxes"],
                  eos_coef: float = 0.1, loss_class_type: str = "focal_loss", alpha: float = 0.25,
@@ -169,7 +178,8 @@ class TwoStageCriterion(SetCriterion):
         labels_all = torch.cat([t["labels"] for t in targets])
         boxes_all = torch.cat([t["boxes"] for t in targets])
 
-        losses = {}
+        losses = LossDict()
+        losses.stacked = {}
         if "class" in self.losses:
             assert self.loss_class_type == "focal_loss"
             target_classes = torch.full((S, B, Q), self.num_classes, dtype=torch.int64, device=dev)
@@ -184,6 +194,7 @@ class TwoStageCriterion(SetCriterion):
             if self.alpha >= 0:
                 loss = (self.alpha * tgt + (1 - self.alpha) * (1 - tgt)) * loss
             per_set = loss.mean(2).sum((1, 2)) / num_boxes * Q
+            losses.stacked["loss_class"] = (per_set, list(suffixes))
             for s, suf in enumerate(suffixes):
                 losses["loss_class" + suf] = per_set[s]
         if "boxes" in self.losses:
@@ -198,6 +209,8 @@ class TwoStageCriterion(SetCriterion):
                 seg = torch.zeros(S, dtype=l1.dtype, device=dev)
                 l1_s = seg.index_add(0, s_i, l1) / num_boxes
                 giou_s = seg.index_add(0, s_i, giou) / num_boxes
+            losses.stacked["loss_bbox"] = (l1_s, list(suffixes))
+            losses.stacked["loss_giou"] = (giou_s, list(suffixes))
             for s, suf in enumerate(suffixes):
                 losses["loss_bbox" + suf] = l1_s[s]
                 losses["loss_giou" + suf] = giou_s[s]

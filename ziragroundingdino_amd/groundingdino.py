@@ -247,6 +247,14 @@ class GroundingDINO(nn.Module):
             object.__setattr__(module, "_zira_param_list", params)
         return not any(p.requires_grad for p in params)
 
+    def _loss_weights(self, name, suffixes, weight_dict, like):
+        key = (name, tuple(suffixes), tuple(weight_dict[name + suf] for suf in suffixes), like.device, like.dtype)
+        cache = self.__dict__.setdefault("_loss_weight_cache", {})
+        w = cache.get(key)
+        if w is None:
+            w = cache[key] = torch.tensor(key[2], dtype=like.dtype).to(like.device)
+        return w
+
     def _project_level(self, l, feat):
         """GroupNorm(input_proj conv + side branch); returns (src, zero-interference loss | None)."""
         main = conv_module_as_gemm(self.input_proj[l][0], feat)  # GEMM library instead of MIOpen
@@ -520,14 +528,30 @@ class GroundingDINO(nn.Module):
             assert targets is not None and self.criterion is not None
             loss_dict = self.criterion(out, targets)
             weight_dict = self.criterion.weight_dict
-            for k in loss_dict.keys():
-                if k in weight_dict:
-                    loss_dict[k] = loss_dict[k] * weight_dict[k]
+            total = None
+            stacked = getattr(loss_dict, "stacked", None)
+            if stacked and all(name + suf in weight_dict for name, (_, sufs) in stacked.items() for suf in sufs):
+                # the criterion made its entries from one vector per loss type: weight the vectors (one multiply per
+                # type), hand out their elements under the reference's keys, and keep the sum for the trainer
+                for name, (vec, sufs) in stacked.items():
+                    w = self._loss_weights(name, sufs, weight_dict, vec)
+                    weighted = vec * w
+                    for s_, suf in enumerate(sufs):
+                        loss_dict[name + suf] = weighted[s_]
+                    total = weighted.sum() if total is None else total + weighted.sum()
+            else:
+                for k in loss_dict.keys():
+                    if k in weight_dict:
+                        loss_dict[k] = loss_dict[k] * weight_dict[k]
             if self.use_project_adapter and self.use_zero_inter_loss_for_conv:
                 loss_dict["loss_conv_adapter"] = loss_conv_adapter * self.loss_adapter_weight
+                total = None if total is None else total + loss_dict["loss_conv_adapter"].reshape(())
             if self.use_cet and self.use_zero_inter_loss:
                 key = "loss_language_adapter" if self.side_branch == "multilayer" else "loss_linear_adapter"
                 loss_dict[key] = loss_linear_adapter * self.loss_adapter_weight
+                total = None if total is None else total + loss_dict[key].reshape(())
+            if total is not None:
+                loss_dict.total = total        # == sum(loss_dict.values()); ZiraTrainer back-propagates this one
             return loss_dict
         return out
 

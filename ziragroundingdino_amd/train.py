@@ -108,7 +108,9 @@ class ZiraTrainer:
         if (next_data is not None and self.amp_dtype is None and hasattr(self.model, "can_prefetch_frontend")
                 and self.model.can_prefetch_frontend()):
             self._prefetched = self.model.prefetch_frontend(next_data)
-        losses = sum(loss_dict.values())
+        losses = getattr(loss_dict, "total", None)   # the model's own sum of the same terms (criterion.LossDict)
+        if losses is None:
+            losses = sum(loss_dict.values())
         losses.backward()
         if self.world > 1 or self.always_reduce:  # single RCCL all-reduce of the side-branch gradients
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
