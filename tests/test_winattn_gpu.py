@@ -23,7 +23,11 @@ def test_swin_layer_native_attention_equals_pytorch_path(H, W, ws, heads):
             want = layer(x, H, W)[0]
         finally:
             zb.SwinTransformerBlock.native_attention = True
-        got = layer(x, H, W)[0]
+        zb.SwinTransformerBlock.native_max_tokens = 256    # (the model keeps 12x12 windows on SDPA; the kernel handles them)
+        try:
+            got = layer(x, H, W)[0]
+        finally:
+            zb.SwinTransformerBlock.native_max_tokens = 64
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) < 2e-5 * max(scale, 1.0), float((got - want).abs().max())
 

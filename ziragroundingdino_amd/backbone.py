@@ -113,7 +113,10 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
-    native_attention = True   # no-grad fp32 GPU forwards: window attention through the C ABI (csrc/winattn.hip)
+    native_max_tokens = 64
+    native_attention = True   # no-grad fp32 GPU forwards with windows of <= 64 tokens (7x7: one query row per lane):
+                              # window attention through the C ABI (csrc/winattn.hip).  12x12 windows (the 384-pixel
+                              # Swin-B / L variants) stay on SDPA: three rows per lane and one wave per block lose to it
 
     def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, drop_path):
         super().__init__()
@@ -137,7 +140,7 @@ class SwinTransformerBlock(nn.Module):
         shortcut = x
         dp0, dp1 = (dp[0], dp[1]) if dp is not None else (None, None)
         if (self.native_attention and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-                and not torch.is_autocast_enabled() and C // self.attn.num_heads == 32 and ws <= 16
+                and not torch.is_autocast_enabled() and C // self.attn.num_heads == 32 and ws * ws <= self.native_max_tokens
                 and self.attn.qkv.bias is not None and self.attn.qkv.weight.dtype == torch.float32):
             x = self._residual(shortcut, self.attn.forward_native(self.norm1(x), H, W, self.shift_size), dp0)
             return self._residual(x, self.mlp(self.norm2(x)), dp1)
