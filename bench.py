@@ -332,8 +332,6 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
-    if args.dtype == "bf16":   # make_graphed_callables under autocast needs its weight-cast cache off: stay eager
-        args.transformer_graph = False
     model.use_transformer_graph = args.transformer_graph
     trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard

@@ -101,7 +101,9 @@ class ZiraTrainer:
         if pre is not None and pre["inputs"] is data:
             kw["frontend"] = pre
         if self.amp_dtype is not None:
-            with torch.autocast(self.flat_grad.device.type, dtype=self.amp_dtype):
+            # (graph capture under autocast needs the weight-cast cache off: torch.cuda.make_graphed_callables)
+            graphs = bool(getattr(self.model, "use_transformer_graph", False))
+            with torch.autocast(self.flat_grad.device.type, dtype=self.amp_dtype, cache_enabled=not graphs):
                 loss_dict = self.model(data, **kw)
         else:
             loss_dict = self.model(data, **kw)
