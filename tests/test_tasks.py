@@ -97,31 +97,34 @@ def test_resume_continues_from_periodic_checkpoint(tmp_path, oracle):
 
     def spec(out, max_iter):
         return TaskSpec(name="a", categories_names=["fish"], data=lambda start: itertools.repeat(data),
-                        max_iter=max_iter, output_dir=str(tmp_path / out), checkpoint_period=2,
+                        max_iter=max_iter, output_dir=str(tmp_path / out), checkpoint_period=1,
                         lr_multiplier=multistep_lr_multiplier(2))
 
-    whole = torch.load(run_task(spec("whole", 3), build, None), weights_only=False)["model"]
+    whole = torch.load(run_task(spec("whole", 4), build, None), weights_only=False)["model"]
 
     class _Cut(Exception):
         pass
 
     def cut(spec_, it, loss_dict):
-        if it == 2:
+        if it == 3:
             raise _Cut()
 
-    with pytest.raises(_Cut):
-        run_task(spec("cut", 3), build, None, on_step=cut)
-    assert sorted(os.listdir(tmp_path / "cut")) == ["last_checkpoint", "model_0000001.pth"]
+    with pytest.raises(_Cut):   # cut AFTER the decay iteration: the checkpoint holds the multiplied learning rates
+        run_task(spec("cut", 4), build, None, on_step=cut)
+    assert sorted(os.listdir(tmp_path / "cut")) == ["last_checkpoint", "model_0000000.pth", "model_0000001.pth",
+                                                    "model_0000002.pth"]
+    lrs = [g["lr"] for g in torch.load(tmp_path / "cut" / "model_0000002.pth", weights_only=False)["trainer"]["optimizer"]["param_groups"]]
+    assert max(lrs) == pytest.approx(1e-4)
     seen = []
-    final = run_task(spec("cut", 3), build, None, resume=True, on_step=lambda s, it, l: seen.append(it))
-    assert seen == [2]
+    final = run_task(spec("cut", 4), build, None, resume=True, on_step=lambda s, it, l: seen.append(it))
+    assert seen == [3]
     resumed = torch.load(final, weights_only=False)["model"]
     for n, v in whole.items():
         if "adapter" in n:
             close(resumed[n], v, 1e-6, "resumed " + n)
     # a finished task is not trained again
-    assert run_task(spec("cut", 3), build, None, resume=True, on_step=lambda *a: seen.append("again")) == final
-    assert seen == [2]
+    assert run_task(spec("cut", 4), build, None, resume=True, on_step=lambda *a: seen.append("again")) == final
+    assert seen == [3]
 
 
 def _chain_worker(rank, world, port, gpath, out_dir):

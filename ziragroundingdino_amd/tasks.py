@@ -114,8 +114,9 @@ def run_task(spec: TaskSpec, build_model, init_checkpoint: Optional[str], device
     model = load_model(build_model, init_checkpoint, device)
     trainer = ZiraTrainer(model, lr=spec.lr, weight_decay=spec.weight_decay, clip_max_norm=spec.clip_max_norm,
                           clip_norm_type=spec.clip_norm_type, process_group=process_group)
-    start_iter = _resume(spec, model, trainer) if resume else 0
-    base_lrs = [g["lr"] for g in trainer.optimizer.param_groups]
+    base_lrs = [g["lr"] for g in trainer.optimizer.param_groups]   # before a resume: a checkpoint stores the
+    start_iter = _resume(spec, model, trainer) if resume else 0    # MULTIPLIED rates of the iteration it was taken at
+    assert len(base_lrs) == len(trainer.optimizer.param_groups)
     multiplier = spec.multiplier()
     period = spec.checkpoint_period or spec.max_iter
     batches = iter(spec.data(start_iter))
