@@ -145,6 +145,48 @@ def msda_micro(dev):
     return out
 
 
+def inmodel_replay(trainer, data, dev):
+    """The MSDA calls of one real step (last decoder layer and last encoder layer: sampling locations and attention
+    weights as the model produces them), re-issued back to back from a hipGraph: kernel time on the model's inputs
+    without the launch gaps that HIP events around eager launches include."""
+    from ziragroundingdino_amd import _C
+    got = {}
+    orig_f, orig_b = _C.ms_deform_attn_forward, _C.ms_deform_attn_backward
+
+    def hook(value, sh, st, loc, attn, go, step):
+        key = "enc" if loc.shape[1] == value.shape[1] else "dec"
+        if key not in got:
+            got[key] = [t.detach().clone() for t in (value, sh, st, loc, attn, go)]
+        return orig_b(value, sh, st, loc, attn, go, step)
+
+    use_graph = trainer.model.use_transformer_graph
+    trainer.model.use_transformer_graph = False
+    _C.ms_deform_attn_backward = hook
+    try:
+        trainer.run_step(data)
+    finally:
+        _C.ms_deform_attn_backward = orig_b
+        trainer.model.use_transformer_graph = use_graph
+    torch.cuda.synchronize()
+    out = {}
+    for key, (v, sh, st, loc, attn, go) in got.items():
+        B, S, M, D = v.shape
+        Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        fb, bb = msda_algorithmic_bytes(B, S, M, D, L, Q, P)
+        fwd = lambda: orig_f(v, sh, st, loc, attn, 64)
+        bwd = lambda: orig_b(v, sh, st, loc, attn, go, 64)
+        per, iters = 10, (200 if key == "dec" else 50)
+        res = {"dims_BSMDLQP": [B, S, M, D, L, Q, P], "warmup": 20, "iters": iters}
+        for name, fn, nbytes in (("fwd", fwd, fb), ("bwd", bwd, bb), ("pair", lambda: (fwd(), bwd()), fb + bb)):
+            g = graphed(fn, per)
+            timeit(g, 2)
+            us = timeit(g, max(1, iters // per)) / per
+            res[name + "_us"] = us
+            res[name + "_frac"] = nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        out[key] = res
+    return out
+
+
 def cpu_baseline_msda(threads):
     """The op alone on the host cores, SURVEY.md section 8(d) inputs: the reference's fallback
     formulation (per-level grid_sample + autograd; ziragroundingdino_amd's product-side function)
@@ -378,6 +420,9 @@ def main():
         timing_source = ("HIP events around every native MSDA call of %d eager steps run right after the timed "
                          "region (its steps replay the transformer from hipGraphs, which hides the launches)"
                          % args.kernel_timing_steps)
+    replay = None
+    if rank == 0 and not args.no_micro:
+        replay = inmodel_replay(trainer, data, dev)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -411,6 +456,8 @@ def main():
                              "algorithmic_bytes": nbytes, "avg_us": t_pair * 1e6})
         if not args.no_micro:
             roofline["micro"] = msda_micro(dev)
+        if replay:
+            roofline["inmodel_replay"] = replay
         images = args.steps * args.batch * world
         flagship = args.backbone == "swin_T_224_1k" and args.dtype == "f32"
         size = "T" if args.backbone.startswith("swin_T") else "B"
