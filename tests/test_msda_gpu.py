@@ -194,6 +194,36 @@ def test_encoder_shape_against_oracle(oracle, pattern):
         _close(g, w, 5e-5 if name == "grad_value" else 2e-5, name)
 
 
+@pytest.mark.parametrize("D,M,P,shapes", [(16, 8, 4, [(64, 80), (32, 40), (16, 20)]), (64, 4, 2, [(96, 120), (48, 60), (24, 30)]),
+                                          (32, 8, 3, [(70, 91), (35, 46)])])
+def test_dense_backward_other_widths_against_oracle(oracle, D, M, P, shapes):
+    """The dense (cell walk) backward at the other specialised channel widths and level / point counts (the model only
+    ever calls it with D = 32, L = 4, P = 4): queries on the pixel grid of every level, N(0, 1.5 px) offsets plus a few
+    far-away and out-of-range samples."""
+    sh = np.asarray(shapes, dtype=np.int64)
+    S = int((sh[:, 0] * sh[:, 1]).sum())
+    B, L = 2, len(shapes)
+    assert B * M * S >= 16 * 4096, "not a dense call"
+    rng = np.random.default_rng(D + P)
+    value, _, start, _, attn, go = _random_case(B, S, M, D, shapes, P, seed=D)
+    ref = np.concatenate([
+        np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2)
+        for h, w in shapes]).astype(np.float32)
+    off_px = 1.5 * rng.standard_normal((B, S, M, L, P, 2)).astype(np.float32)
+    far = rng.random((B, S, M, L, P)) < 0.02
+    off_px[far] += rng.uniform(-60, 60, (int(far.sum()), 2)).astype(np.float32)
+    norm = np.stack([sh[:, 1], sh[:, 0]], -1).astype(np.float32)[None, None, None, :, None, :]
+    loc = np.ascontiguousarray((ref[None, :, None, None, None, :] + off_px / norm).astype(np.float32))
+    want_out = oracle.msda_forward(value, sh, start, loc, attn)
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    tv, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    _close(_C.ms_deform_attn_forward(tv, tsh, tst, tloc, tattn, 64), want_out, 2e-5, "output")
+    got = _C.ms_deform_attn_backward(tv, tsh, tst, tloc, tattn, tgo, 64)
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        _close(g, w, 5e-5 if name == "grad_value" else 2e-5, name)
+
+
 def test_full_size_properties():
     """BASELINE shape (B=2,Q=900,M=8,D=32,L=4,P=4), no oracle: linearity in value / attn /
     grad_out, zero for fully-outside samples, adjointness <out, go> == <value, grad_value>."""
