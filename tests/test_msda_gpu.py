@@ -224,6 +224,70 @@ def test_dense_backward_other_widths_against_oracle(oracle, D, M, P, shapes):
         _close(g, w, 5e-5 if name == "grad_value" else 2e-5, name)
 
 
+def _dense_case(seed, B=2, M=8, D=32, P=4, shapes=((64, 80), (32, 40), (16, 20))):
+    """Queries on the pixel grid of every level (Q = S), N(0, 1.5 px) offsets: a dense call (heads * Q >= 65536)."""
+    sh = np.asarray(shapes, dtype=np.int64)
+    S = int((sh[:, 0] * sh[:, 1]).sum())
+    L = len(shapes)
+    assert B * M * S >= 16 * 4096
+    rng = np.random.default_rng(seed)
+    value, _, start, _, attn, go = _random_case(B, S, M, D, shapes, P, seed=seed)
+    ref = np.concatenate([
+        np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2)
+        for h, w in shapes]).astype(np.float32)
+    off_px = 1.5 * rng.standard_normal((B, S, M, L, P, 2)).astype(np.float32)
+    norm = np.stack([sh[:, 1], sh[:, 0]], -1).astype(np.float32)[None, None, None, :, None, :]
+    loc = np.ascontiguousarray((ref[None, :, None, None, None, :] + off_px / norm).astype(np.float32))
+    return value, sh, start, loc, attn, go
+
+
+@pytest.mark.parametrize("gscale,ascale", [(1e-30, 1.0), (1e30, 1.0), (1.0, 37.5), (3e-12, 1e-3)])
+def test_dense_backward_fixed_point_scale(oracle, gscale, ascale):
+    """The dense D = 32 backward sums grad_value in 64-bit fixed point whose scale follows max|grad_out| * max|attn|:
+    the result must not depend on the magnitude of either."""
+    value, sh, start, loc, attn, go = _dense_case(5)
+    go = (go * np.float32(gscale)).astype(np.float32)
+    attn = (attn * np.float32(ascale)).astype(np.float32)
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = _C.ms_deform_attn_backward(*map(t, (value, sh, start, loc, attn, go)), 64)
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        w = np.asarray(w, dtype=np.float64)
+        unit = float(np.abs(w).max())
+        assert unit > 0 and np.isfinite(unit)
+        err = float(np.abs(g.cpu().numpy().astype(np.float64) - w).max()) / unit
+        assert err <= 5e-5, "%s: %.3e of the largest entry" % (name, err)
+
+
+def test_dense_backward_is_run_to_run_identical():
+    value, sh, start, loc, attn, go = _dense_case(6)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    args = list(map(t, (value, sh, start, loc, attn, go)))
+    first = _C.ms_deform_attn_backward(*args, 64)
+    for _ in range(3):
+        again = _C.ms_deform_attn_backward(*args, 64)
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("poison", [float("inf"), float("nan")])
+def test_dense_backward_non_finite_grad_out(oracle, poison):
+    """Non-finite gradients (an overflowed loss scale) cannot be summed in fixed point: the call falls back to the
+    float path and propagates them like the reference does."""
+    value, sh, start, loc, attn, go = _dense_case(7)
+    go.reshape(go.shape[0], go.shape[1], -1)[1, 1234, 3 * 32 + 5] = poison
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = _C.ms_deform_attn_backward(*map(t, (value, sh, start, loc, attn, go)), 64)
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        g = g.cpu().numpy()
+        fin = np.isfinite(w)
+        assert not fin.all(), name if name != "grad_value" else "oracle did not propagate"
+        assert not np.isfinite(g[~fin]).any(), "%s: finite where the reference is not" % name
+        scale = max(1.0, float(np.abs(w[fin]).max()))
+        assert float(np.abs(g[fin] - w[fin]).max()) / scale <= 5e-5, name
+
+
 def test_full_size_properties():
     """BASELINE shape (B=2,Q=900,M=8,D=32,L=4,P=4), no oracle: linearity in value / attn /
     grad_out, zero for fully-outside samples, adjointness <out, go> == <value, grad_value>."""

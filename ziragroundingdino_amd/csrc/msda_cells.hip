@@ -52,6 +52,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "msda_internal.h"
 
@@ -78,6 +79,25 @@
 #endif
 #ifndef ZIRA_WALK_GRID_SPARSE
 #define ZIRA_WALK_GRID_SPARSE 4096
+#endif
+
+#ifndef ZIRA_DENSE_ACCUM
+#define ZIRA_DENSE_ACCUM 1   // dense calls with D = 32: msda_bwd_accum (LDS fixed-point accumulators) instead of the walk
+#endif
+#ifndef ZIRA_ACC_TWL
+#define ZIRA_ACC_TWL 3       // accumulate: log2 of the tile width (tiles of 15 x 8 pixels: two blocks per CU)
+#endif
+#ifndef ZIRA_ACC_VSTAR
+#define ZIRA_ACC_VSTAR 8192  // accumulate: records a work item should hold
+#endif
+#ifndef ZIRA_ACC_THREADS
+#define ZIRA_ACC_THREADS 512
+#endif
+#ifndef ZIRA_ACC_DR
+#define ZIRA_ACC_DR 3      // accumulate: grad_out rows requested this many records ahead (DR + 1 divides 8)
+#endif
+#ifndef ZIRA_ACC_ABL
+#define ZIRA_ACC_ABL 0   // developer timing builds (wrong results): 1 no accumulator adds, 2 no home dots, 4 all grad_out rows = row 0
 #endif
 
 #ifndef ZIRA_ABL
@@ -125,7 +145,7 @@ inline FastDiv make_fast_div(unsigned d)
 }
 
 struct CellGeom {
-    unsigned S, M, L, P, LP, Q, heads;
+    unsigned S, M, L, P, LP, Q, heads, D;
     unsigned ng, thp;          // walkers per wave (64 / LPG) and pixel rows per tile (ng - 1)
     unsigned twl_max, twl_min; // log2 of the segment width: upper / lower limit of the per-level choice
     unsigned vstar;            // records a work item should hold
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
     const float *__restrict__ loc, const float *__restrict__ attn,
     const int64_t *__restrict__ shapes, CellGeom G, float *__restrict__ grad_loc,
     float *__restrict__ grad_attn, unsigned *__restrict__ desc, uint4 *__restrict__ region,
-    unsigned *__restrict__ tickets)
+    unsigned *__restrict__ tickets, const float *__restrict__ grad_out, unsigned *__restrict__ amax_blk)
 {
     extern __shared__ unsigned lds_bin[];
     Level *lv = reinterpret_cast<Level *>(lds_bin);                 // [kMaxLevels]
@@ -302,6 +322,19 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
     for (unsigned i = threadIdx.x; i < NTW; i += kBinThreads) hist[i] = 0;
     __syncthreads();
 
+    // (accumulate path) largest |grad_out| of the block's rows and largest |attention weight| of its samples, as bit
+    // patterns (NaN > inf > finite): they set the fixed-point scale of the accumulators
+    unsigned mx_g = 0, mx_a = 0;
+    if (amax_blk) {
+        const unsigned d4 = G.D / 4;
+        for (unsigned i = threadIdx.x; i < G.QB * d4; i += kBinThreads) {
+            const unsigned ql = i / d4, c = i - ql * d4, q = blk * G.QB + ql;
+            if (q >= G.Q) continue;
+            const uint4 gb = *reinterpret_cast<const uint4 *>(grad_out + ((size_t)(b * G.Q + q) * G.M + m) * G.D + c * 4);
+            const unsigned m01 = max(gb.x & 0x7fffffffu, gb.y & 0x7fffffffu), m23 = max(gb.z & 0x7fffffffu, gb.w & 0x7fffffffu);
+            mx_g = max(mx_g, max(m01, m23));
+        }
+    }
     const unsigned nsamp = G.QB * G.LP;
     for (unsigned idx = threadIdx.x; idx < nsamp; idx += kBinThreads) {
         const unsigned ql = fast_div(idx, G.LPdiv), s = idx - ql * G.LP, q = blk * G.QB + ql;
@@ -311,6 +344,7 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
         const unsigned l = fast_div(s, G.Pdiv);
         const Level L = lv[l];
         const SampleGeo geo = sample_geo(xy.x, xy.y, attn[si], L.H, L.W);
+        mx_a = max(mx_a, __float_as_uint(geo.a) & 0x7fffffffu);
         if (!geo.valid) {  // contributes nothing anywhere (cuh:288): its gradients are zero
             *reinterpret_cast<float2 *>(grad_loc + 2 * si) = make_float2(0.f, 0.f);
             grad_attn[si] = 0.f;
@@ -327,7 +361,14 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
         ranks[idx * 2] = r00 | (r01 << 16);
         ranks[idx * 2 + 1] = r10 | (r11 << 16);
     }
+    if (amax_blk) {
+        if (threadIdx.x < 2) misc[12 + threadIdx.x] = 0;
+        __syncthreads();
+        atomicMax(&misc[12], mx_g);
+        atomicMax(&misc[13], mx_a);
+    }
     __syncthreads();
+    if (amax_blk && threadIdx.x < 2) amax_blk[2 * blockIdx.x + threadIdx.x] = misc[12 + threadIdx.x];
 
     // exclusive scan of the histogram, two tiles per thread; hist[] becomes the offsets and this
     // block's descriptor row gets {offset << 16 | count} for every tile of the head
@@ -421,6 +462,15 @@ __device__ __forceinline__ float group_sum(float x)
     return x;
 }
 
+// lane (8 g + j) <- lane (8 g + I): `row_newbcast` broadcasts one lane of every 16-lane row; the two halves of a
+// row take different source lanes, selected with the bank mask (banks = 4 lanes)
+template <unsigned I>
+__device__ __forceinline__ unsigned bcast8(unsigned x)
+{
+    unsigned r = __builtin_amdgcn_update_dpp(0u, x, 0x150 + I, 0xf, 0xf, true);
+    return __builtin_amdgcn_update_dpp(r, x, 0x150 + 8 + I, 0xf, 0xc, false);
+}
+
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, unsigned lane)
 {
 #pragma unroll
@@ -482,8 +532,9 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ start, CellGeom G,
     const unsigned *__restrict__ desc, const uint4 *__restrict__ region, float *__restrict__ partial,
     unsigned *__restrict__ tickets, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn)
+    float *__restrict__ grad_attn, const unsigned *__restrict__ only_if)
 {
+    if (only_if && *only_if == 0) return;   // (behind msda_bwd_accum: only when that kernel declined)
     constexpr unsigned NG = 64 / LPG;       // walkers per wave
     constexpr unsigned THP = NG - 1;        // pixel rows per tile
     constexpr unsigned NV = D / (4 * LPG);  // float4 pieces of a row per lane
@@ -894,6 +945,344 @@ __global__ __launch_bounds__(256) void msda_bwd_fold(const int64_t *__restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K2': accumulate (dense calls, D = 32)
+// ------------------------------------------------------------------------------------------
+// The walk is bound by the instructions that keep 16 walkers in lockstep (sorting a tile's records by
+// (walker, step), padding, the transitions).  This kernel does not order anything: a block takes a
+// work item, puts the tile's value rows (plus the one-pixel frame the home cells need) and a zeroed
+// accumulator tile into LDS and streams the item's records in the order the bin kernel left them.
+// Eight lanes (four channels each) handle one record: the four <grad_out, value row> dots from the LDS
+// value tile give grad_attn / grad_loc for home records, and the four corner rows are ADDED TO THE LDS
+// ACCUMULATORS -- not as floats: `ds_add_f32` executes at ~3 cycles per LANE on gfx950 (193 cycles per
+// wave instruction measured), `ds_add_u64` at 7 cycles per wave instruction.  Every term w * (a * g)
+// is formed in fp32 exactly as the reference forms it (cuh:117-147), scaled by a power of two chosen
+// from max|grad_out| * max|attn| (found by the bin kernel) so that it lies below 2^38, rounded to an
+// integer and added as a 64-bit integer.  The sum of a pixel is therefore EXACT (no rounding between
+// terms, 2^25 terms of headroom), independent of the order of the records, and rounded to fp32 once
+// when the tile is flushed: grad_value becomes run-to-run identical and at least as close to the
+// reference as an fp32 accumulation in any order.  Non-finite inputs (the bin kernel's maxima catch
+// them) cannot be represented: the kernel then leaves everything to the walk, which is launched
+// behind it and returns at once in the normal case.
+constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52: (double)x + kMagic holds rint(x) in its low mantissa bits
+constexpr int kAccBits = 38;
+
+template <int D, int NTHR>
+__global__ __launch_bounds__(NTHR) void msda_bwd_accum(
+    const float *__restrict__ grad_out, const float *__restrict__ value,
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ start, CellGeom G,
+    const unsigned *__restrict__ desc, const uint4 *__restrict__ region, float *__restrict__ partial,
+    unsigned *__restrict__ tickets, const unsigned *__restrict__ amax_blk, unsigned *__restrict__ flag,
+    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    constexpr unsigned LPS = D / 4;        // lanes per record
+    constexpr unsigned RPW = 64 / LPS;     // records per wave step
+    constexpr unsigned NWV = NTHR / 64;
+    static_assert(LPS == 8, "D = 32");
+    extern __shared__ unsigned lds_acc[];
+    Level *lv = reinterpret_cast<Level *>(lds_acc);            // [kMaxLevels]
+    unsigned *misc = lds_acc + kLevelWords * kMaxLevels;       // [16]
+    unsigned *runpre = misc + 16;                              // [nblk + 1]
+    unsigned *runoff = runpre + G.nblk + 1;                    // [nblk]
+    const unsigned twm = 1u << G.twl_max, VC = twm + 2, VR = G.thp + 2;
+    unsigned hdr = kLevelWords * kMaxLevels + 16 + 2 * G.nblk + 1;
+    hdr = (hdr + 3) & ~3u;
+    float *val = reinterpret_cast<float *>(lds_acc + hdr);     // [VR][VC][D]  pixels (ty*thp - 1 + r, x0 - 1 + c)
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(val + VR * VC * D);  // [thp][twm][D]
+
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned grp = lane / LPS, j = lane % LPS;
+    load_levels(shapes, G, lv, misc);
+    const unsigned NT = misc[0], NW = misc[1];
+    if (NT > G.ntmax) return;
+
+    // fixed-point scale from the bin kernel's maxima
+    {
+        unsigned ug = 0, ua = 0;
+        for (unsigned i = tid; i < G.heads * G.nblk; i += NTHR) {
+            const uint2 w = reinterpret_cast<const uint2 *>(amax_blk)[i];
+            ug = max(ug, w.x);
+            ua = max(ua, w.y);
+        }
+        if (tid < 2) misc[8 + tid] = 0;
+        __syncthreads();
+        atomicMax(&misc[8], ug);
+        atomicMax(&misc[9], ua);
+        __syncthreads();
+    }
+    const unsigned ug = misc[8], ua = misc[9];
+    const bool bad = ug >= 0x7f800000u || ua >= 0x7f800000u;
+    if (blockIdx.x == 0 && tid == 0) *flag = bad ? 1u : 0u;
+    if (bad) return;
+    // |g| < 2^(eg + 1), |a| < 2^(ea + 1): every term w * (a * g) (w <= 1) is below 2^(eg + ea + 2).  The power of two
+    // that takes it below 2^kAccBits is applied in two exact steps so that no intermediate leaves the normal range
+    // whatever the magnitudes: sA goes into the attention weight (a * g then peaks near 1), sC into the corner weight.
+    float scaleA, scaleC;
+    double unscale;
+    {
+        const int eg = (int)(ug >> 23) - 127, ea = (int)(ua >> 23) - 127;
+        int sA = -(eg + ea + 2);
+        sA = sA > 120 - ea ? 120 - ea : (sA < -120 - ea ? -120 - ea : sA);
+        sA = sA > 126 ? 126 : (sA < -126 ? -126 : sA);
+        int sC = kAccBits - (eg + ea + 2) - sA;
+        sC = sC > 120 ? 120 : (sC < -100 ? -100 : sC);
+        scaleA = __uint_as_float((unsigned)(sA + 127) << 23);
+        scaleC = __uint_as_float((unsigned)(sC + 127) << 23);
+        unscale = __longlong_as_double((long long)(1023 - (sA + sC)) << 52);
+    }
+
+    const unsigned nvirt = G.heads * NW, per = (nvirt + 7) >> 3;
+    const unsigned xcd = blockIdx.x & 7;
+    constexpr unsigned ulmask = (1u << kUlBits) - 1, vlmask = (1u << (9 - kUlBits)) - 1;
+    const unsigned THP = G.thp;
+    const unsigned rs = G.M * D;
+    const unsigned mlp = G.M * G.LP;
+
+    for (;;) {
+        __syncthreads();  // (the previous item's LDS is no longer read)
+        if (tid == 0) misc[10] = atomicAdd(&tickets[xcd * 16], 1u);
+        __syncthreads();
+        const unsigned tix = misc[10];
+        const unsigned vt = xcd * per + tix;
+        if (tix >= per || vt >= nvirt) break;
+        const unsigned head = vt / NW;
+        const Item it = decode_item(lv, G.L, NW - 1 - (vt - head * NW));
+        const unsigned b = fast_div(head, G.Mdiv), m = head - b * G.M;
+        const Level Lv = lv[it.l];
+        const unsigned tw = 1u << Lv.twl;
+        const int H = Lv.H, W = Lv.W;
+        const unsigned st = (unsigned)start[it.l];
+        const uint4 *reg_h = region + (size_t)head * G.nblk * G.slice;
+        const int y0 = (int)(it.ty * THP), x0 = (int)(it.seg * tw);
+        const float *vbase = value + (((size_t)b * G.S + st) * G.M + m) * D;
+        float *gvbase = grad_value + (((size_t)b * G.S + st) * G.M + m) * D;
+
+        // ---- wave 0: the tile's runs; the others: value tile, zeroed accumulators ---------------
+        if (wave == 0) {
+            unsigned n = 0, nruns = 0;
+            const unsigned *drow = desc + ((size_t)head * NT + it.tile) * G.nblk;
+            for (unsigned c0 = 0; c0 < G.nblk; c0 += 64 * 8) {
+                unsigned d[8];
+#pragma unroll
+                for (unsigned k = 0; k < 8; ++k) {
+                    const unsigned i = c0 + 64 * k + lane;
+                    d[k] = i < G.nblk ? drow[i] : 0u;
+                }
+#pragma unroll
+                for (unsigned k = 0; k < 8; ++k) {
+                    if (c0 + 64 * k < G.nblk) {
+                        const unsigned i = c0 + 64 * k + lane;
+                        const unsigned cn = d[k] & 0xffffu;
+                        const unsigned incl = wave_incl_scan(cn, lane);
+                        const unsigned long long mask = __ballot(cn != 0);
+                        const unsigned slot = nruns + __popcll(mask & ((1ull << lane) - 1));
+                        if (cn) {
+                            runpre[slot] = n + incl - cn;
+                            runoff[slot] = i * G.slice + (d[k] >> 16);
+                        }
+                        n += __shfl(incl, 63);
+                        nruns += __popcll(mask);
+                    }
+                }
+            }
+            if (lane == 0) {
+                runpre[nruns] = n;
+                misc[11] = n;
+                misc[12] = nruns;
+            }
+            ZIRA_WAVE_SYNC();
+            // This work item's share of the records: whole runs (the ORDER of the records inside a run is not
+            // reproducible -- the bin kernel ranks them with an LDS atomic -- but the set is, and so is every sum
+            // over whole runs): share k starts at the first run boundary at or behind n k / K.
+            if (lane < 2) {
+                const unsigned t = (unsigned)(((unsigned long long)n * (it.k + lane)) / Lv.K);
+                unsigned lo = 0, hi = nruns;      // smallest i with runpre[i] >= t
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (runpre[mid] >= t) hi = mid; else lo = mid + 1;
+                }
+                misc[13 + lane] = runpre[lo];
+            }
+        }
+        for (unsigned i = tid; i < VR * (tw + 2) * LPS; i += NTHR) {
+            const unsigned c4 = i % LPS, pix = i / LPS, r = pix / (tw + 2), c = pix - r * (tw + 2);
+            const int y = y0 - 1 + (int)r, x = x0 - 1 + (int)c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H && x >= 0 && x < W)
+                v = *reinterpret_cast<const float4 *>(vbase + ((size_t)y * W + x) * rs + c4 * 4);
+            *reinterpret_cast<float4 *>(val + (r * VC + c) * D + c4 * 4) = v;
+        }
+        for (unsigned i = tid; i < THP * twm * D / 2; i += NTHR)
+            reinterpret_cast<uint4 *>(acc)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const unsigned n = misc[11], nruns = misc[12];
+        const unsigned e0 = misc[13], e1 = misc[14];
+
+        const float *gbase = grad_out + ((size_t)b * G.Q * G.M + m) * D;
+        float *ga_h = grad_attn + ((size_t)b * G.Q * G.M + m) * G.LP + (size_t)it.l * G.P;
+        float *gl_h = grad_loc + 2 * (((size_t)b * G.Q * G.M + m) * G.LP + (size_t)it.l * G.P);
+        const float Wa = (float)W, Ha = (float)H;
+
+        // ---- records: 64 per wave and round; group g takes records 8 g .. 8 g + 7 of the round, one per step ------
+        // A lane loads ONE record (lane L: record c0 + L, a coalesced kilobyte per wave) a round ahead and derives
+        // what does not depend on the channel (accumulator rows of the four corners, value-tile position, output
+        // index) ONCE; at step i the group's lanes read those words out of lane 8 g + i with DPP row broadcasts.
+        // The grad_out row of step i + DR is requested while step i is computed (ring of NR rows).  Corners that
+        // belong to a neighbouring tile (which holds a copy of the record) go to a per-group trash row instead of
+        // being branched around.
+        constexpr unsigned DR = ZIRA_ACC_DR, NR = DR + 1;
+        static_assert(RPW % NR == 0, "ring slots are static across rounds");
+        struct Prep {
+            unsigned lw, lh, a, a01, a23, vh, oi, qo;
+        };
+        auto locate = [&](unsigned c0) {
+            uint4 rec = make_uint4(kInvalidVisit, 0u, 0u, 0u);
+            const unsigned e = c0 + lane;
+            if (c0 < e1 && e < e1) {
+                unsigned lo = 0, hi = nruns;      // runpre[lo] <= e < runpre[hi]
+                while (hi - lo > 1) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (runpre[mid] <= e) lo = mid; else hi = mid;
+                }
+                rec = reg_h[runoff[lo] + (e - runpre[lo])];
+            }
+            return rec;
+        };
+        const unsigned trash = (THP * twm + grp) * D;   // (accumulator rows behind the tile, one per group)
+        auto prepare = [&](const uint4 &rec) {
+            Prep P;
+            const unsigned w0 = rec.x;
+            const bool okr = w0 != kInvalidVisit;
+            const unsigned ul = (w0 >> kCellShift) & ulmask, vl = (w0 >> (kCellShift + kUlBits)) & vlmask;
+            const unsigned q = w0 & ((1u << kQBits) - 1), pp = (w0 >> kQBits) & ((1u << kPBits) - 1);
+            unsigned ad[4];
+#pragma unroll
+            for (unsigned c = 0; c < 4; ++c) {
+                const unsigned pr = ul - 1 + (c >> 1), pc = vl - 1 + (c & 1);   // (unsigned: -1 wraps and fails the test)
+                ad[c] = (okr && pr < THP && pc < tw && !(ZIRA_ACC_ABL & 1)) ? (pr * twm + pc) * D : trash;
+            }
+            const int u = y0 + (int)ul, v = x0 + (int)vl;
+            const bool home = okr && (vl < tw || v == W) && (ul < THP || u == H) && !(ZIRA_ACC_ABL & 2);
+            P.lw = rec.y;
+            P.lh = rec.z;
+            P.a = okr ? rec.w : 0u;
+            P.a01 = ad[0] | (ad[1] << 16);
+            P.a23 = ad[2] | (ad[3] << 16);
+            P.vh = (home ? ((ul * VC + vl) * D) : 0u) | (home ? 0x10000u : 0u);
+            P.oi = q * mlp + pp;
+            P.qo = (okr && !(ZIRA_ACC_ABL & 4)) ? q * rs : 0u;
+            return P;
+        };
+        float4 ring[NR];
+        auto issue_row = [&](float4 &dst, unsigned qo) {
+            dst = *reinterpret_cast<const float4 *>(gbase + (qo + j * 4));
+        };
+        Prep cur = prepare(locate(e0 + wave * 64)), nprep;
+        uint4 nxt;
+        auto step = [&](auto ic) {
+            constexpr unsigned i = decltype(ic)::value;
+            {   // the row of step i + DR (of the next round when it is past this one's end)
+                constexpr unsigned t = i + DR;
+                if (t == RPW) nprep = prepare(nxt);
+                issue_row(ring[t % NR], t < RPW ? bcast8<t % RPW>(cur.qo) : bcast8<t % RPW>(nprep.qo));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float lw = __uint_as_float(bcast8<i>(cur.lw)), lh = __uint_as_float(bcast8<i>(cur.lh));
+            const float a = __uint_as_float(bcast8<i>(cur.a));
+            const unsigned a01 = bcast8<i>(cur.a01), a23 = bcast8<i>(cur.a23), vh = bcast8<i>(cur.vh);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w00 = __fmul_rn(hh, hw), w01 = __fmul_rn(hh, lw), w10 = __fmul_rn(lh, hw), w11 = __fmul_rn(lh, lw);
+            const float4 g4 = ring[i % NR];
+            if (vh >> 16) {
+                const float *vp = val + ((vh & 0xffffu) + j * 4);
+                const float4 v00 = *reinterpret_cast<const float4 *>(vp);
+                const float4 v01 = *reinterpret_cast<const float4 *>(vp + D);
+                const float4 v10 = *reinterpret_cast<const float4 *>(vp + VC * D);
+                const float4 v11 = *reinterpret_cast<const float4 *>(vp + VC * D + D);
+                const float p00 = dot4(g4, v00, 0.f), p01 = dot4(g4, v01, 0.f);
+                const float p10 = dot4(g4, v10, 0.f), p11 = dot4(g4, v11, 0.f);
+                float ga = __fmul_rn(w00, p00);
+                ga = fmaf(w01, p01, ga);
+                ga = fmaf(w10, p10, ga);
+                ga = fmaf(w11, p11, ga);
+                float gx = fmaf(hh, __fsub_rn(p01, p00), __fmul_rn(lh, __fsub_rn(p11, p10)));
+                float gy = fmaf(hw, __fsub_rn(p10, p00), __fmul_rn(lw, __fsub_rn(p11, p01)));
+                ga = group_sum<LPS>(ga);
+                gx = group_sum<LPS>(gx);
+                gy = group_sum<LPS>(gy);
+                const unsigned oi = bcast8<i>(cur.oi);
+                if (j == 0) {
+                    ga_h[oi] = ga;
+                    *reinterpret_cast<float2 *>(gl_h + 2 * oi) =
+                        make_float2(__fmul_rn(__fmul_rn(Wa, a), gx), __fmul_rn(__fmul_rn(Ha, a), gy));
+                }
+            }
+            // corner rows: term = w * (a * g), as the reference forms it, times 2^(sA + sC) (exact: folded into a and w)
+            const float as = __fmul_rn(a, scaleA);
+            const float tt[4] = {__fmul_rn(g4.x, as), __fmul_rn(g4.y, as), __fmul_rn(g4.z, as), __fmul_rn(g4.w, as)};
+            const float wc[4] = {__fmul_rn(w00, scaleC), __fmul_rn(w01, scaleC), __fmul_rn(w10, scaleC), __fmul_rn(w11, scaleC)};
+            const unsigned ad[4] = {a01 & 0xffffu, a01 >> 16, a23 & 0xffffu, a23 >> 16};
+#pragma unroll
+            for (unsigned c = 0; c < 4; ++c) {
+                // accumulator row layout: slot k * LPS + j holds channel 4 j + k, so that the lanes of a record
+                // add to consecutive 8-byte words (32-byte lane strides run at half the rate)
+                unsigned long long *ap = acc + (ad[c] + j);
+#pragma unroll
+                for (unsigned k = 0; k < 4; ++k) {
+                    const double dd = (double)__fmul_rn(wc[c], tt[k]) + kMagic;
+                    const unsigned long long nn = (unsigned long long)(__double_as_longlong(dd) - __double_as_longlong(kMagic));
+                    atomicAdd(ap + k * LPS, nn);
+                }
+            }
+        };
+        if (e0 + wave * 64 < e1) {
+            issue_row(ring[0], bcast8<0>(cur.qo));
+            if (DR > 1) issue_row(ring[1 % NR], bcast8<1>(cur.qo));
+            if (DR > 2) issue_row(ring[2 % NR], bcast8<2>(cur.qo));
+        }
+        for (unsigned c0 = e0 + wave * 64; c0 < e1; c0 += NWV * 64) {
+            nxt = locate(c0 + NWV * 64);
+            step(std::integral_constant<unsigned, 0>{});
+            step(std::integral_constant<unsigned, 1>{});
+            step(std::integral_constant<unsigned, 2>{});
+            step(std::integral_constant<unsigned, 3>{});
+            step(std::integral_constant<unsigned, 4>{});
+            step(std::integral_constant<unsigned, 5>{});
+            step(std::integral_constant<unsigned, 6>{});
+            step(std::integral_constant<unsigned, 7>{});
+            cur = nprep;
+        }
+        __syncthreads();
+
+        // ---- flush: every pixel of the tile once ------------------------------------------------
+        float *obase;
+        size_t orow;      // floats between pixel rows
+        unsigned ostride; // floats between pixels
+        if (Lv.K > 1) {
+            const size_t prow = (size_t)head * G.prows_max + Lv.pbase + (size_t)((it.tile - Lv.tbase) * Lv.K + it.k) * (THP * tw);
+            obase = partial + prow * D;
+            orow = (size_t)tw * D;
+            ostride = D;
+        } else {
+            obase = gvbase + ((size_t)y0 * W + x0) * rs;
+            orow = (size_t)W * rs;
+            ostride = rs;
+        }
+        for (unsigned i = tid; i < THP * tw * LPS; i += NTHR) {
+            const unsigned c4 = i % LPS, pix = i / LPS, r = pix / tw, c = pix - r * tw;
+            if (y0 + (int)r >= H || x0 + (int)c >= W) continue;
+            const long long *ap = reinterpret_cast<const long long *>(acc + ((r * twm + c) * D + c4));
+            float4 o;
+            o.x = (float)((double)ap[0] * unscale);
+            o.y = (float)((double)ap[LPS] * unscale);
+            o.z = (float)((double)ap[2 * LPS] * unscale);
+            o.w = (float)((double)ap[3 * LPS] * unscale);
+            *reinterpret_cast<float4 *>(obase + r * orow + (size_t)c * ostride + c4 * 4) = o;
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -911,8 +1300,14 @@ inline size_t bin_lds_bytes(const CellGeom &G)
     return (kLevelWords * kMaxLevels + 16 + ((size_t)G.ntmax + 1) / 2 + 2 * (size_t)G.QB * G.LP) * 4;
 }
 
+inline bool use_accum(int B, int M, int D, int Q)
+{
+    return ZIRA_DENSE_ACCUM && D == 32 && (unsigned long long)B * M * Q >= 16 * 4096;
+}
+
 inline bool make_geom(int B, int S, int M, int D, int L, int Q, int P, CellGeom &G)
 {
+    G.D = D;
     const int lpg = lpg_for(D);
     if (!lpg) return false;
     if (L > (int)kMaxLevels || P > (1 << kPBits) || Q >= (1 << kQBits)) return false;
@@ -924,6 +1319,14 @@ inline bool make_geom(int B, int S, int M, int D, int L, int Q, int P, CellGeom 
     G.twl_max = 3;
     G.twl_min = dense ? 2 : 1;
     G.vstar = dense ? ZIRA_WALK_VSTAR_DENSE : ZIRA_WALK_VSTAR_SPARSE;
+    if (use_accum(B, M, D, Q)) {  // one tile shape for all levels; busy levels only get more work items per tile
+#ifdef ZIRA_ACC_NG
+        G.ng = ZIRA_ACC_NG;
+        G.thp = G.ng - 1;
+#endif
+        G.twl_max = G.twl_min = ZIRA_ACC_TWL;
+        G.vstar = ZIRA_ACC_VSTAR;
+    }
     G.split = dense ? 1u : 0u;
     G.QB = 64;
     while ((unsigned long long)G.QB * G.LP * 4 > 4096 && G.QB > 1) G.QB >>= 1;  // (12-bit index inside a run)
@@ -944,6 +1347,7 @@ inline bool make_geom(int B, int S, int M, int D, int L, int Q, int P, CellGeom 
         G.prows_max = (unsigned)(items * G.thp * (1u << G.twl_max) * 2);
     }
     G.cap = (G.vstar * 5 / 2 + 511) & ~511u;  // padded stream: records x (longest list / mean list)
+    if (G.cap > 10240) G.cap = 10240;         // (the walk takes larger shares in several passes)
     G.LPdiv = make_fast_div(G.LP);
     G.Pdiv = make_fast_div(P);
     G.Mdiv = make_fast_div(M);
@@ -956,11 +1360,19 @@ inline bool make_geom(int B, int S, int M, int D, int L, int Q, int P, CellGeom 
 inline size_t desc_bytes(const CellGeom &G) { return align256((size_t)G.heads * G.nblk * G.ntmax * 4) + 512; }  // + 8 ticket lines
 inline size_t region_bytes(const CellGeom &G) { return align256((size_t)G.heads * G.nblk * G.slice * 16); }
 inline size_t partial_bytes(const CellGeom &G, int D) { return align256((size_t)G.heads * G.prows_max * D * 4); }
+inline size_t amax_bytes(const CellGeom &G) { return align256((size_t)G.heads * G.nblk * 8) + 256; }  // + the flag word
+inline size_t accum_lds_bytes(const CellGeom &G, int D)
+{
+    size_t hdr = kLevelWords * kMaxLevels + 16 + 2 * (size_t)G.nblk + 1;
+    hdr = (hdr + 3) & ~(size_t)3;
+    const size_t twm = (size_t)1 << G.twl_max;
+    return (hdr + (G.thp + 2) * (twm + 2) * D) * 4 + (G.thp * twm + 8) * D * 8;   // (+ 8 trash rows)
+}
 
 template <int D, int LPG>
 int launch_walk(const CellGeom &G, const float *grad_out, const float *value, const int64_t *shapes,
                 const int64_t *start, const unsigned *desc, const uint4 *region, float *partial,
-                unsigned *tickets, float *gv, float *gl, float *ga, hipStream_t st)
+                unsigned *tickets, float *gv, float *gl, float *ga, hipStream_t st, const unsigned *only_if = nullptr)
 {
     const unsigned NG = 64 / LPG, TW1 = (1u << G.twl_max) + 1;
     const size_t lds2 = (kLevelWords * kMaxLevels + 16 + 2 * (size_t)G.nblk + 1 + (size_t)NG * TW1 + TW1 + G.cap) * 4;
@@ -968,7 +1380,7 @@ int launch_walk(const CellGeom &G, const float *grad_out, const float *value, co
     // one wave per block; the waves of an XCD stride over the work items of its heads
     const unsigned grid = G.split ? ZIRA_WALK_GRID_DENSE : ZIRA_WALK_GRID_SPARSE;
     hipLaunchKernelGGL((msda_bwd_walk<D, LPG>), dim3(grid), dim3(64), lds2, st, grad_out, value, shapes, start,
-                       G, desc, region, partial, tickets, gv, gl, ga);
+                       G, desc, region, partial, tickets, gv, gl, ga, only_if);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !G.split) return (int)e;
     hipLaunchKernelGGL(msda_bwd_fold<D>, dim3(1024), dim3(256), 0, st, shapes, start, G, partial, gv);
@@ -983,7 +1395,7 @@ size_t cells_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P)
 {
     CellGeom G;
     if (!make_geom(B, S, M, D, L, Q, P, G)) return 0;
-    return desc_bytes(G) + region_bytes(G) + partial_bytes(G, D);
+    return desc_bytes(G) + region_bytes(G) + partial_bytes(G, D) + amax_bytes(G);
 }
 
 int cells_backward_f32(const float *grad_out, const float *value, const int64_t *shapes,
@@ -993,16 +1405,38 @@ int cells_backward_f32(const float *grad_out, const float *value, const int64_t 
 {
     CellGeom G;
     if (!make_geom(B, S, M, D, L, Q, P, G) ||
-        ws_bytes < desc_bytes(G) + region_bytes(G) + partial_bytes(G, D))
+        ws_bytes < desc_bytes(G) + region_bytes(G) + partial_bytes(G, D) + amax_bytes(G))
         return (int)hipErrorInvalidValue;
     unsigned *desc = reinterpret_cast<unsigned *>(ws);
     uint4 *region = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(ws) + desc_bytes(G));
     float *partial = reinterpret_cast<float *>(reinterpret_cast<char *>(region) + region_bytes(G));
     unsigned *tickets = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(ws) + desc_bytes(G) - 512);
+    const bool accum = use_accum(B, M, D, Q);
+    unsigned *amax = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(partial) + partial_bytes(G, D));
+    unsigned *flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(amax) + amax_bytes(G) - 256);
     hipLaunchKernelGGL(msda_bwd_bin, dim3(G.heads * G.nblk), dim3(kBinThreads), bin_lds_bytes(G), st, loc, attn, shapes,
-                       G, gl, ga, desc, region, tickets);
+                       G, gl, ga, desc, region, tickets, grad_out, accum ? amax : (unsigned *)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    if (accum) {
+        const size_t lds = accum_lds_bytes(G, D);
+        if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_accum<32, ZIRA_ACC_THREADS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const unsigned per_cu = (unsigned)((160 * 1024) / lds), by_threads = 2048 / ZIRA_ACC_THREADS;
+        const unsigned bpc = per_cu < by_threads ? per_cu : by_threads;
+        hipLaunchKernelGGL((msda_bwd_accum<32, ZIRA_ACC_THREADS>), dim3(256 * (bpc ? bpc : 1)), dim3(ZIRA_ACC_THREADS), lds, st,
+                           grad_out, value, shapes, start, G, desc, region, partial, tickets, amax, flag, gv, gl, ga);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        // non-finite grad_out / attention weights: the accumulate kernel raised the flag and did nothing
+        return launch_walk<32, ZIRA_WALK_LPG32>(G, grad_out, value, shapes, start, desc, region, partial, tickets, gv, gl, ga, st, flag);
+    }
     if (D == 16) return launch_walk<16, 4>(G, grad_out, value, shapes, start, desc, region, partial, tickets, gv, gl, ga, st);
     if (D == 32) return launch_walk<32, ZIRA_WALK_LPG32>(G, grad_out, value, shapes, start, desc, region, partial, tickets, gv, gl, ga, st);
     return launch_walk<64, 8>(G, grad_out, value, shapes, start, desc, region, partial, tickets, gv, gl, ga, st);
