@@ -65,13 +65,16 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
 
 /* Sorted float32 backward: same results up to summation order, 2-6x faster than the plain entry
  * point (no fp32 atomics on the common path).  Dense calls (B*M*Q >= 65536: encoder self-attention,
- * every pixel a query) take the cell walk -- samples binned by the 2x2 pixel block they touch, tiles
- * walked with the window's accumulators in registers, three kernels, bit-stable from run to run --,
+ * every pixel a query) take the cell kernels -- samples binned by the 2x2 pixel block they touch into
+ * tiles of 15 x 8 pixels; for D = 32 a tile's four corner rows per sample are summed in LDS in 64-bit
+ * fixed point (scale from max|grad_out| * max|attn|: the sums are exact and grad_value is identical
+ * from run to run; non-finite gradients fall back to a float walk of the same tiles), for D = 16 / 64
+ * the tiles are walked with the window's accumulators in registers --,
  * sparse calls (decoder cross-attention) the entry sort -- per-block counting sort of corner
  * contributions, per-tile row sums, and a short launch that adds the slices of overfull tiles with
  * fp32 atomics.
  * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions
- * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 692 MB at Q=S), or 0 when that path does
+ * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 496 MB at Q=S), or 0 when that path does
  * not apply (the plain entry point is then the only one).  The workspace is caller-owned
  * DEVICE memory, 16-byte aligned, needs no initialisation and may be reused by later calls
  * on the same stream; with workspace == NULL or too small the call degrades to

@@ -2060,8 +2060,9 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
     return ZIRA_MSDA_EINVAL;
 }
 
-// Which sorted backward serves a call of the workspace entry point: the cell walk
-// (csrc/msda_cells.hip) for dense calls (encoder self-attention: every pixel is a query), the entry
+// Which sorted backward serves a call of the workspace entry point: the cell kernels
+// (csrc/msda_cells.hip: bin + LDS accumulate for D = 32, bin + walk for D = 16 / 64) for dense calls
+// (encoder self-attention: every pixel is a query), the entry
 // sort below for sparse ones (decoder cross-attention).  Developer switch for A/B runs:
 // ZIRA_MSDA_BWD=cells | tiled forces one of them where it applies.
 static bool use_cells_path(int B, int M, int Q)
@@ -2148,8 +2149,10 @@ const char *zira_msda_variant_f32(int D)
     // D = 16 / 32 / 64 take the lean kernels (and, with a workspace, the tiled backward) whenever
     // the call passes lean_ok(); the other specialised widths use the row-per-group kernels
     if (D == 16 || D == 32 || D == 64)
-        return "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_walk + msda_bwd_fold (dense calls) / "
-               "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic";
+        return D == 32 ? "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_accum + msda_bwd_fold (dense calls) / "
+                         "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic"
+                       : "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_walk + msda_bwd_fold (dense calls) / "
+                         "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic";
     switch (lpr_for(D)) {
         case 1: return "rows<1>";
         case 2: return "rows<2>";

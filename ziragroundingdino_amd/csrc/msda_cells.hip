@@ -93,6 +93,12 @@
 #ifndef ZIRA_ACC_THREADS
 #define ZIRA_ACC_THREADS 512
 #endif
+#ifndef ZIRA_BIN_ABL
+#define ZIRA_BIN_ABL 0   // developer timing builds (wrong results): 1 no record stores, 2 no grad_out maximum
+#endif
+#ifndef ZIRA_ACC_MINW
+#define ZIRA_ACC_MINW 4    // accumulate: waves per SIMD the register allocation must allow
+#endif
 #ifndef ZIRA_ACC_DR
 #define ZIRA_ACC_DR 3      // accumulate: grad_out rows requested this many records ahead (DR + 1 divides 8)
 #endif
@@ -325,14 +331,17 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
     // (accumulate path) largest |grad_out| of the block's rows and largest |attention weight| of its samples, as bit
     // patterns (NaN > inf > finite): they set the fixed-point scale of the accumulators
     unsigned mx_g = 0, mx_a = 0;
-    if (amax_blk) {
-        const unsigned d4 = G.D / 4;
-        for (unsigned i = threadIdx.x; i < G.QB * d4; i += kBinThreads) {
+    constexpr unsigned kGoLoads = 4;   // (rows of the block = QB * D / 4 float4 pieces; 256 threads take up to 4 each up front,
+    uint4 gob[kGoLoads];               //  so that their latency runs behind the sample pass)
+    const unsigned d4 = G.D / 4, ngo = G.QB * d4;
+    if (amax_blk && !(ZIRA_BIN_ABL & 2)) {
+#pragma unroll
+        for (unsigned r = 0; r < kGoLoads; ++r) {
+            const unsigned i = threadIdx.x + r * kBinThreads;
             const unsigned ql = i / d4, c = i - ql * d4, q = blk * G.QB + ql;
-            if (q >= G.Q) continue;
-            const uint4 gb = *reinterpret_cast<const uint4 *>(grad_out + ((size_t)(b * G.Q + q) * G.M + m) * G.D + c * 4);
-            const unsigned m01 = max(gb.x & 0x7fffffffu, gb.y & 0x7fffffffu), m23 = max(gb.z & 0x7fffffffu, gb.w & 0x7fffffffu);
-            mx_g = max(mx_g, max(m01, m23));
+            gob[r] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < ngo && q < G.Q)
+                gob[r] = *reinterpret_cast<const uint4 *>(grad_out + ((size_t)(b * G.Q + q) * G.M + m) * G.D + c * 4);
         }
     }
     const unsigned nsamp = G.QB * G.LP;
@@ -362,6 +371,20 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
         ranks[idx * 2 + 1] = r10 | (r11 << 16);
     }
     if (amax_blk) {
+        if (!(ZIRA_BIN_ABL & 2)) {
+#pragma unroll
+            for (unsigned r = 0; r < kGoLoads; ++r) {
+                const unsigned m01 = max(gob[r].x & 0x7fffffffu, gob[r].y & 0x7fffffffu);
+                const unsigned m23 = max(gob[r].z & 0x7fffffffu, gob[r].w & 0x7fffffffu);
+                mx_g = max(mx_g, max(m01, m23));
+            }
+            for (unsigned i = threadIdx.x + kGoLoads * kBinThreads; i < ngo; i += kBinThreads) {   // (D = 64 with 64 queries)
+                const unsigned ql = i / d4, c = i - ql * d4, q = blk * G.QB + ql;
+                if (q >= G.Q) continue;
+                const uint4 gb = *reinterpret_cast<const uint4 *>(grad_out + ((size_t)(b * G.Q + q) * G.M + m) * G.D + c * 4);
+                mx_g = max(mx_g, max(max(gb.x & 0x7fffffffu, gb.y & 0x7fffffffu), max(gb.z & 0x7fffffffu, gb.w & 0x7fffffffu)));
+            }
+        }
         if (threadIdx.x < 2) misc[12 + threadIdx.x] = 0;
         __syncthreads();
         atomicMax(&misc[12], mx_g);
@@ -415,7 +438,7 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
         const unsigned l = fast_div(s, G.Pdiv);
         const Level L = lv[l];
         const SampleGeo geo = sample_geo(xy.x, xy.y, attn[si], L.H, L.W);
-        if (!geo.valid) continue;
+        if (!geo.valid || (ZIRA_BIN_ABL & 1)) continue;
         const TileSet t = tiles_of_cell(geo.u, geo.v, L.W, L.nty, G.thp, G.thpdiv, L.twl);
         const unsigned r0 = ranks[idx * 2], r1 = ranks[idx * 2 + 1];
         const unsigned t00 = L.tbase + t.ty0 * L.ntx, t10 = L.tbase + t.ty1 * L.ntx;
@@ -957,10 +980,11 @@ __global__ __launch_bounds__(256) void msda_bwd_fold(const int64_t *__restrict__
 // value tile give grad_attn / grad_loc for home records, and the four corner rows are ADDED TO THE LDS
 // ACCUMULATORS -- not as floats: `ds_add_f32` executes at ~3 cycles per LANE on gfx950 (193 cycles per
 // wave instruction measured), `ds_add_u64` at 7 cycles per wave instruction.  Every term w * (a * g)
-// is formed in fp32 exactly as the reference forms it (cuh:117-147), scaled by a power of two chosen
-// from max|grad_out| * max|attn| (found by the bin kernel) so that it lies below 2^38, rounded to an
-// integer and added as a 64-bit integer.  The sum of a pixel is therefore EXACT (no rounding between
-// terms, 2^25 terms of headroom), independent of the order of the records, and rounded to fp32 once
+// (w = the corner's bilinear weight and a * g rounded to fp32 as in the reference, cuh:117-147; their
+// product taken exactly in double) is scaled by a power of two chosen from max|grad_out| * max|attn|
+// (found by the bin kernel) so that it lies below 2^38, rounded to an integer and added as a 64-bit
+// integer.  The sum of a pixel is therefore EXACT (no rounding between
+// terms), independent of the order of the records, and rounded to fp32 once
 // when the tile is flushed: grad_value becomes run-to-run identical and at least as close to the
 // reference as an fp32 accumulation in any order.  Non-finite inputs (the bin kernel's maxima catch
 // them) cannot be represented: the kernel then leaves everything to the walk, which is launched
@@ -969,7 +993,7 @@ constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52: (double)x + kMagi
 constexpr int kAccBits = 38;
 
 template <int D, int NTHR>
-__global__ __launch_bounds__(NTHR) void msda_bwd_accum(
+__global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ start, CellGeom G,
     const unsigned *__restrict__ desc, const uint4 *__restrict__ region, float *__restrict__ partial,
@@ -1018,18 +1042,15 @@ __global__ __launch_bounds__(NTHR) void msda_bwd_accum(
     // |g| < 2^(eg + 1), |a| < 2^(ea + 1): every term w * (a * g) (w <= 1) is below 2^(eg + ea + 2).  The power of two
     // that takes it below 2^kAccBits is applied in two exact steps so that no intermediate leaves the normal range
     // whatever the magnitudes: sA goes into the attention weight (a * g then peaks near 1), sC into the corner weight.
-    float scaleA, scaleC;
-    double unscale;
+    float scaleA;
+    int sA, sBase;   // sBase + bits = the exponent of scaleC for an item whose terms may use `bits` bits
     {
         const int eg = (int)(ug >> 23) - 127, ea = (int)(ua >> 23) - 127;
-        int sA = -(eg + ea + 2);
+        sA = -(eg + ea + 2);
         sA = sA > 120 - ea ? 120 - ea : (sA < -120 - ea ? -120 - ea : sA);
         sA = sA > 126 ? 126 : (sA < -126 ? -126 : sA);
-        int sC = kAccBits - (eg + ea + 2) - sA;
-        sC = sC > 120 ? 120 : (sC < -100 ? -100 : sC);
+        sBase = -(eg + ea + 2) - sA;
         scaleA = __uint_as_float((unsigned)(sA + 127) << 23);
-        scaleC = __uint_as_float((unsigned)(sC + 127) << 23);
-        unscale = __longlong_as_double((long long)(1023 - (sA + sC)) << 52);
     }
 
     const unsigned nvirt = G.heads * NW, per = (nvirt + 7) >> 3;
@@ -1041,7 +1062,7 @@ __global__ __launch_bounds__(NTHR) void msda_bwd_accum(
 
     for (;;) {
         __syncthreads();  // (the previous item's LDS is no longer read)
-        if (tid == 0) misc[10] = atomicAdd(&tickets[xcd * 16], 1u);
+        if (tid == 0) misc[10] = atomicAdd(&tickets[xcd * 16], 1u);   // (taking it an item ahead loses: 435 against 401 us)
         __syncthreads();
         const unsigned tix = misc[10];
         const unsigned vt = xcd * per + tix;
@@ -1118,6 +1139,16 @@ __global__ __launch_bounds__(NTHR) void msda_bwd_accum(
         __syncthreads();
         const unsigned n = misc[11], nruns = misc[12];
         const unsigned e0 = misc[13], e1 = misc[14];
+        // The integer added for a term is the bit pattern of (term + 1.5 * 2^52) as it comes out of the fma: its low
+        // 51 bits are the term in two's complement, the bits above (exponent, the 2^51 of the magic) are the same for
+        // every term and only pile up above bit 50.  The sum is therefore read back from the low 51 bits, and the terms
+        // get as many bits as leave room for this item's (e1 - e0) records below 2^50: kAccBits for up to 4096.
+        int bits = 50 - (32 - (int)__builtin_clz((e1 - e0) | 1u));
+        bits = bits > kAccBits ? kAccBits : bits;
+        int sC = sBase + bits;
+        sC = sC > 120 ? 120 : (sC < -100 ? -100 : sC);
+        const float scaleC = __uint_as_float((unsigned)(sC + 127) << 23);
+        const double unscale = __longlong_as_double((long long)(1023 - (sA + sC)) << 52);
 
         const float *gbase = grad_out + ((size_t)b * G.Q * G.M + m) * D;
         float *ga_h = grad_attn + ((size_t)b * G.Q * G.M + m) * G.LP + (size_t)it.l * G.P;
@@ -1220,8 +1251,10 @@ __global__ __launch_bounds__(NTHR) void msda_bwd_accum(
             }
             // corner rows: term = w * (a * g), as the reference forms it, times 2^(sA + sC) (exact: folded into a and w)
             const float as = __fmul_rn(a, scaleA);
-            const float tt[4] = {__fmul_rn(g4.x, as), __fmul_rn(g4.y, as), __fmul_rn(g4.z, as), __fmul_rn(g4.w, as)};
-            const float wc[4] = {__fmul_rn(w00, scaleC), __fmul_rn(w01, scaleC), __fmul_rn(w10, scaleC), __fmul_rn(w11, scaleC)};
+            const double tt[4] = {(double)__fmul_rn(g4.x, as), (double)__fmul_rn(g4.y, as), (double)__fmul_rn(g4.z, as),
+                                  (double)__fmul_rn(g4.w, as)};
+            const double wc[4] = {(double)__fmul_rn(w00, scaleC), (double)__fmul_rn(w01, scaleC),
+                                  (double)__fmul_rn(w10, scaleC), (double)__fmul_rn(w11, scaleC)};
             const unsigned ad[4] = {a01 & 0xffffu, a01 >> 16, a23 & 0xffffu, a23 >> 16};
 #pragma unroll
             for (unsigned c = 0; c < 4; ++c) {
@@ -1230,9 +1263,8 @@ __global__ __launch_bounds__(NTHR) void msda_bwd_accum(
                 unsigned long long *ap = acc + (ad[c] + j);
 #pragma unroll
                 for (unsigned k = 0; k < 4; ++k) {
-                    const double dd = (double)__fmul_rn(wc[c], tt[k]) + kMagic;
-                    const unsigned long long nn = (unsigned long long)(__double_as_longlong(dd) - __double_as_longlong(kMagic));
-                    atomicAdd(ap + k * LPS, nn);
+                    const double dd = fma(wc[c], tt[k], kMagic);   // (the product of two floats is exact in double)
+                    atomicAdd(ap + k * LPS, (unsigned long long)__double_as_longlong(dd));
                 }
             }
         };
@@ -1274,10 +1306,10 @@ __global__ __launch_bounds__(NTHR) void msda_bwd_accum(
             if (y0 + (int)r >= H || x0 + (int)c >= W) continue;
             const long long *ap = reinterpret_cast<const long long *>(acc + ((r * twm + c) * D + c4));
             float4 o;
-            o.x = (float)((double)ap[0] * unscale);
-            o.y = (float)((double)ap[LPS] * unscale);
-            o.z = (float)((double)ap[2 * LPS] * unscale);
-            o.w = (float)((double)ap[3 * LPS] * unscale);
+            o.x = (float)((double)((ap[0] << 13) >> 13) * unscale);        // (sign extension from bit 50)
+            o.y = (float)((double)((ap[LPS] << 13) >> 13) * unscale);
+            o.z = (float)((double)((ap[2 * LPS] << 13) >> 13) * unscale);
+            o.w = (float)((double)((ap[3 * LPS] << 13) >> 13) * unscale);
             *reinterpret_cast<float4 *>(obase + r * orow + (size_t)c * ostride + c4 * 4) = o;
         }
     }
