@@ -1,11 +1,12 @@
-# usage (GPU box): scripts/kstats_enc.sh [lib ...]  -- rocprofv3 kernel stats of kbench's encoder case per library build
+# usage (GPU box): scripts/kstats_case.sh <kbench case> [lib ...]  -- rocprofv3 kernel stats of one kbench case per library build
 root=${GRAFT_REPO_ROOT:-$(pwd)}
+c=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for lib in "${@:-default}"; do
   if [ "$lib" = default ]; then unset ZIRA_MSDA_LIB; else export ZIRA_MSDA_LIB=$root/build_ab/$lib.so; fi
   rm -rf /tmp/ks
-  CASES=encoder ROUNDS=2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $root/scripts/kbench.py > /dev/null 2>&1
-  echo "== $lib"
+  CASES=$c ROUNDS=2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $root/scripts/kbench.py > /dev/null 2>&1
+  echo "== $c $lib"
   python3 - <<'PY'
 import csv, glob, re
 for f in glob.glob("/tmp/ks/**/*kernel_stats.csv", recursive=True):
