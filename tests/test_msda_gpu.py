@@ -417,3 +417,34 @@ def test_tiled_backward_overwrites_poisoned_grad_value():
     assert torch.isfinite(gv).all() and torch.isfinite(gl).all() and torch.isfinite(ga).all()
     # with Q=50 most value rows receive nothing and must be exactly zero
     assert (gv == 0).float().mean() > 0.5
+
+
+@pytest.mark.parametrize("fill", [0xAB, 0xFF, 0x00])
+def test_dense_backward_with_garbage_workspace(oracle, fill):
+    """The dense path (bin + LDS accumulate + fold) through the C ABI: whatever the workspace and the output buffers
+    hold before the call -- tickets, per-block maxima, the fallback flag, partial rows, trash rows are all (re)written
+    by the call itself -- the result is the oracle's."""
+    from ziragroundingdino_amd import _lib
+
+    lib = _lib.load()
+    value, sh, start, loc, attn, go = _dense_case(9)
+    B, S, M, D = value.shape
+    L, P = loc.shape[3], loc.shape[4]
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    n = lib.zira_msda_bwd_workspace_bytes(B, S, M, D, L, S, P)
+    assert n > 0
+    ws = torch.full((n,), fill, dtype=torch.uint8, device=DEV)
+    gv = torch.full_like(v, float("nan"))
+    gl = torch.full_like(tloc, float("nan"))
+    ga = torch.full_like(tattn, float("nan"))
+    for _ in range(2):   # (the second call finds what the first one left behind)
+        rc = lib.zira_msda_bwd_f32_ws(tgo.data_ptr(), v.data_ptr(), tsh.data_ptr(), tst.data_ptr(),
+                                      tloc.data_ptr(), tattn.data_ptr(), B, S, M, D, L, S, P,
+                                      gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(), n,
+                                      torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for g, w, name in zip((gv, gl, ga), want, ("grad_value", "grad_loc", "grad_attn")):
+            _close(g, w, 5e-5 if name == "grad_value" else 2e-5, name)
