@@ -71,10 +71,15 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
     if key is query:  # one GEMM for the two projections of the same input
         qk = F.linear(query, w[:2 * E], b[:2 * E])
         q, k = qk[..., :E], qk[..., E:]
+        v = F.linear(value, w[2 * E:], b[2 * E:])
+    elif key is value:  # (cross-attention to one memory: decoder -> text)
+        q = F.linear(query, w[:E], b[:E])
+        kv = F.linear(key, w[E:], b[E:])
+        k, v = kv[..., :E], kv[..., E:]
     else:
         q = F.linear(query, w[:E], b[:E])
         k = F.linear(key, w[E:2 * E], b[E:2 * E])
-    v = F.linear(value, w[2 * E:], b[2 * E:])
+        v = F.linear(value, w[2 * E:], b[2 * E:])
     q = q.reshape(L, B * H, hd).transpose(0, 1).view(B, H, L, hd)
     k = k.reshape(S, B * H, hd).transpose(0, 1).view(B, H, S, hd)
     v = v.reshape(S, B * H, hd).transpose(0, 1).view(B, H, S, hd)
@@ -488,14 +493,15 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 tgt_reference_points=None, memory_text=None, text_attention_mask=None, memory=None,
                 memory_key_padding_mask=None, memory_level_start_index=None,
                 memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
-                cross_attn_mask=None):
+                cross_attn_mask=None, memory_text_lb=None):
         assert cross_attn_mask is None
         if self.self_attn is not None:
             q = k = self.with_pos_embed(tgt, tgt_query_pos)
             tgt2 = _mha(self.self_attn, q, k, tgt, attn_mask=self_attn_mask)
             tgt = self.norm2(tgt + self.dropout2(tgt2))
         if self.use_text_cross_attention:
-            text_lb = memory_text.transpose(0, 1)
+            # (the decoder passes the [tokens, batch, C] copy it made once for all its layers)
+            text_lb = memory_text_lb if memory_text_lb is not None else memory_text.transpose(0, 1)
             tgt2 = _mha(self.ca_text, self.with_pos_embed(tgt, tgt_query_pos), text_lb, text_lb,
                         key_padding_mask=text_attention_mask)
             tgt = self.catext_norm(tgt + self.catext_dropout(tgt2))
@@ -659,10 +665,12 @@ class TransformerDecoder(nn.Module):
         reference_points = refpoints_unsigmoid.sigmoid()
         ref_points = [reference_points]
         adapter_loss = tgt.new_zeros(1)
+        # the same for every layer: the ratios of a 4-d reference point and the [tokens, batch, C] text memory
+        ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[None, :] if reference_points.shape[-1] == 4 else None
+        memory_text_lb = memory_text.transpose(0, 1).contiguous() if memory_text is not None else None
         for layer_id, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
-                reference_points_input = (reference_points[:, :, None]
-                                          * torch.cat([valid_ratios, valid_ratios], -1)[None, :])
+                reference_points_input = reference_points[:, :, None] * ratios4
             else:
                 reference_points_input = reference_points[:, :, None] * valid_ratios[None, :]
             query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :])
@@ -677,7 +685,8 @@ class TransformerDecoder(nn.Module):
                 text_attention_mask=text_attention_mask, memory=memory,
                 memory_key_padding_mask=memory_key_padding_mask,
                 memory_level_start_index=level_start_index, memory_spatial_shapes=spatial_shapes,
-                memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask)
+                memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask,
+                memory_text_lb=memory_text_lb)
             adapter_loss = adapter_loss + adapter_loss_
 
             if self.bbox_embed is not None:  # iterative refinement, detached between layers
