@@ -14,6 +14,7 @@ Every multi-scale deformable attention call (6 encoder layers with Q = S, 6 deco
 with Q = 900) runs the gfx950 kernels through ``MultiScaleDeformableAttention``.
 """
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -55,6 +56,22 @@ def _cascade_reduce(x: Tensor, op: str) -> Tensor:
     return v.amax() if op == "max" else v.sum()
 
 
+_ADDITIVE_MASKS = []   # [(weakref to the bool mask, its version, dtype, additive mask)], newest last
+
+
+def _additive_mask(mask: Tensor, dtype) -> Tensor:
+    """0 / -inf float form of a boolean "not allowed" mask.  The six decoder layers (and the text layers of the
+    encoder) pass the SAME mask tensor: it is converted once, keyed on the tensor object (not its address)."""
+    version = mask._version if not mask.is_inference() else 0
+    for ref, ver, dt, out in _ADDITIVE_MASKS:
+        if ref() is mask and ver == version and dt == dtype:
+            return out
+    out = torch.zeros_like(mask, dtype=dtype).masked_fill_(mask, float("-inf"))
+    _ADDITIVE_MASKS.append((weakref.ref(mask), version, dtype, out))
+    del _ADDITIVE_MASKS[:-4]
+    return out
+
+
 def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tensor,
              key_padding_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None) -> Tensor:
     """``mha(query, key, value, key_padding_mask=..., attn_mask=..., need_weights=False)[0]`` for the
@@ -91,7 +108,7 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
     if key_padding_mask is not None:
         kpm = key_padding_mask
         if kpm.dtype == torch.bool:
-            kpm = torch.zeros_like(kpm, dtype=q.dtype).masked_fill_(kpm, float("-inf"))
+            kpm = _additive_mask(kpm, q.dtype)
         kpm = kpm.view(B, 1, 1, S)
         mask = kpm if mask is None else mask + kpm
     dropout_p = mha.dropout if mha.training else 0.0
@@ -118,8 +135,8 @@ def _attention_small(q, k, v, mask, dropout_p=0.0):
     scale = 1.0 / math.sqrt(d)
     if mask is not None:
         scores = torch.baddbmm(mask.expand(B, H, L, S).reshape(B * H, L, S), q3, k3.transpose(1, 2), alpha=scale)
-    else:
-        scores = torch.bmm(q3 * scale, k3.transpose(1, 2))
+    else:   # (beta = 0: the first argument is ignored; saves the q * scale kernel and its backward)
+        scores = torch.baddbmm(q3.new_zeros(1, 1, 1).expand(B * H, L, S), q3, k3.transpose(1, 2), beta=0, alpha=scale)
     p = scores.softmax(-1)
     if dropout_p > 0.0:
         p = F.dropout(p, dropout_p)
@@ -484,9 +501,16 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
+    fuse_bias_relu = True   # bias + ReLU in the GEMM epilogue, as in the encoder layer
+
     def forward_ffn(self, tgt):
         with torch.amp.autocast("cuda", enabled=False):  # reference :1004 keeps the FFN in fp32
-            tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+            if (self.fuse_bias_relu and self.activation is F.relu and tgt.is_cuda and tgt.dtype == torch.float32
+                    and (getattr(self.dropout3, "p", 0.0) == 0.0 or not self.training)):
+                h = _LinearReLU.apply(tgt.reshape(-1, tgt.shape[-1]), self.linear1.weight, self.linear1.bias)
+                tgt2 = self.linear2(h.view(*tgt.shape[:-1], -1))
+            else:
+                tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
         return self.norm3(tgt + self.dropout4(tgt2)), tgt.new_zeros(1)
 
     def forward(self, tgt, tgt_query_pos=None, tgt_query_sine_embed=None, tgt_key_padding_mask=None,
