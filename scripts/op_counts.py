@@ -36,6 +36,6 @@ for (name, shapes, where), (n, t, _) in by.items():
 print("\nby source line (top 60 by launches):")
 for where, (n, t) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:60]:
     print("%6d launches %9.1f us  %s" % (n, t, where))
-print("\nby op / shape / line (top 70 by launches):")
-for (name, shapes, where), (n, t, _) in sorted(by.items(), key=lambda kv: -kv[1][0])[:70]:
+print("\nby op / shape / line (top 170 by launches):")
+for (name, shapes, where), (n, t, _) in sorted(by.items(), key=lambda kv: -kv[1][0])[:170]:
     print("%5d %8.1f us  %-28s %-70s %s" % (n, t, name[:28], shapes, where))
