@@ -234,6 +234,15 @@ int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *b
                          int head_dim, int window, int shift, float scale, float *out, void *stream);
 
 
+/* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
+ * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):
+ *   pos [rows, C] (x, y[, w, h]), C = 2 or 4;  dim_t [T] = temperature^(2 (i // 2) / T);  scale = 2 pi;
+ *   out [rows, C * T], parts ordered (y, x[, w, h]), sin on even / cos on odd channels of pos * scale / dim_t.
+ * Bit-identical to the PyTorch op chain it stands for.  Device pointers. */
+int zira_sine_embed_f32(const float *pos, const float *dim_t, long long rows, int C, int T, float scale, float *out,
+                        void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -37,8 +37,7 @@ def oracle():
 def _quiesce_gpu_between_tests(request):
     """GPU tests build models with hipGraphs, side streams and multi-GB caches.  What a test leaves behind is collected
     and the device drained BEFORE the next test starts, so that graph / stream / event teardown never happens at a random
-    allocation of a later test while that test has work in flight on several streams (seen as rare process aborts in
-    whole-suite runs)."""
+    allocation of a later test while that test has work in flight on several streams."""
     yield
     if request.node.get_closest_marker("gpu") is None:
         return

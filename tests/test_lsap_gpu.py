@@ -69,8 +69,15 @@ def test_no_targets_and_infeasible_flag():
     bad[0, 0, :, 1] = float("inf")                # scipy: "cost matrix is infeasible"
     with pytest.raises(ValueError):
         linear_sum_assignment(bad[0, 0].numpy())
-    linear_sum_assignment_batched(bad.cuda(), [3])
+    q, t = linear_sum_assignment_batched(bad.cuda(), [3])
     assert infeasible(torch.device("cuda", torch.cuda.current_device()), reset=True)
+    # the flagged problem still yields indices a gather can use (they index torch.empty memory otherwise)
+    assert q.tolist() == [[0, 1, 2]] and t.tolist() == [[0, 1, 2]]
+    nan = torch.rand(2, 2, 5, 7)
+    nan[1, 0] = float("nan")
+    q, t = linear_sum_assignment_batched(nan.cuda(), [4, 3], global_targets=True)
+    assert infeasible(torch.device("cuda", torch.cuda.current_device()), reset=True)
+    assert int(q.min()) >= 0 and int(q.max()) < 5 and int(t.min()) >= 0 and int(t.max()) < 7
     assert not infeasible(torch.device("cuda", torch.cuda.current_device()))
 
 

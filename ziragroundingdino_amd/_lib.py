@@ -19,6 +19,7 @@ SYMBOLS = (
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32",
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32",
+    "zira_sine_embed_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -86,6 +87,8 @@ def load():
     lib.zira_cat_logits_bwd_f32.restype = i
     lib.zira_window_attn_f32.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, f32, vp, vp]
     lib.zira_window_attn_f32.restype = i
+    lib.zira_sine_embed_f32.argtypes = [vp, vp, ll, i, i, f32, vp, vp]
+    lib.zira_sine_embed_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p
     lib.zira_msda_variant_f32.argtypes = [i]
     lib.zira_msda_variant_f32.restype = ctypes.c_char_p

@@ -112,8 +112,13 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ cost
             }
             p = wave_merge(p);
             min_val = p.val;
-            if (min_val == INFINITY) {  // infeasible cost matrix (scipy raises)
+            if (min_val == INFINITY) {  // infeasible cost matrix (inf / NaN entries): scipy raises
+                // The flag tells the host (matcher.check()); the pairs still get VALID indices -- target k with
+                // query k -- so that the gathers the criterion issues from them stay inside their tensors (the
+                // outputs are torch.empty memory, and an out-of-range index is a device-side assert, i.e. an abort).
                 if (lane == 0 && status) atomicOr(status, kInfeasible);
+                int64_t *qf = q_out + (size_t)s * Mtot + moff, *tf = t_out + (size_t)s * Mtot + moff;
+                for (int k = lane; k < nr; k += 64) { qf[k] = k; tf[k] = k + (t_global ? toff : 0); }
                 return;
             }
             const int index = p.lastu >= 0 ? p.lastu : p.first;

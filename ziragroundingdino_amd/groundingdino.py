@@ -409,6 +409,10 @@ class GroundingDINO(nn.Module):
             text_dict, cate_to_token_mask_list, loss_linear_adapter = frontend["finish_text"]()
             return self._forward_rest(batched_inputs, images, samples, features, poss, text_dict, cate_to_token_mask_list,
                                       loss_linear_adapter, targets)
+        if self._prefetch_stream is not None:
+            # A prefetch that this call does not consume (a handle for another minibatch) may still be running: it
+            # replays the SAME front-end graphs, whose static input / output buffers this call is about to use.
+            torch.cuda.current_stream(self._prefetch_stream.device).wait_stream(self._prefetch_stream)
         images = self.preprocess_image(batched_inputs)
         samples = nested_tensor_from_tensor_list(images)
         captions, names_list = self._captions(batched_inputs)

@@ -34,6 +34,16 @@ def _get_activation_fn(activation, d_model=256, batch_dim=0):
     raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
 
 
+def _native_elementwise_ok(x: Tensor) -> bool:
+    """fp32 GPU tensors that take no part in autograd: the one-launch HIP form of the sine embedding applies
+    (csrc/refpoints.hip)."""
+    return (x.is_cuda and x.dtype == torch.float32 and not (x.requires_grad and torch.is_grad_enabled())
+            and x.numel() > 0 and NATIVE_REFPOINT_OPS)
+
+
+NATIVE_REFPOINT_OPS = True   # developer switch: False = the PyTorch op chains everywhere
+
+
 def inverse_sigmoid(x, eps=1e-3):
     x = x.clamp(min=0, max=1)
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
@@ -94,6 +104,17 @@ def gen_sineembed_for_position(pos_tensor: Tensor) -> Tensor:
         order = torch.tensor([1, 0, 2, 3][:n], device=pos_tensor.device)
         consts = _SINE_CONSTS[key] = (order, _dim_t(128, 10000, pos_tensor.device))
     order, dim_t = consts
+    if _native_elementwise_ok(pos_tensor):
+        from . import _lib
+
+        pc = pos_tensor.contiguous()
+        out = torch.empty(pc.shape[:-1] + (n * 128,), dtype=torch.float32, device=pc.device)
+        with torch.cuda.device(pc.device):
+            rc = _lib.load().zira_sine_embed_f32(pc.data_ptr(), dim_t.data_ptr(), pc.numel() // n, n, 128, 2 * math.pi,
+                                                 out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_sine_embed_f32 failed: hipError %d" % rc)
+        return out
     arg = pos_tensor.index_select(-1, order)[..., None] * (2 * math.pi) / dim_t      # [nq, bs, n, 128]
     return _interleaved_sincos(arg).flatten(2)
 
