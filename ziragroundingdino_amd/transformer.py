@@ -87,12 +87,12 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
     w, b = mha.in_proj_weight, mha.in_proj_bias
     if key is query:  # one GEMM for the two projections of the same input
         qk = F.linear(query, w[:2 * E], b[:2 * E])
-        q, k = qk[..., :E], qk[..., E:]
+        q, k = qk.split(E, dim=-1)    # (split: its backward is one cat; two slices are two zero-fills, two copies and an add)
         v = F.linear(value, w[2 * E:], b[2 * E:])
     elif key is value:  # (cross-attention to one memory: decoder -> text)
         q = F.linear(query, w[:E], b[:E])
         kv = F.linear(key, w[E:], b[E:])
-        k, v = kv[..., :E], kv[..., E:]
+        k, v = kv.split(E, dim=-1)
     else:
         q = F.linear(query, w[:E], b[:E])
         k = F.linear(key, w[E:2 * E], b[E:2 * E])
