@@ -1,4 +1,5 @@
-// msda_cells.hip -- backward of multi-scale deformable attention for gfx950 (MI355X), "cell walk".
+// msda_cells.hip -- backward of multi-scale deformable attention for gfx950 (MI355X), dense calls:
+// "cell walk" and LDS accumulate.
 //
 // Arithmetic to match: reference csrc/MsDeformAttn/ms_deform_im2col_cuda.cuh:87-159 (bilinear
 // col2im: grad_value += w_corner * attn * grad_out, grad_attn = <grad_out, sample>, grad_loc from
@@ -26,6 +27,11 @@
 //     step, requested one step ahead), so value is read about twice in total instead of four
 //     gathered rows per sample.
 //   * per sample the walk needs its 16-byte record and one grad_out row gather (8 rows in round 1).
+//
+// Since round 2 the walk (K2 below) serves D = 16 / 64; dense D = 32 calls (the model's) sum the tiles in LDS
+// instead -- msda_bwd_accum, further down: the same bin kernel and records, tiles of 15 x 8 pixels, the
+// corner rows added into 64-bit fixed-point accumulators with ds_add_u64 (exact sums, no ordering needed),
+// the walk kept behind it as the float path for non-finite gradients.
 //
 // Kernels (caller-provided workspace):
 //   K1 msda_bwd_bin    one thread per sample: pixel coordinates, bilinear fractions; valid samples
