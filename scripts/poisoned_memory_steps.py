@@ -17,11 +17,21 @@ def poison():
     del bufs
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "prefetch"
-model = small_model().train()
+full = len(sys.argv) > 2 and sys.argv[2] == "full"       # the bench configuration instead of the small test model
+do_poison = not (len(sys.argv) > 3 and sys.argv[3] == "clean")
+if full:
+    from ziragroundingdino_amd.config import zira_swint_config
+    from ziragroundingdino_amd.groundingdino import build_model
+    torch.manual_seed(0)
+    model = build_model(zira_swint_config(device="cuda")).to("cuda").train()
+    batches = [synthetic_batch(2, 800, 1333, seed=s, device="cuda") for s in range(4)]
+else:
+    model = small_model().train()
+    batches = [synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, seed=s, device="cuda") for s in range(4)]
 tr = ZiraTrainer(model)
-batches = [synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, seed=s, device="cuda") for s in range(4)]
-for i in range(12):
-    poison()
+for i in range(6 if full else 12):
+    if do_poison:
+        poison()
     data = batches[i % 4]
     nxt = batches[(i + 1) % 4] if mode == "prefetch" else None
     out = tr.run_step(data, next_data=nxt) if nxt is not None else tr.run_step(data)
