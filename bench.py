@@ -302,11 +302,21 @@ def pmc_traffic():
     if not files:
         return None
     try:
-        dec = json.load(open(files[-1]))["decoder"]
+        summary = json.load(open(files[-1]))
+        dec = summary["decoder"]
         total = sum(k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"] for k in dec.values())
+        groups = {}   # the same per timed group: forward kernel / backward kernels of each shape
+        for shape, tag in (("decoder", "dec"), ("encoder", "enc")):
+            ks = summary.get(shape, {})
+            fwd = [v for k, v in ks.items() if k.startswith("msda_fwd")]
+            bwd = [v for k, v in ks.items() if k.startswith("msda_bwd")]
+            if fwd:
+                groups["fwd_" + tag] = sum(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"] for v in fwd)
+            if bwd:
+                groups["bwd_" + tag] = sum(v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"] for v in bwd)
         return {"traffic": total, "traffic_source": os.path.relpath(files[-1], ROOT) +
                 " (uniform sampling locations at the same shape; sum over " +
-                ", ".join(sorted(k.split("<")[0] for k in dec)) + ")"}
+                ", ".join(sorted(k.split("<")[0] for k in dec)) + ")", "groups": groups}
     except Exception:
         return None
 
@@ -445,6 +455,9 @@ def main():
                     "kernels": kernels, "dominant": dominant, "timing_source": timing_source}
         pmc = pmc_traffic()
         if pmc:
+            for key, nbytes in pmc.pop("groups", {}).items():   # HBM bytes per launch of every group (PMC, uniform / grid inputs)
+                if key in kernels:
+                    kernels[key]["traffic"] = nbytes
             roofline.update(pmc)
         if "fwd_dec" in kernels and "bwd_dec" in kernels:
             f, b = kernels["fwd_dec"], kernels["bwd_dec"]
