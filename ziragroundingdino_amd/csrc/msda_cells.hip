@@ -1416,7 +1416,9 @@ int launch_walk(const CellGeom &G, const float *grad_out, const float *value, co
     const size_t lds2 = (kLevelWords * kMaxLevels + 16 + 2 * (size_t)G.nblk + 1 + (size_t)NG * TW1 + TW1 + G.cap) * 4;
     if (lds2 > 64 * 1024) return (int)hipErrorInvalidValue;
     // one wave per block; the waves of an XCD stride over the work items of its heads
-    const unsigned grid = G.split ? ZIRA_WALK_GRID_DENSE : ZIRA_WALK_GRID_SPARSE;
+    // (behind the accumulate kernel the launch is normally a no-op: a small grid keeps it cheap, the ticket counters
+    // make any grid size correct)
+    const unsigned grid = only_if ? 512u : (G.split ? ZIRA_WALK_GRID_DENSE : ZIRA_WALK_GRID_SPARSE);
     hipLaunchKernelGGL((msda_bwd_walk<D, LPG>), dim3(grid), dim3(64), lds2, st, grad_out, value, shapes, start,
                        G, desc, region, partial, tickets, gv, gl, ga, only_if);
     hipError_t e = hipGetLastError();
