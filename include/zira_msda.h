@@ -176,6 +176,12 @@ int zira_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta
 int zira_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,
                            const float *rstd, int64_t rows, int C, float *dx, void *stream);
 
+/* y = LayerNorm(x + res), the residual connection in front of a post-LN layer in one pass: the sum (same rounding as a
+ * separate add) is also written to sum_out [rows, C], which zira_layernorm_bwd_f32 takes as its x; the gradient it
+ * returns belongs to x and res alike.  Other arguments as zira_layernorm_fwd_f32. */
+int zira_add_layernorm_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, int64_t rows,
+                               int C, float eps, float *sum_out, float *y, float *mean, float *rstd, void *stream);
+
 /* ---- Batched linear sum assignment (Hungarian matching) -------------------------------------
  * Replaces the per-image scipy.optimize.linear_sum_assignment calls of
  * groundingdino/models/GroundingDINO/matcher/matcher.py:105-151 (HungarianMatcher.forward: `C.cpu()`

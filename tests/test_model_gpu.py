@@ -315,3 +315,30 @@ def test_frontend_prefetch_gives_the_same_steps():
     b._prefetched = b_model.prefetch_frontend(batches[0])
     lb = b.run_step(batches[2])
     assert all(torch.isfinite(v) for v in lb.values())
+
+
+def test_add_layer_norm_equals_add_then_norm():
+    """LayerNorm.add_norm(x, r) (one kernel: csrc/layernorm.hip with a residual input) against norm(x + r): the same
+    forward bits, the same gradients for x, r (frozen affine: row kernel backward) and, with a trainable affine, for
+    weight and bias (ATen's backward on the saved sum)."""
+    from ziragroundingdino_amd.dense import LayerNorm
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5000, 256, generator=g).cuda().requires_grad_()
+    r = torch.randn(2, 5000, 256, generator=g).cuda().requires_grad_()
+    gy = torch.randn(2, 5000, 256, generator=g).cuda()
+    for trainable in (False, True):
+        ln = LayerNorm(256).cuda()
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.uniform_(-0.5, 0.5)
+        ln.requires_grad_(trainable)
+        want = ln(x + r)
+        gw = torch.autograd.grad(want, [x, r] + ([ln.weight, ln.bias] if trainable else []), gy)
+        got = ln.add_norm(x, r)
+        gg = torch.autograd.grad(got, [x, r] + ([ln.weight, ln.bias] if trainable else []), gy)
+        assert torch.equal(got, want)
+        for a, b in zip(gg, gw):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    small = torch.randn(4, 7, 256, generator=g).cuda()        # (below the row kernel's size: the plain path)
+    assert torch.equal(LayerNorm(256).cuda().add_norm(small, small), LayerNorm(256).cuda()(small + small))

@@ -16,7 +16,7 @@ SYMBOLS = (
     "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
     "zira_xty_workspace_floats", "zira_xty_f32",
     "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
-    "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32",
+    "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32", "zira_add_layernorm_fwd_f32",
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32",
     "zira_sine_embed_f32",
@@ -73,6 +73,8 @@ def load():
     lib.zira_layernorm_fwd_f32.restype = i
     lib.zira_layernorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, i, vp, vp]
     lib.zira_layernorm_bwd_f32.restype = i
+    lib.zira_add_layernorm_fwd_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, i, ctypes.c_float, vp, vp, vp, vp, vp]
+    lib.zira_add_layernorm_fwd_f32.restype = i
     lib.zira_lsap_workspace_bytes.argtypes = [i, i, i, i]
     lib.zira_lsap_workspace_bytes.restype = sz
     lib.zira_lsap_f32.argtypes = [vp, i, i, i, i, i, vp, vp, vp, i, i, vp, vp, sz, vp]

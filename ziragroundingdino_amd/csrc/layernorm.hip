@@ -53,8 +53,10 @@ template <int G, int NV>
 __global__ __launch_bounds__(kThreads) void ln_fwd_rows(
     const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
     long rows, int C, float eps, float *__restrict__ y, float *__restrict__ mean,
-    float *__restrict__ rstd)
+    float *__restrict__ rstd, const float *__restrict__ res, float *__restrict__ sum_out)
 {
+    // res != nullptr: the row that is normalised is x + res (the residual connection in front of a post-LN);
+    // it is also written to sum_out, which the backward reads in place of x
     const int c4 = C >> 2;
     const int gl = threadIdx.x % G;
     const long groups_per_block = kThreads / G;
@@ -80,6 +82,11 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_rows(
         for (int k = 0; k < NV; ++k) {
             const int i = gl + k * G;
             v[k] = i < c4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res && i < c4) {
+                const float4 rv = reinterpret_cast<const float4 *>(res + r * C)[i];
+                v[k] = make_float4(v[k].x + rv.x, v[k].y + rv.y, v[k].z + rv.z, v[k].w + rv.w);
+                reinterpret_cast<float4 *>(sum_out + r * C)[i] = v[k];
+            }
             s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
         const float mu = group_sum<G>(s) * inv_c;
@@ -190,10 +197,11 @@ int launch_ln_bwd(const float *dy, const float *x, const float *gamma, const flo
 
 template <int G, int NV>
 int launch_ln(const float *x, const float *gamma, const float *beta, long rows, int C, float eps,
-              float *y, float *mean, float *rstd, hipStream_t st)
+              float *y, float *mean, float *rstd, hipStream_t st, const float *res = nullptr,
+              float *sum_out = nullptr)
 {
     hipLaunchKernelGGL((ln_fwd_rows<G, NV>), dim3(ln_blocks(rows, kThreads / G)), dim3(kThreads), 0, st, x,
-                       gamma, beta, rows, C, eps, y, mean, rstd);
+                       gamma, beta, rows, C, eps, y, mean, rstd, res, sum_out);
     return (int)hipGetLastError();
 }
 
@@ -214,6 +222,22 @@ int zira_layernorm_fwd_f32(const float *x, const float *gamma, const float *beta
     if (c4 <= 128) return launch_ln<64, 2>(x, gamma, beta, rows, C, eps, y, mean, rstd, st);
     if (c4 <= 192) return launch_ln<64, 3>(x, gamma, beta, rows, C, eps, y, mean, rstd, st);
     return launch_ln<64, 4>(x, gamma, beta, rows, C, eps, y, mean, rstd, st);
+}
+
+int zira_add_layernorm_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, int64_t rows,
+                               int C, float eps, float *sum_out, float *y, float *mean, float *rstd, void *stream)
+{
+    if (!x || !res || !sum_out || !y || rows < 0 || C <= 0 || (C & 3) || C > 1024) return ZIRA_MSDA_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)res | (uintptr_t)sum_out | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15)
+        return ZIRA_MSDA_EINVAL;
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int c4 = C >> 2;
+    if (c4 <= 32) return launch_ln<32, 1>(x, gamma, beta, rows, C, eps, y, mean, rstd, st, res, sum_out);
+    if (c4 <= 64) return launch_ln<64, 1>(x, gamma, beta, rows, C, eps, y, mean, rstd, st, res, sum_out);
+    if (c4 <= 128) return launch_ln<64, 2>(x, gamma, beta, rows, C, eps, y, mean, rstd, st, res, sum_out);
+    if (c4 <= 192) return launch_ln<64, 3>(x, gamma, beta, rows, C, eps, y, mean, rstd, st, res, sum_out);
+    return launch_ln<64, 4>(x, gamma, beta, rows, C, eps, y, mean, rstd, st, res, sum_out);
 }
 
 int zira_layernorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean,

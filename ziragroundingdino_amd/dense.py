@@ -321,6 +321,65 @@ class _LayerNorm(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    """LayerNorm(x + res) in one pass (zira_add_layernorm_fwd_f32): the residual connection in front of a post-LN.
+    The sum is formed with the rounding of a separate add and saved for the backward, whose input gradient goes to
+    x and res alike."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, res, weight, bias, eps):
+        from . import _lib
+        C = x.shape[-1]
+        xc, rc_ = x.contiguous(), res.contiguous()
+        rows = xc.numel() // C
+        y, s = torch.empty_like(xc), torch.empty_like(xc)
+        stats = torch.empty((2, rows), device=x.device, dtype=torch.float32)
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        rc = _lib.load().zira_add_layernorm_fwd_f32(
+            xc.data_ptr(), rc_.data_ptr(), w.data_ptr() if w is not None else None,
+            b.data_ptr() if b is not None else None, rows, C, float(eps), s.data_ptr(), y.data_ptr(),
+            stats[0].data_ptr(), stats[1].data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_add_layernorm_fwd_f32 failed with code %d" % rc)
+        ctx.save_for_backward(s, w, b, stats)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        s, w, b, stats = ctx.saved_tensors
+        lead = s.shape[:-1] + (1,)
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        mask = [need_in, w is not None and ctx.needs_input_grad[2], b is not None and ctx.needs_input_grad[3]]
+        gy = gy.contiguous()
+        if LayerNorm.fused_backward and mask[0] and not mask[1] and not mask[2] and gy.dtype == torch.float32:
+            from . import _lib
+            gs = torch.empty_like(s)
+            rc = _lib.load().zira_layernorm_bwd_f32(
+                gy.data_ptr(), s.data_ptr(), w.data_ptr() if w is not None else None, stats[0].data_ptr(),
+                stats[1].data_ptr(), s.numel() // ctx.C, ctx.C, gs.data_ptr(),
+                torch.cuda.current_stream(s.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError("zira_layernorm_bwd_f32 failed with code %d" % rc)
+            gw = gb = None
+        else:
+            gs, gw, gb = torch.ops.aten.native_layer_norm_backward(
+                gy, s, [ctx.C], stats[0].view(lead), stats[1].view(lead), w, b, mask)
+        return (gs if ctx.needs_input_grad[0] else None, gs if ctx.needs_input_grad[1] else None, gw, gb, None)
+
+
+def add_layer_norm(x, res, normalized_shape, weight=None, bias=None, eps=1e-5):
+    """F.layer_norm(x + res, ...); one kernel where layer_norm() would use the row kernel."""
+    normalized_shape = tuple(normalized_shape) if not isinstance(normalized_shape, int) else (normalized_shape,)
+    if (LayerNorm.fused_residual and x.shape == res.shape and x.dtype == res.dtype
+            and layer_norm_supported(x, normalized_shape, weight, bias)):
+        return _AddLayerNorm.apply(x, res, weight, bias, eps)
+    return layer_norm(x + res, normalized_shape, weight, bias, eps)
+
+
 def layer_norm(x, normalized_shape, weight=None, bias=None, eps=1e-5):
     """F.layer_norm with the forward of wide fp32 activations on csrc/layernorm.hip."""
     normalized_shape = tuple(normalized_shape) if not isinstance(normalized_shape, int) else (normalized_shape,)
@@ -334,8 +393,15 @@ class LayerNorm(torch.nn.LayerNorm):
 
     fused = True            # class-level switches for A/B runs
     fused_backward = True
+    fused_residual = True
 
     def forward(self, x):
         if self.fused:
             return layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
         return super().forward(x)
+
+    def add_norm(self, x, res):
+        """self(x + res)"""
+        if self.fused:
+            return add_layer_norm(x, res, self.normalized_shape, self.weight, self.bias, self.eps)
+        return super().forward(x + res)

@@ -447,14 +447,14 @@ class DeformableTransformerEncoderLayer(nn.Module):
             src2 = self.linear2(h.view(*src.shape[:-1], -1))
         else:
             src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(src2)), src.new_zeros(1)
+        return self.norm2.add_norm(src, self.dropout3(src2)), src.new_zeros(1)   # (residual add inside the LN kernel)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
                 key_padding_mask=None):
         src2 = self.self_attn(query=self.with_pos_embed(src, pos), reference_points=reference_points,
                               value=src, spatial_shapes=spatial_shapes,
                               level_start_index=level_start_index, key_padding_mask=key_padding_mask)
-        src = self.norm1(src + self.dropout1(src2))
+        src = self.norm1.add_norm(src, self.dropout1(src2))
         return self.forward_ffn(src)
 
 
