@@ -26,6 +26,17 @@ def main():
     centre = torch.rand(B, 900, 1, 1, 1, 2, generator=g) * 0.8 + 0.1
     cl = (centre + 0.05 * torch.randn(B, 900, M, 4, P, 2, generator=g)).to(dev)
     cfgs.append(("decoder_clustered", (v, sh, st, cl, attn, go), 900, 200))
+    # committed capture of a training step's decoder inputs (tests/golden), and the hot / pinpoint patterns of the tests
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "inmodel_decoder_locations.npz")
+    with np.load(gold) as z:
+        il, ia = torch.from_numpy(z["loc"].astype(np.float32)).to(dev), torch.from_numpy(z["attn"].astype(np.float32)).to(dev)
+    cfgs.append(("decoder_inmodel", (v, sh, st, il, ia, go), 900, 200))
+    rng = np.random.default_rng(5)
+    spots = rng.uniform(0.2, 0.8, (3, 2))
+    ctr = spots[rng.integers(0, 3, (B, 900))][:, :, None, None, None, :]
+    for nm, sd in (("decoder_hot", 0.01), ("decoder_pinpoint", 0.0)):
+        hl = torch.from_numpy((ctr + sd * rng.standard_normal((B, 900, M, 4, P, 2))).astype(np.float32)).to(dev)
+        cfgs.append((nm, (v, sh, st, hl, attn, go), 900, 200))
     ve, _, _, _, attne, goe = make_msda_inputs(B, S, M, D, shapes, P, 2, dev)
     cfgs.append(("encoder", (ve, sh, st, encoder_loc(B, M, shapes, P, 3, dev), attne, goe), S, 20))
     if not os.environ.get("CASES"):  # measured streaming ceiling beside the 8 TB/s spec figure

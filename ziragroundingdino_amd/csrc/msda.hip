@@ -2076,12 +2076,19 @@ static bool use_cells_path(int B, int M, int Q)
     return (unsigned long long)B * M * Q >= 16 * 4096;
 }
 
+#ifndef ZIRA_SPARSE_TILES
+#define ZIRA_SPARSE_TILES 1   // sparse calls with D = 32: plan + tile accumulate (csrc/msda_tiles.hip); 0: the round-2 entry sort
+#endif
+
 size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P)
 {
     TilePlan p;
     if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0) return 0;
     if (use_cells_path(B, M, Q)) {
         const size_t n = zira::cells_workspace_bytes(B, S, M, D, L, Q, P);
+        if (n) return n;
+    } else if (ZIRA_SPARSE_TILES) {
+        const size_t n = zira::tiles_workspace_bytes(B, S, M, D, L, Q, P);
         if (n) return n;
     }
     if (!make_tile_plan(B, S, M, D, L, Q, P, p)) return 0;
@@ -2101,6 +2108,14 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
         if (need && workspace_bytes >= need)
             return zira::cells_backward_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
                                             gv, gl, ga, workspace, workspace_bytes, (hipStream_t)stream);
+    }
+    if (ZIRA_SPARSE_TILES && workspace && !use_cells_path(B, M, Q) && !((uintptr_t)workspace & 15)) {
+        const size_t need = zira::tiles_workspace_bytes(B, S, M, D, L, Q, P);
+        if (need && workspace_bytes >= need) {
+            const int rc = zira::tiles_backward_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
+                                                    gv, gl, ga, workspace, workspace_bytes, (hipStream_t)stream);
+            if (rc != -1) return rc;
+        }
     }
     TilePlan p;
     if (!workspace || !make_tile_plan(B, S, M, D, L, Q, P, p) ||

@@ -35,14 +35,22 @@ def match_layout(sizes: Sequence[int], num_queries: int, device) -> Tuple[torch.
     return hit
 
 
+def _dev_key(device) -> str:
+    """State key of a device: always the indexed form ("cuda" -> "cuda:<current device>")."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return str(device)
+
+
 def infeasible(device, reset: bool = False) -> bool:
     """True if any assignment on ``device`` since start-up (or the last ``reset``) met an infeasible
-    (inf / NaN) cost matrix -- scipy raises ValueError there.  Reading the flag synchronises; meant for
-    the end of a task, tests and debugging."""
-    st = _state.get(str(torch.device(device)))
-    hit = bool(st is not None and int(st["status"].item()))
+    (inf / NaN) cost matrix -- scipy raises ValueError there (status bit 0; bit 1 belongs to ``bad_boxes``).
+    Reading the flag synchronises; meant for checkpoints, the end of a task, tests and debugging."""
+    st = _state.get(_dev_key(device))
+    hit = bool(st is not None and int(st["status"].item()) & 1)
     if reset and st is not None:
-        st["status"].zero_()
+        st["status"].bitwise_and_(~1)
     return hit
 
 
@@ -62,10 +70,10 @@ def linear_sum_assignment_batched(cost: torch.Tensor, sizes: Sequence[int], glob
     t_idx = torch.empty((S, Mtot), dtype=torch.int64, device=dev)
     if Mtot == 0:
         return q_idx, t_idx
-    st = _state.get(str(dev))
+    st = _state.get(_dev_key(dev))
     need = int(lib.zira_lsap_workspace_bytes(S, B, Q, Tmax))
     if st is None or st["ws"].numel() < need:
-        st = _state[str(dev)] = {"status": st["status"] if st else torch.zeros(1, dtype=torch.int32, device=dev),
+        st = _state[_dev_key(dev)] = {"status": st["status"] if st else torch.zeros(1, dtype=torch.int32, device=dev),
                                  "ws": torch.empty(max(need, 16), dtype=torch.uint8, device=dev)}
     with torch.cuda.device(dev):
         rc = lib.zira_lsap_f32(cost.data_ptr(), S, B, Q, Ttot, Tmax, meta.data_ptr(), q_idx.data_ptr(),
@@ -77,16 +85,16 @@ def linear_sum_assignment_batched(cost: torch.Tensor, sizes: Sequence[int], glob
 
 
 def _status(dev):
-    st = _state.get(str(dev))
+    st = _state.get(_dev_key(dev))
     if st is None:
-        st = _state[str(dev)] = {"status": torch.zeros(1, dtype=torch.int32, device=dev),
+        st = _state[_dev_key(dev)] = {"status": torch.zeros(1, dtype=torch.int32, device=dev),
                                  "ws": torch.empty(16, dtype=torch.uint8, device=dev)}
     return st["status"]
 
 
 def bad_boxes(device, reset: bool = False) -> bool:
     """True if ``matching_cost`` met a box with x1 < x0 or y1 < y0 (the reference asserts there; synchronises)."""
-    st = _state.get(str(torch.device(device)))
+    st = _state.get(_dev_key(device))
     hit = bool(st is not None and int(st["status"].item()) & 2)
     if reset and st is not None:
         st["status"].bitwise_and_(~2)

@@ -105,6 +105,17 @@ def _resume(spec: TaskSpec, model, trainer: ZiraTrainer) -> int:
     return int(checkpoint["trainer"]["iteration"]) + 1
 
 
+def _check_matching(model):
+    """The device-side matcher records what the reference stops on at once (scipy's ValueError for an
+    infeasible -- inf / NaN -- cost matrix, ``generalized_box_iou``'s xyxy assertion:
+    matcher/matcher.py:147, util/box_ops.py:51-52) as device flags and goes on with dummy assignments.
+    Read them back here so that a diverged run ends before a checkpoint is written or merged."""
+    criterion = getattr(model, "criterion", None)
+    matcher = getattr(criterion, "matcher", None)
+    if matcher is not None and hasattr(matcher, "check"):
+        matcher.check()
+
+
 def run_task(spec: TaskSpec, build_model, init_checkpoint: Optional[str], device="cpu", process_group=None,
              resume=False, on_step=None) -> str:
     """``do_train`` for one task; returns the path of its ``model_final.pth``."""
@@ -126,8 +137,11 @@ def run_task(spec: TaskSpec, build_model, init_checkpoint: Optional[str], device
         loss_dict = trainer.run_step(next(batches))
         if on_step is not None:
             on_step(spec, it, loss_dict)
-        if (it + 1) % period == 0 and _is_main(process_group):
-            save_checkpoint(spec.output_dir, "model_%07d" % it, model, trainer, it)
+        if (it + 1) % period == 0:
+            _check_matching(model)        # before anything is written: one host sync per checkpoint period
+            if _is_main(process_group):
+                save_checkpoint(spec.output_dir, "model_%07d" % it, model, trainer, it)
+    _check_matching(model)                # ... and before the side branches are merged into the weights
     trainer.after_train(list(spec.categories_names))
     if _is_main(process_group):
         save_checkpoint(spec.output_dir, "model_final", model, trainer, spec.max_iter)
