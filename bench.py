@@ -231,13 +231,33 @@ def cpu_baseline_msda(threads):
     return out
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (on ROCm builds without the amdsmi
+    path `torch.cuda.device_count()` falls through to hipGetDeviceCount, which brings the runtime up)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    try:
+        nodes = "/sys/class/kfd/kfd/topology/nodes"
+        for d in os.listdir(nodes):
+            with open(os.path.join(nodes, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0   # (CPU nodes have no SIMDs)
+    except OSError:
+        return None
+    return n
+
+
 def spawn_ranks(n, argv):
-    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as a child job and exit
-    with its code.  Nothing here touches the GPU (device_count() does not initialise it)."""
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as a CHILD job and exit with
+    its code.  The ranks must stay a child process (subprocess), never an exec of this one: on this pool a
+    process that has initialised the GPU must not be replaced.  Nothing here touches the GPU."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
-    if have < n:
+    have = visible_gpus()
+    if have is not None and have < n:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -362,6 +382,12 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: GEMMs under bf16 autocast around the fp32 native ops (configs[3])")
     ap.add_argument("--no-micro", action="store_true", help="skip the section 8(d) kernel micro-benchmark")
+    ap.add_argument("--categories", type=int, default=15,
+                    help="categories in the synthetic caption: 2 + 2 n text tokens (15 -> T = 32, the ODinW-like length of SURVEY.md 8d)")
+    ap.add_argument("--minibatches", type=int, default=4,
+                    help="distinct synthetic minibatches the steps rotate through (graph static buffers and the prefetch path see new data every step)")
+    ap.add_argument("--no-second-mode", action="store_true",
+                    help="skip the second timed region in the other launch mode (eager <-> hipGraph replay)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -386,35 +412,62 @@ def main():
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
     model.use_transformer_graph = args.transformer_graph
     trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
-    data = synthetic_batch(args.batch, args.height, args.width, seed=rank, device=dev)  # own shard
+    # own shard: `--minibatches` distinct minibatches per rank, visited in turn
+    batches = [synthetic_batch(args.batch, args.height, args.width, n_categories=args.categories,
+                               seed=rank * 1009 + i, device=dev) for i in range(max(1, args.minibatches))]
+    data = batches[0]
+    cursor = [0]
+
+    def run_steps(n):
+        for _ in range(n):
+            cur = batches[cursor[0] % len(batches)]
+            nxt = batches[(cursor[0] + 1) % len(batches)]
+            cursor[0] += 1
+            trainer.run_step(cur, next_data=nxt if args.prefetch else None)
+
+    def timed(n):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(n)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
 
     try:
-        for _ in range(args.warmup):
-            trainer.run_step(data, next_data=data if args.prefetch else None)
-    except RuntimeError as e:   # graph capture refused (memory, an op that cannot be captured): the eager launch path
-        if not args.transformer_graph:
+        run_steps(args.warmup)
+    except RuntimeError as e:
+        # Only a refused graph capture is retried eagerly: anything else (out of memory, a launch error, a device
+        # assert) ends the run -- and so does a capture that was left open (the stream would still be capturing).
+        msg = str(e).splitlines()[0] if str(e) else repr(e)
+        capture = any(w in str(e).lower() for w in ("captur", "graph"))
+        if not args.transformer_graph or not capture or torch.cuda.is_current_stream_capturing():
             raise
-        print("[bench] transformer graph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0],
+        print("[bench] transformer graph capture failed (%s); falling back to eager launches" % msg,
               file=sys.stderr, flush=True)
         args.transformer_graph = False
         model.use_transformer_graph = False
         trainer.flat_grad.zero_()
-        for _ in range(args.warmup):
-            trainer.run_step(data, next_data=data if args.prefetch else None)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        run_steps(args.warmup)
     _C.TIMING = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.run_step(data, next_data=data if args.prefetch else None)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps)
     records, _C.TIMING = _C.TIMING, None
+    modes = {"graph" if args.transformer_graph else "eager": elapsed}
+    if not args.no_second_mode and args.dtype == "f32":   # the same steps in the other launch mode (every rank: collectives)
+        other = not args.transformer_graph
+        model.use_transformer_graph = other
+        try:
+            run_steps(max(2, args.warmup))
+            modes["graph" if other else "eager"] = timed(args.steps)
+        except RuntimeError as e:
+            if not other or torch.cuda.is_current_stream_capturing():
+                raise
+            print("[bench] second mode skipped (%s)" % (str(e).splitlines()[0] if str(e) else repr(e)), file=sys.stderr, flush=True)
+        model.use_transformer_graph = args.transformer_graph
     timing_source = "HIP events around every native MSDA call of the timed steps"
     if args.transformer_graph and args.kernel_timing_steps > 0:   # (every rank: the steps hold collectives)
         # graph replays hide the launches from event timing: the same step, launched eagerly, right after
@@ -434,9 +487,11 @@ def main():
     if rank == 0 and not args.no_micro:
         replay = inmodel_replay(trainer, data, dev)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        keys = sorted(modes)
+        t = torch.tensor([elapsed] + [modes[k] for k in keys], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        modes = {k: float(t[1 + i].item()) for i, k in enumerate(keys)}
 
     if rank == 0:
         groups = summarize_timing(records, args.batch)
@@ -471,6 +526,16 @@ def main():
             roofline["micro"] = msda_micro(dev)
         if replay:
             roofline["inmodel_replay"] = replay
+            if "dec" in replay:
+                # The headline figure: the model's own decoder inputs re-issued back to back from a hipGraph -- the
+                # execution mode of the timed region.  The eager event brackets (launch gaps included) stay beside it.
+                r = replay["dec"]
+                fb, bb = msda_algorithmic_bytes(*r["dims_BSMDLQP"])
+                roofline["eager_events"] = {k: roofline.get(k) for k in ("achieved", "frac", "avg_us")}
+                roofline.update({"achieved": (fb + bb) / (r["pair_us"] * 1e-6) / 1e9, "frac": r["pair_frac"],
+                                 "avg_us": r["pair_us"], "algorithmic_bytes": fb + bb,
+                                 "frac_source": "inmodel_replay.dec.pair_us (graph-replayed launches of the decoder "
+                                                "MSDA call captured from a training step); eager_events = " + timing_source})
         images = args.steps * args.batch * world
         flagship = args.backbone == "swin_T_224_1k" and args.dtype == "f32"
         size = "T" if args.backbone.startswith("swin_T") else "B"
@@ -499,6 +564,9 @@ def main():
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world, "transformer_graph": bool(args.transformer_graph),
                 "frontend_prefetch": bool(args.prefetch),
+                "text_tokens": 2 + 2 * args.categories, "distinct_minibatches": len(batches),
+                "launch_modes": {k: {"images_per_s": images / v, "ms_per_step": v / args.steps * 1e3}
+                                 for k, v in sorted(modes.items())},
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "msda_kernel_variant": _lib.variant_f32(32),
             },
@@ -507,7 +575,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and flagship:
             n_img, el, cores, desc = cpu_baseline_step(args.height, args.width, args.cpu_sample_div)
             line["cpu_baseline"] = {"value": n_img / el, "unit": "images/s", "cores": cores,
-                                    "kind": "port", "sample": desc, "msda": cpu_baseline_msda(cores)}
+                                    "cores_on_host": os.cpu_count(), "kind": "port", "sample": desc, "msda": cpu_baseline_msda(cores)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -104,6 +104,20 @@ int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t
                       double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                       void *stream);
 
+/* Host-memory twins (float32; no stream, returns when done): where the reference's CPU entry points raise
+ * "Not implemented on the CPU" (csrc/MsDeformAttn/ms_deform_attn_cpu.cpp:17-41) a binding can offer the op on host
+ * tensors instead.  All pointers are HOST pointers; same layouts and semantics as the device entry points; a few
+ * std::threads over the (batch, head) pairs.  Product code (csrc/msda_cpu.cpp), independent of the test oracle. */
+int zira_msda_fwd_cpu_f32(const float *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const float *sampling_loc,
+                          const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                          float *out);
+
+int zira_msda_bwd_cpu_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                          const int64_t *level_start_index, const float *sampling_loc,
+                          const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                          float *grad_value, float *grad_sampling_loc, float *grad_attn_weight);
+
 /* ---- ZiRa reparameterizable side branch (RSB): fused epilogue ---------------------------
  * Replaces the elementwise / reduction tail of RepZeroConv2d.forward and
  * RepZeroLinear.forward in training mode (reference

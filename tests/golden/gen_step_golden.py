@@ -121,6 +121,18 @@ class Slice:
             m.__rep__()
 
     def forward(self, inp):
+        out, loss_conv, loss_lin = self.outputs(inp)
+        crit = self.crit
+        loss_dict = crit(out, inp["targets"])
+        for k in loss_dict:
+            if k in crit.weight_dict:
+                loss_dict[k] = loss_dict[k] * crit.weight_dict[k]
+        loss_dict["loss_conv_adapter"] = loss_conv * 0.1
+        loss_dict["loss_linear_adapter"] = loss_lin * 0.1
+        return loss_dict
+
+    def outputs(self, inp):
+        """The network part of ``GroundingDINO.forward`` (:459-575): -> (out dict, conv zero loss, linear zero loss)."""
         import groundingdino.util.misc as misc
         U, tr, cls, crit, adapters, input_proj = self.U, self.tr, self.cls, self.crit, self.adapters, self.input_proj
         am, pid, c2t = self.ref["bertwarper"].generate_masks_with_special_tokens_and_transfer_map(
@@ -151,13 +163,7 @@ class Slice:
                "aux_outputs": [{"pred_logits": a_, "pred_boxes": b_} for a_, b_ in zip(classes[:-1], coords[:-1])]}
         interm = U.recover_to_cls_logits(tr.enc_out_class_embed(hs_enc[-1], text_dict), c2t, for_fill=-100.0)
         out["enc_outputs"] = {"pred_logits": interm, "pred_boxes": ref_enc[-1]}
-        loss_dict = crit(out, inp["targets"])
-        for k in loss_dict:
-            if k in crit.weight_dict:
-                loss_dict[k] = loss_dict[k] * crit.weight_dict[k]
-        loss_dict["loss_conv_adapter"] = loss_conv * 0.1
-        loss_dict["loss_linear_adapter"] = loss_lin * 0.1
-        return loss_dict
+        return out, loss_conv, loss_lin
 
 
 def main():

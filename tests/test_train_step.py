@@ -68,6 +68,117 @@ def run_slice_step(model, inp, feats, poss, am, pid, c2t):
     return model.forward_features(feats, poss, inp["img_mask"], text_dict, c2t, loss_lin, inp["targets"])
 
 
+class _SliceWrapper(nn.Module):
+    """trainer.run_step calls model(data): the slice model behind the interface the trainer uses."""
+    training = True
+
+    def __init__(self, model):
+        super().__init__()
+        object.__setattr__(self, "_m", model)
+
+    def __call__(self, data):
+        return run_slice_step(self._m, *data)
+
+    def add_cls_prompt(self, names):
+        self._m.add_cls_prompt(names)
+
+    def after_train(self):
+        self._m.after_train()
+
+    def before_train(self):
+        self._m.before_train()
+
+    def named_parameters(self, *a, **k):
+        return self._m.named_parameters(*a, **k)
+
+
+@pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
+def test_accumulated_steps_match_reference(msda_backend):
+    """batch_size_scale = 2 (reference Trainer.run_step, train_multidatasets.py:192-199): gradients pile up, the
+    clip runs on the pile every iteration, the optimizer steps at iterations 0 and 2
+    (tests/golden/gen_accum_golden.py, the reference's modules)."""
+    dev = msda_backend
+    g = torch.load(os.path.join(GOLDEN, "accum_zira_slice.pt"), weights_only=False)
+    model = build_slice_model(g, dev)
+    trainer = ZiraTrainer(model, batch_size_scale=g["batch_size_scale"])
+    assert sorted(trainer.names) == sorted(g["trainable_names"])
+    trainer.model = _SliceWrapper(model)
+    batches = []
+    for inputs in g["inputs"]:
+        inp, feats, poss, am, pid, c2t = slice_inputs({"inputs": inputs}, model, dev)
+        batches.append((inp, feats, poss, am, pid, c2t))
+    for it in range(3):
+        out = trainer.run_step(batches[it % 2])
+        close(sum(out.values()), g["totals"][it], 1e-4, "total loss of iteration %d" % it)
+        if it == 1:   # no step at iteration 1: the clipped gradients of iteration 1 stay in the bucket
+            assert float(trainer.flat_grad.abs().max()) > 0
+            close(torch.linalg.vector_norm(trainer.flat_grad), torch.tensor(0.1), 1e-3, "clipped pile")
+        else:
+            assert float(trainer.flat_grad.abs().max()) == 0
+    named = dict(model.named_parameters())
+    for n in g["trainable_names"]:
+        close(named[n], g["params_after"][n], 1e-4, "param after 3 iterations " + n)
+
+
+@pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
+def test_eval_branch_matches_reference(msda_backend):
+    """``GroundingDINO.forward`` in eval mode (reference :589-602, ``dt_inference`` :634-675): side branches off,
+    top-k over query x class, boxes rescaled to the requested output size, clipped, empty ones dropped
+    (tests/golden/gen_eval_golden.py: the reference's modules in eval mode + its dt_inference arithmetic)."""
+    dev = msda_backend
+    g = torch.load(os.path.join(GOLDEN, "eval_zira_slice.pt"), weights_only=False)
+    model = build_slice_model(g, dev).eval()
+    model.select_box_nums_for_evaluation = g["topk"]
+    inp, feats, poss, am, pid, c2t = slice_inputs(g, model, dev)
+    with torch.no_grad():
+        text_dict, loss_lin = model.project_text(inp["bert_hidden"], torch.ones_like(inp["input_ids"]).bool(), pid, am)
+        out = model.forward_features(feats, poss, inp["img_mask"], text_dict, c2t, loss_lin, None)
+        close(out["pred_logits"], g["pred_logits"], 1e-4, "pred_logits")
+        close(out["pred_boxes"], g["pred_boxes"], 1e-4, "pred_boxes")
+        batched = [{"height": h, "width": w} for h, w in g["output_sizes"]]
+        res = model.postprocess(out["pred_logits"], out["pred_boxes"], batched, g["image_sizes"])
+    assert len(res) == len(g["results"])
+    for r, want, osize in zip(res, g["results"], g["output_sizes"]):
+        inst = r["instances"]
+        assert tuple(inst.image_size) == tuple(osize)
+        assert len(inst) == len(want["scores"])
+        close(inst.scores, want["scores"], 1e-5, "scores")          # (top-k returns them sorted)
+        # detections as (class, box): the same multiset (near-tied scores may swap places between devices)
+        got = sorted(zip(inst.pred_classes.tolist(), [tuple(round(v, 1) for v in b) for b in inst.pred_boxes.tensor.tolist()]))
+        ref = sorted(zip(want["pred_classes"].tolist(), [tuple(round(v, 1) for v in b) for b in want["pred_boxes"].tolist()]))
+        assert [c for c, _ in got] == [c for c, _ in ref]
+        for (_, a), (_, b) in zip(got, ref):
+            assert max(abs(x - y) for x, y in zip(a, b)) <= 0.2, (a, b)   # pixels of a <= 160-pixel output
+
+
+def test_detector_postprocess_clips_and_drops_empty_boxes():
+    from ziragroundingdino_amd.structures import Boxes, Instances, detector_postprocess
+
+    r = Instances((10, 20), pred_boxes=Boxes(torch.tensor([[-5.0, 2.0, 8.0, 30.0], [25.0, 1.0, 30.0, 4.0], [3.0, 3.0, 3.0, 9.0]])),
+                  scores=torch.tensor([0.9, 0.8, 0.7]), pred_classes=torch.tensor([1, 2, 3]))
+    out = detector_postprocess(r, 20, 40)     # x2 in both directions, clip to 40 x 20
+    assert out.image_size == (20, 40)
+    assert out.pred_boxes.tensor.tolist() == [[0.0, 4.0, 16.0, 20.0]]      # box 1 leaves the image, box 2 has no width
+    assert out.scores.tolist() == pytest.approx([0.9]) and out.pred_classes.tolist() == [1]
+
+
+def test_fp16_takes_the_grad_scaler_branch():
+    """amp_dtype=float16 builds a GradScaler (reference Trainer.__init__ :131-136); bf16 / fp32 do not."""
+    lin = nn.Linear(4, 4)
+
+    class _M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.adapter = lin
+
+        def before_train(self):
+            pass
+
+    assert ZiraTrainer(_M(), amp_dtype=torch.float16, tuned_gemms=False).grad_scaler is not None
+    assert ZiraTrainer(_M(), amp_dtype=torch.bfloat16, tuned_gemms=False).grad_scaler is None
+    assert ZiraTrainer(_M(), tuned_gemms=False).grad_scaler is None
+
+
 @pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
 def test_two_training_steps_match_reference(msda_backend):
     dev = msda_backend

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ZIRA_MSDA_LIB") or os.path.join(_HERE, "libzira_msda.
 SYMBOLS = (
     "zira_msda_fwd_f32", "zira_msda_bwd_f32", "zira_msda_fwd_f64", "zira_msda_bwd_f64",
     "zira_msda_bwd_workspace_bytes", "zira_msda_bwd_f32_ws",
+    "zira_msda_fwd_cpu_f32", "zira_msda_bwd_cpu_f32",
     "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
     "zira_xty_workspace_floats", "zira_xty_f32",
     "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
@@ -48,6 +49,8 @@ def load():
         f.argtypes, f.restype = fwd_args, i
         f = getattr(lib, "zira_msda_bwd_" + suffix)
         f.argtypes, f.restype = bwd_args, i
+    lib.zira_msda_fwd_cpu_f32.argtypes, lib.zira_msda_fwd_cpu_f32.restype = fwd_args[:-1], i   # host pointers, no stream
+    lib.zira_msda_bwd_cpu_f32.argtypes, lib.zira_msda_bwd_cpu_f32.restype = bwd_args[:-1], i
     lib.zira_msda_bwd_workspace_bytes.argtypes = [i] * 7
     lib.zira_msda_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.zira_msda_bwd_f32_ws.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]

@@ -436,13 +436,18 @@ class GroundingDINO(nn.Module):
         if self.training:
             return out_or_loss
         out = out_or_loss
-        results = self.dt_inference(out["pred_logits"], out["pred_boxes"], images.image_sizes)
+        return self.postprocess(out["pred_logits"], out["pred_boxes"], batched_inputs, images.image_sizes)
+
+    def postprocess(self, box_cls, box_pred, batched_inputs, image_sizes):
+        """The evaluation tail of ``forward`` (reference :589-602): top-k detections per image, rescaled to the
+        requested output size, clipped, empty boxes dropped."""
+        from .structures import detector_postprocess
+
+        results = self.dt_inference(box_cls, box_pred, image_sizes)
         processed = []
-        for r, inp, image_size in zip(results, batched_inputs, images.image_sizes):
+        for r, inp, image_size in zip(results, batched_inputs, image_sizes):
             height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
-            r.pred_boxes.scale(width / image_size[1], height / image_size[0])  # detector_postprocess
-            r.image_size = (height, width)
-            processed.append({"instances": r})
+            processed.append({"instances": detector_postprocess(r, height, width)})
         return processed
 
     def forward_features(self, features, poss, samples_mask, text_dict, cate_to_token_mask_list,

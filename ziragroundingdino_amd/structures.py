@@ -18,8 +18,34 @@ class Boxes:
         self.tensor[:, 0::2] *= scale_x
         self.tensor[:, 1::2] *= scale_y
 
+    def clip(self, box_size):
+        """detectron2 ``Boxes.clip``: x into [0, w], y into [0, h], in place."""
+        h, w = box_size
+        self.tensor[:, 0::2] = self.tensor[:, 0::2].clamp(min=0, max=w)
+        self.tensor[:, 1::2] = self.tensor[:, 1::2].clamp(min=0, max=h)
+
+    def nonempty(self, threshold=0.0):
+        """detectron2 ``Boxes.nonempty``: both sides longer than ``threshold``."""
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def __getitem__(self, item):
+        return Boxes(self.tensor[item].view(-1, 4) if isinstance(item, int) else self.tensor[item])
+
     def __len__(self):
         return self.tensor.shape[0]
+
+
+def detector_postprocess(results, output_height, output_width):
+    """What detectron2's ``detector_postprocess`` does to box predictions (the reference calls it on every
+    image, groundingdino_dual_zero_rep_branch.py:599): boxes rescaled from the network's input size to the
+    requested output size, clipped to it, empty boxes dropped (with their scores / classes)."""
+    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **{k: v for k, v in results.__dict__.items() if k != "image_size"})
+    boxes = out.pred_boxes
+    boxes.scale(scale_x, scale_y)
+    boxes.clip(out.image_size)
+    return out[boxes.nonempty()]
 
 
 class Instances:
@@ -34,6 +60,20 @@ class Instances:
             if k != "image_size":
                 setattr(out, k, v.to(device) if hasattr(v, "to") else v)
         return out
+
+    def __getitem__(self, item):
+        """Every field indexed the same way (detectron2 ``Instances.__getitem__``)."""
+        out = Instances(self.image_size)
+        for k, v in self.__dict__.items():
+            if k != "image_size":
+                setattr(out, k, v[item])
+        return out
+
+    def __len__(self):
+        for k, v in self.__dict__.items():
+            if k != "image_size":
+                return len(v)
+        return 0
 
 
 class ImageList:

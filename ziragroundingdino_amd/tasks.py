@@ -53,6 +53,7 @@ class TaskSpec:
     clip_norm_type: float = 2.0
     lr_multiplier: Optional[Callable[[int], float]] = None   # default: x0.1 after 40 % (10 epochs, decay at 4)
     checkpoint_period: Optional[int] = None                  # default: max_iter (the configs' 10 epochs)
+    batch_size_scale: int = 1                                # optimizer step every k iterations (train_multidatasets.py:192-199)
 
     def multiplier(self) -> Callable[[int], float]:
         return self.lr_multiplier or multistep_lr_multiplier((self.max_iter * 4) // 10)
@@ -124,9 +125,11 @@ def run_task(spec: TaskSpec, build_model, init_checkpoint: Optional[str], device
         return final
     model = load_model(build_model, init_checkpoint, device)
     trainer = ZiraTrainer(model, lr=spec.lr, weight_decay=spec.weight_decay, clip_max_norm=spec.clip_max_norm,
-                          clip_norm_type=spec.clip_norm_type, process_group=process_group)
+                          clip_norm_type=spec.clip_norm_type, process_group=process_group,
+                          batch_size_scale=spec.batch_size_scale)
     base_lrs = [g["lr"] for g in trainer.optimizer.param_groups]   # before a resume: a checkpoint stores the
     start_iter = _resume(spec, model, trainer) if resume else 0    # MULTIPLIED rates of the iteration it was taken at
+    trainer.iter = start_iter             # (the reference's step rule, iter % batch_size_scale == 0, counts from here)
     assert len(base_lrs) == len(trainer.optimizer.param_groups)
     multiplier = spec.multiplier()
     period = spec.checkpoint_period or spec.max_iter

@@ -5,6 +5,11 @@ test_odinw13_softfreeze/for_train/test_aquarium.py:13-25).
 
     forward -> sum(loss_dict) -> backward -> [all-reduce] -> clip_grad_norm_(0.1, L2) -> AdamW
 
+``batch_size_scale`` = k (train_multidatasets.py:129-130, :192-199): gradients pile up in ``.grad`` over k
+iterations, the clip runs on the piled-up gradients EVERY iteration, the optimizer steps (and the gradients
+are cleared) only when ``iter % k == 0`` -- iteration 0 included.  fp16 autocast takes the reference's
+GradScaler branch (:185-191).
+
 Data parallelism, MI355X-first: one process per GPU; only the ZiRa side branches ever receive
 gradients (4.6 M values, 18.5 MB fp32), so their ``.grad`` tensors are views of ONE flat buffer
 that is all-reduced over RCCL/xGMI in a single call right after backward (the side branches are
@@ -29,13 +34,20 @@ def lr_factor(name: str) -> float:
 
 class ZiraTrainer:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), clip_max_norm=0.1,
-                 clip_norm_type=2.0, process_group=None, tuned_gemms=True, amp_dtype=None):
+                 clip_norm_type=2.0, process_group=None, tuned_gemms=True, amp_dtype=None, batch_size_scale=1,
+                 grad_scaler=None):
         self.model = model
         # ``train.amp.enabled`` of the reference's configs (Trainer.run_step :170-174 wraps the forward in
-        # autocast); here the dtype is named.  bf16 needs no GradScaler.  The native fp32 ops (MSDA, side
-        # branch epilogue, LayerNorm) keep computing in fp32 inside the autocast region.
-        assert amp_dtype in (None, torch.bfloat16), "fp16 autocast would need a GradScaler; use bf16"
+        # autocast); here the dtype is named.  bf16 needs no GradScaler; fp16 (the reference's autocast default)
+        # gets one, as in Trainer.__init__ :131-136.  The native fp32 ops (MSDA, side branch epilogue,
+        # LayerNorm) keep computing in fp32 inside the autocast region.
+        assert amp_dtype in (None, torch.bfloat16, torch.float16), "amp_dtype: None, torch.bfloat16 or torch.float16"
         self.amp_dtype = amp_dtype
+        self.grad_scaler = grad_scaler
+        if amp_dtype is torch.float16 and grad_scaler is None:
+            self.grad_scaler = torch.amp.GradScaler(next(model.parameters()).device.type)
+        assert int(batch_size_scale) >= 1
+        self.batch_size_scale = int(batch_size_scale)
         if tuned_gemms and next(model.parameters()).is_cuda:
             from . import tuned_gemm
 
@@ -113,16 +125,26 @@ class ZiraTrainer:
         losses = getattr(loss_dict, "total", None)   # the model's own sum of the same terms (criterion.LossDict)
         if losses is None:
             losses = sum(loss_dict.values())
-        losses.backward()
+        scaler = self.grad_scaler if self.amp_dtype is torch.float16 else None
+        (scaler.scale(losses) if scaler is not None else losses).backward()
         if self.world > 1 or self.always_reduce:  # single RCCL all-reduce of the side-branch gradients
+            # (with batch_size_scale > 1 the bucket also holds the earlier iterations' gradients: they are
+            # identical on every rank, so sum / world leaves them as they are -- what DDP's reducer does too)
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)
         if self.clip_max_norm is not None:
-            # clip_grad_norm_ over the side-branch tensors == one norm of the flat bucket
+            if scaler is not None:
+                scaler.unscale_(self.optimizer)   # (:187-189; without a clip, scaler.step() unscales)
+            # clip_grad_norm_ over the side-branch tensors == one norm of the flat bucket; every iteration (:188-189, :194-195)
             total_norm = torch.linalg.vector_norm(self.flat_grad, self.clip_norm_type)
             self.flat_grad.mul_(torch.clamp(self.clip_max_norm / (total_norm + 1e-6), max=1.0))
-        self.optimizer.step()
-        self.flat_grad.zero_()  # keeps the views alive (no set_to_none)
+        if self.iter % self.batch_size_scale == 0:   # (:190, :196)
+            if scaler is not None:
+                scaler.step(self.optimizer)
+                scaler.update()
+            else:
+                self.optimizer.step()
+            self.flat_grad.zero_()  # keeps the views alive (no set_to_none)
         self.iter += 1
         return {k: v.detach() for k, v in loss_dict.items()}
 
