@@ -33,5 +33,5 @@ rows = sorted(prof.key_averages(), key=lambda r: -r.self_device_time_total)
 rows = [r for r in rows if r.self_device_time_total > 0]
 tot = sum(r.self_device_time_total for r in rows)
 print("total device time %.1f us over %d kernels" % (tot, sum(r.count for r in rows)))
-for r in rows[:24]:
+for r in rows[:60]:
     print("  %8.1f us x%-3d %s" % (r.self_device_time_total, r.count, r.key[:120]))

@@ -3,11 +3,11 @@
 Runs the reference's `Transformer` (transformer_for_adapter.py:41-415) with the heads its model file
 attaches (groundingdino_dual_zero_rep_branch.py:321-361) at the real depth and size -- 6 encoder + 6
 decoder layers, d_model 256, FFN 2048, 900 queries, 4 levels of 100x167 / 50x84 / 25x42 / 13x21
-(S = 22223), B = 1, 32 text tokens -- on the CPU of the build container (its pure-PyTorch MSDA path),
+(S = 22223), B = 2 (the benchmarked batch), 32 text tokens -- on the CPU of the build container (its pure-PyTorch MSDA path),
 forward and backward.  Weights are name-seeded (tests/golden/seeded.py) and inputs are regenerated
 from seeds by the test, so the fixture only holds compact outputs: the two-stage top-k indices, the
 last decoder layer's hidden states and boxes, a strided sample of the encoder memory, the scalar
-objective and gradient norms / samples.  ~40 s of CPU time, ~10 GB of memory.
+objective and gradient norms / samples.  ~2 min of CPU time, ~20 GB of memory.
 
     python tests/golden/gen_fullsize_golden.py      (needs /root/reference; never runs on the GPU box)
 """
@@ -41,7 +41,10 @@ def full_args():
                 fusion_droppath=0.1, use_adapter=False)
 
 
-def make_inputs(d=256, bs=1):
+BS = 2   # BASELINE configs[1]: two images per GPU
+
+
+def make_inputs(d=256, bs=BS):
     """Inputs from fixed seeds (the test calls this too: nothing of it is stored)."""
     g = torch.Generator().manual_seed(77)
     srcs = [torch.randn(bs, d, h, w, generator=g) for h, w in SHAPES]

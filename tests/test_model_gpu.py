@@ -293,6 +293,75 @@ def test_one_rank_rccl_step_matches_no_collective():
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_TWO_RANKS_ONE_GPU = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ["ZIRA_ROOT"], "tests")); sys.path.insert(0, os.environ["ZIRA_ROOT"])
+from test_model_gpu import small_model
+from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                      # both ranks share the one GPU of the box
+group = None
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # device tensors staged through the host
+    group = dist.group.WORLD
+model = small_model().train()
+model.use_transformer_graph = True            # hipGraph replay of the transformer, as bench.py runs it
+trainer = ZiraTrainer(model, process_group=group)
+full = [synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, seed=s, device="cuda") for s in range(2)]
+batches = [b[rank:rank + 1] for b in full] if world > 1 else full   # one image per rank / both images
+losses = []
+for it in range(4):                           # rotating minibatches, the next one's frozen front end prefetched
+    out = trainer.run_step(batches[it % 2], next_data=batches[(it + 1) % 2])
+    losses.append(float(sum(out.values())))
+torch.cuda.synchronize()
+assert trainer._prefetched is not None and all(l == l for l in losses)
+if rank == 0:
+    torch.save({"params": {n: p.detach().cpu() for n, p in zip(trainer.names, trainer.params)}, "losses": losses},
+               os.environ["ZIRA_OUT"])
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+print("TWO-RANKS-ONE-GPU-OK rank %d" % rank)
+"""
+
+
+def test_two_ranks_on_one_gpu_match_one_process(tmp_path):
+    """The real N > 1 path on the hardware at hand: two fresh processes share cuda:0 over a gloo group (device
+    tensors), each with the HIP kernels, the transformer replayed from hipGraphs, the front-end prefetch stream and
+    the flat-bucket all-reduce live, one image per rank -- against ONE process stepping on both images (reference:
+    DDP in train_multidatasets.py:406, num_boxes all-reduce in two_stage_criterion.py:59-65).  Four steps over two
+    rotating minibatches."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(29900 + os.getpid() % 90)
+
+    def launch(rank, world, out):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world),
+                   ZIRA_ROOT=root, ZIRA_OUT=str(out), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        return subprocess.Popen([sys.executable, "-c", _TWO_RANKS_ONE_GPU], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+
+    procs = [launch(0, 2, tmp_path / "w2.pt"), launch(1, 2, tmp_path / "w2_r1.pt")]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "TWO-RANKS-ONE-GPU-OK" in so, so[-2000:] + se[-4000:]
+    solo = launch(0, 1, tmp_path / "w1.pt")
+    so, se = solo.communicate(timeout=900)
+    assert solo.returncode == 0 and "TWO-RANKS-ONE-GPU-OK" in so, so[-2000:] + se[-4000:]
+    w2, w1 = torch.load(tmp_path / "w2.pt"), torch.load(tmp_path / "w1.pt")
+    # rank 0 reports the loss terms of ITS image (with the all-reduced normalisers); the weights must agree: sums over
+    # images divided by the mean number of boxes, gradients averaged over the ranks.  (Tolerance as in _RCCL_ONE_RANK.)
+    assert set(w1["params"]) == set(w2["params"])
+    for n, q in w1["params"].items():
+        p = w2["params"][n]
+        assert torch.isfinite(p).all(), n
+        d = (p - q).abs()
+        assert float((d > 1e-5 + 1e-3 * q.abs()).float().mean()) < 0.01, (n, float((d > 1e-5 + 1e-3 * q.abs()).float().mean()))
+        assert float(d.max()) < 0.2 * 4 * 1e-3, (n, float(d.max()))
+
+
 def test_frontend_prefetch_gives_the_same_steps():
     """ZiraTrainer.run_step(data, next_data=...) queues the frozen front end of the next minibatch on a second stream
     and the next step picks it up: same losses and weights as without (no stochastic depth / dropout in this model)."""

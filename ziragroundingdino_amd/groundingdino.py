@@ -200,9 +200,11 @@ class GroundingDINO(nn.Module):
         self.use_frontend_graphs = True
         self._graphed_backbone = GraphedNoGrad(self._backbone_tensors, modules=(self.backbone,))
         self._graphed_bert = GraphedNoGrad(self._bert_hidden, modules=(self.bert,))
-        # hipGraph replay of transformer forward + backward (opt-in: fixed input sizes, frozen
-        # transformer weights, training mode); see graphs.GraphedTransformer
-        self.use_transformer_graph = False
+        # hipGraph replay of transformer forward + backward (training mode on the GPU with the transformer
+        # frozen -- every ZiRa task; up to two input signatures, further ones run eagerly); see
+        # graphs.GraphedTransformer.  On by default since round 3 (2000-step soak over rotating minibatches,
+        # scripts/soak_graph.py; two ranks sharing a GPU, tests/test_model_gpu.py); False launches eagerly.
+        self.use_transformer_graph = True
         self.overlap_text_and_image = True   # frozen BERT replayed on a side stream while the frozen Swin runs
         self._text_stream = None
         self._prefetch_stream = None
