@@ -63,26 +63,27 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
                       float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                       void *stream);
 
-/* Sorted float32 backward: same results up to summation order, 2-6x faster than the plain entry
- * point (no fp32 atomics on the common path).  Dense calls (B*M*Q >= 65536: encoder self-attention,
- * every pixel a query) take the cell kernels -- samples binned by the 2x2 pixel block they touch into
- * tiles of 15 x 8 pixels; for D = 32 a tile's four corner rows per sample are summed in LDS in 64-bit
- * fixed point (scale from max|grad_out| * max|attn|: the sums are exact and grad_value is identical
- * from run to run; non-finite gradients fall back to a float walk of the same tiles), for D = 16 / 64
- * the tiles are walked with the window's accumulators in registers --,
- * sparse calls (decoder cross-attention) the entry sort -- per-block counting sort of corner
- * contributions, per-tile row sums, and a short launch that adds the slices of overfull tiles with
- * fp32 atomics.
- * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions
- * (8.9 MB at B=2,S=22223,M=8,D=32,L=4,Q=900,P=4; 496 MB at Q=S), or 0 when that path does
- * not apply (the plain entry point is then the only one).  The workspace is caller-owned
- * DEVICE memory, 16-byte aligned, needs no initialisation and may be reused by later calls
- * on the same stream; with workspace == NULL or too small the call degrades to
- * zira_msda_bwd_f32.  Every element of grad_value, grad_sampling_loc and grad_attn_weight is
- * written by the call, none needs pre-zeroing.
- * Extra precondition: the levels tile [0, S) exactly (level_start_index[l] + H_l*W_l ==
- * level_start_index[l+1], last one == S), which the reference module asserts
- * (ms_deform_attn.py:284). */
+/* Workspace float32 backward: same results up to summation order, 2-6x faster than the plain entry point (no fp32
+ * atomics on the common path).  Dense calls (B*M*Q >= 65536: encoder self-attention, every pixel a query) take the cell
+ * kernels -- samples binned by the 2x2 pixel block they touch into tiles of 15 x 8 pixels; for D = 32 a tile's four
+ * corner rows per sample are summed in LDS in 64-bit fixed point (scale per (image, head) from max|grad_out| *
+ * max|attn| of that head: the sums are exact and grad_value is identical from run to run; non-finite gradients fall
+ * back to a float walk of the same tiles), for D = 16 / 64 the tiles are walked with the window's accumulators in
+ * registers.  Sparse calls (decoder cross-attention) with D = 32, P <= 4 take "plan + tile accumulate"
+ * (csrc/msda_tiles.hip): a plan kernel bins the samples per 16 x 8-pixel tile into 16-byte records and cuts busy
+ * tiles by record count, a persistent kernel sums each tile in LDS in double (ds_add_f64: no cost for pile-ups on a
+ * few pixels, inf / NaN propagate) and writes it once; shares of cut tiles meet through fp32 atomics.  Other sparse
+ * calls keep the round-2 entry sort (per-block counting sort of corner contributions, per-tile row sums).
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (47 MB at
+ * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, a few MB are touched; 496 MB at Q=S), or 0 when
+ * no workspace path applies (the plain entry point is then the only one).  The workspace is caller-owned DEVICE
+ * memory, 16-byte aligned, needs no initialisation and may be reused by later calls on the same stream; with
+ * workspace == NULL or too small the call degrades to zira_msda_bwd_f32.  Every element of grad_value,
+ * grad_sampling_loc and grad_attn_weight is written by the call, none needs pre-zeroing.
+ * Extra precondition: the levels tile [0, S) exactly (level_start_index[l] + H_l*W_l == level_start_index[l+1], last
+ * one == S), which the reference module asserts (ms_deform_attn.py:284).  The tables live on the device, so the call
+ * cannot check them up front: when the dense kernels find more tiles than S allows they refuse -- and zero-fill all
+ * three gradients instead of leaving them uninitialised. */
 size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, int P);
 
 int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_t *spatial_shapes,

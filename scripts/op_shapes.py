@@ -11,6 +11,7 @@ from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config()).to(dev).train()
+model.use_transformer_graph = False
 model.use_frontend_graphs = bool(int(os.environ.get("FRONT_GRAPH", "0")))
 trainer = ZiraTrainer(model)
 data = synthetic_batch(2, 800, 1333, device=dev)

@@ -259,6 +259,32 @@ def test_dense_backward_fixed_point_scale(oracle, gscale, ascale):
         assert err <= 5e-5, "%s: %.3e of the largest entry" % (name, err)
 
 
+@pytest.mark.parametrize("path", ["dense", "sparse"])
+def test_backward_with_one_outsized_head(oracle, path):
+    """Wide dynamic range across heads: the gradients of ONE (image, head) pair are 1e6 times the others'.  The dense
+    D = 32 backward scales its fixed-point sums per head (a call-wide scale would leave the quiet heads ~2^-18 of the
+    quantum's headroom: 1e-3 relative errors), the sparse one sums in double: every head's grad_value must be right
+    RELATIVE TO ITS OWN magnitude."""
+    if path == "dense":
+        value, sh, start, loc, attn, go = _dense_case(7)
+    else:
+        value, sh, start, loc, attn, go = _random_case(2, 900, 8, 32, NORTH_STAR_SHAPES, 4, seed=7, lo=0.0, hi=1.0)
+    B, S, M, D = value.shape
+    go = go.reshape(B, -1, M, D).copy()
+    go[1, :, 3, :] *= np.float32(1e6)
+    go = go.reshape(B, -1, M * D)
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)[0].astype(np.float64)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = _C.ms_deform_attn_backward(*map(t, (value, sh, start, loc, attn, go)), 64)[0].cpu().numpy().astype(np.float64)
+    for b in range(B):
+        for m in range(M):
+            w, g = want[b, :, m, :], got[b, :, m, :]
+            unit = float(np.abs(w).max())
+            assert unit > 0
+            err = float(np.abs(g - w).max()) / unit
+            assert err <= 5e-5, "head (%d, %d): %.3e of its own largest entry" % (b, m, err)
+
+
 def test_dense_backward_is_run_to_run_identical():
     value, sh, start, loc, attn, go = _dense_case(6)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)

@@ -2001,10 +2001,6 @@ int bwd_generic(const T *grad_out, const T *value, const int64_t *shapes, const 
 
 }  // namespace
 
-#ifndef ZIRA_FWD_BOX
-#define ZIRA_FWD_BOX 1   // dense calls with D = 32: LDS-staged value boxes (csrc/msda_box.hip); 0: msda_fwd_lean for everything
-#endif
-
 extern "C" {
 
 int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *start,
@@ -2014,8 +2010,6 @@ int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *
     if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !out)
         return ZIRA_MSDA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (ZIRA_FWD_BOX && zira::box_forward_applies(B, S, M, D, L, Q, P))
-        return zira::box_forward_f32(value, shapes, start, loc, attn, B, S, M, L, Q, out, st);
     if (lean_ok(B, S, M, D, L, Q, P)) {
         if (D == 16) return launch_fwd_lean<1>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
         if (D == 32) return launch_fwd_lean<2>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);

@@ -316,7 +316,8 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
     const float *__restrict__ loc, const float *__restrict__ attn,
     const int64_t *__restrict__ shapes, CellGeom G, float *__restrict__ grad_loc,
     float *__restrict__ grad_attn, unsigned *__restrict__ desc, uint4 *__restrict__ region,
-    unsigned *__restrict__ tickets, const float *__restrict__ grad_out, unsigned *__restrict__ amax_blk)
+    unsigned *__restrict__ tickets, const float *__restrict__ grad_out, unsigned *__restrict__ amax_blk,
+    float *__restrict__ grad_value)
 {
     extern __shared__ unsigned lds_bin[];
     Level *lv = reinterpret_cast<Level *>(lds_bin);                 // [kMaxLevels]
@@ -329,7 +330,17 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
     if (blockIdx.x == 0 && threadIdx.x < 8) tickets[threadIdx.x * 16] = 0;  // the walk's work counters, one line per XCD
     load_levels(shapes, G, lv, misc);
     const unsigned NT = misc[0];
-    if (NT > G.ntmax) return;  // levels do not tile [0, S): refuse rather than overrun LDS
+    if (NT > G.ntmax) {
+        // The level tables do not tile [0, S) (the caller's precondition, include/zira_msda.h): refuse rather than overrun
+        // LDS -- every kernel of the call returns here -- but leave defined outputs behind: all three gradients zero.
+        const size_t nsamp = (size_t)G.heads / G.M * G.Q * G.M * G.LP, nval = (size_t)G.heads * G.S * G.D;
+        for (size_t i = (size_t)blockIdx.x * kBinThreads + threadIdx.x; i < nval; i += (size_t)gridDim.x * kBinThreads) grad_value[i] = 0.f;
+        for (size_t i = (size_t)blockIdx.x * kBinThreads + threadIdx.x; i < nsamp; i += (size_t)gridDim.x * kBinThreads) {
+            grad_attn[i] = 0.f;
+            grad_loc[2 * i] = grad_loc[2 * i + 1] = 0.f;
+        }
+        return;
+    }
     const unsigned NTW = (NT + 1) / 2;
     for (unsigned i = threadIdx.x; i < NTW; i += kBinThreads) hist[i] = 0;
     __syncthreads();
@@ -1016,7 +1027,8 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
     unsigned *runpre = misc + 16;                              // [nblk + 1]
     unsigned *runoff = runpre + G.nblk + 1;                    // [nblk]
     const unsigned twm = 1u << G.twl_max, VC = twm + 2, VR = G.thp + 2;
-    unsigned hdr = kLevelWords * kMaxLevels + 16 + 2 * G.nblk + 1;
+    unsigned *hmax = runoff + G.nblk;                          // [2 * heads]: max |grad_out|, max |attn| of every head (bit patterns)
+    unsigned hdr = kLevelWords * kMaxLevels + 16 + 2 * G.nblk + 1 + 2 * G.heads;
     hdr = (hdr + 3) & ~3u;
     float *val = reinterpret_cast<float *>(lds_acc + hdr);     // [VR][VC][D]  pixels (ty*thp - 1 + r, x0 - 1 + c)
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(val + VR * VC * D);  // [thp][twm][D]
@@ -1025,39 +1037,45 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
     const unsigned grp = lane / LPS, j = lane % LPS;
     load_levels(shapes, G, lv, misc);
     const unsigned NT = misc[0], NW = misc[1];
-    if (NT > G.ntmax) return;
+    if (NT > G.ntmax) {   // (the bin kernel zero-filled the outputs; the flag the walk launch reads must not be garbage)
+        if (blockIdx.x == 0 && tid == 0) *flag = 0u;
+        return;
+    }
 
-    // fixed-point scale from the bin kernel's maxima
+    // The bin kernel's maxima, PER HEAD: the fixed-point scale of an item follows its own head's largest possible
+    // term, so one head (or image) with outsized gradients does not cost the others their low bits.
     {
-        unsigned ug = 0, ua = 0;
-        for (unsigned i = tid; i < G.heads * G.nblk; i += NTHR) {
-            const uint2 w = reinterpret_cast<const uint2 *>(amax_blk)[i];
-            ug = max(ug, w.x);
-            ua = max(ua, w.y);
-        }
         if (tid < 2) misc[8 + tid] = 0;
         __syncthreads();
-        atomicMax(&misc[8], ug);
-        atomicMax(&misc[9], ua);
+        unsigned ag = 0, aa = 0;
+        for (unsigned hd = wave; hd < G.heads; hd += NWV) {   // a wave per head: lanes stride over the head's bin blocks
+            unsigned ug = 0, ua = 0;
+            for (unsigned i = lane; i < G.nblk; i += 64) {
+                const uint2 w = reinterpret_cast<const uint2 *>(amax_blk)[(size_t)hd * G.nblk + i];
+                ug = max(ug, w.x);
+                ua = max(ua, w.y);
+            }
+#pragma unroll
+            for (unsigned d = 32; d >= 1; d >>= 1) {
+                ug = max(ug, (unsigned)__shfl_xor((int)ug, (int)d));
+                ua = max(ua, (unsigned)__shfl_xor((int)ua, (int)d));
+            }
+            if (lane == 0) {
+                hmax[2 * hd] = ug;
+                hmax[2 * hd + 1] = ua;
+            }
+            ag = max(ag, ug);
+            aa = max(aa, ua);
+        }
+        if (lane == 0) {
+            atomicMax(&misc[8], ag);
+            atomicMax(&misc[9], aa);
+        }
         __syncthreads();
     }
-    const unsigned ug = misc[8], ua = misc[9];
-    const bool bad = ug >= 0x7f800000u || ua >= 0x7f800000u;
+    const bool bad = misc[8] >= 0x7f800000u || misc[9] >= 0x7f800000u;
     if (blockIdx.x == 0 && tid == 0) *flag = bad ? 1u : 0u;
     if (bad) return;
-    // |g| < 2^(eg + 1), |a| < 2^(ea + 1): every term w * (a * g) (w <= 1) is below 2^(eg + ea + 2).  The power of two
-    // that takes it below 2^kAccBits is applied in two exact steps so that no intermediate leaves the normal range
-    // whatever the magnitudes: sA goes into the attention weight (a * g then peaks near 1), sC into the corner weight.
-    float scaleA;
-    int sA, sBase;   // sBase + bits = the exponent of scaleC for an item whose terms may use `bits` bits
-    {
-        const int eg = (int)(ug >> 23) - 127, ea = (int)(ua >> 23) - 127;
-        sA = -(eg + ea + 2);
-        sA = sA > 120 - ea ? 120 - ea : (sA < -120 - ea ? -120 - ea : sA);
-        sA = sA > 126 ? 126 : (sA < -126 ? -126 : sA);
-        sBase = -(eg + ea + 2) - sA;
-        scaleA = __uint_as_float((unsigned)(sA + 127) << 23);
-    }
 
     const unsigned nvirt = G.heads * NW, per = (nvirt + 7) >> 3;
     const unsigned xcd = blockIdx.x & 7;
@@ -1076,6 +1094,21 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
         const unsigned head = vt / NW;
         const Item it = decode_item(lv, G.L, NW - 1 - (vt - head * NW));
         const unsigned b = fast_div(head, G.Mdiv), m = head - b * G.M;
+        // |g| < 2^(eg + 1), |a| < 2^(ea + 1) in this head: every term w * (a * g) (w <= 1) is below 2^(eg + ea + 2).  The
+        // power of two that takes it below 2^kAccBits is applied in two exact steps so that no intermediate leaves the
+        // normal range whatever the magnitudes: sA goes into the attention weight (a * g then peaks near 1), sC into
+        // the corner weight.
+        float scaleA;
+        int sA, sBase;   // sBase + bits = the exponent of scaleC for an item whose terms may use `bits` bits
+        {
+            const unsigned ug = hmax[2 * head], ua = hmax[2 * head + 1];
+            const int eg = (int)(ug >> 23) - 127, ea = (int)(ua >> 23) - 127;
+            sA = -(eg + ea + 2);
+            sA = sA > 120 - ea ? 120 - ea : (sA < -120 - ea ? -120 - ea : sA);
+            sA = sA > 126 ? 126 : (sA < -126 ? -126 : sA);
+            sBase = -(eg + ea + 2) - sA;
+            scaleA = __uint_as_float((unsigned)(sA + 127) << 23);
+        }
         const Level Lv = lv[it.l];
         const unsigned tw = 1u << Lv.twl;
         const int H = Lv.H, W = Lv.W;
@@ -1401,7 +1434,7 @@ inline size_t partial_bytes(const CellGeom &G, int D) { return align256((size_t)
 inline size_t amax_bytes(const CellGeom &G) { return align256((size_t)G.heads * G.nblk * 8) + 256; }  // + the flag word
 inline size_t accum_lds_bytes(const CellGeom &G, int D)
 {
-    size_t hdr = kLevelWords * kMaxLevels + 16 + 2 * (size_t)G.nblk + 1;
+    size_t hdr = kLevelWords * kMaxLevels + 16 + 2 * (size_t)G.nblk + 1 + 2 * (size_t)G.heads;
     hdr = (hdr + 3) & ~(size_t)3;
     const size_t twm = (size_t)1 << G.twl_max;
     return (hdr + (G.thp + 2) * (twm + 2) * D) * 4 + (G.thp * twm + 8) * D * 8;   // (+ 8 trash rows)
@@ -1455,7 +1488,7 @@ int cells_backward_f32(const float *grad_out, const float *value, const int64_t 
     unsigned *amax = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(partial) + partial_bytes(G, D));
     unsigned *flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(amax) + amax_bytes(G) - 256);
     hipLaunchKernelGGL(msda_bwd_bin, dim3(G.heads * G.nblk), dim3(kBinThreads), bin_lds_bytes(G), st, loc, attn, shapes,
-                       G, gl, ga, desc, region, tickets, grad_out, accum ? amax : (unsigned *)nullptr);
+                       G, gl, ga, desc, region, tickets, grad_out, accum ? amax : (unsigned *)nullptr, gv);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (accum) {

@@ -27,11 +27,6 @@ int tiles_backward_f32(const float *grad_out, const float *value, const int64_t 
                        int M, int D, int L, int Q, int P, float *grad_value, float *grad_loc,
                        float *grad_attn, void *workspace, size_t workspace_bytes, hipStream_t st);
 
-// Forward for dense calls (Q == S, D = 32, P = 4): value boxes staged in LDS per query tile (csrc/msda_box.hip).
-bool box_forward_applies(int B, int S, int M, int D, int L, int Q, int P);
-int box_forward_f32(const float *value, const int64_t *shapes, const int64_t *start, const float *loc,
-                    const float *attn, int B, int S, int M, int L, int Q, float *out, hipStream_t st);
-
 }  // namespace zira
 
 #endif

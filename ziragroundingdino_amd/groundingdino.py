@@ -482,7 +482,9 @@ class GroundingDINO(nn.Module):
             srcs.append(src)
             masks.append(mask)
 
-        if (self.use_transformer_graph and self.training and srcs[0].is_cuda
+        # (capture under autocast needs the weight-cast cache off, as ZiraTrainer sets it: with the cache on, eager launches)
+        autocast_cache = torch.is_autocast_enabled("cuda") and torch.is_autocast_cache_enabled()
+        if (self.use_transformer_graph and self.training and srcs[0].is_cuda and not autocast_cache
                 and self._frozen(self.transformer) and torch.is_grad_enabled()):
             hs, reference, hs_enc, ref_enc, init_box_proposal = self._graphed_transformer(
                 srcs, masks, poss, text_dict, no_padding=no_padding)
