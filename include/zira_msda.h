@@ -74,7 +74,7 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
  * tiles by record count, a persistent kernel sums each tile in LDS in double (ds_add_f64: no cost for pile-ups on a
  * few pixels, inf / NaN propagate) and writes it once; shares of cut tiles meet through fp32 atomics.  Other sparse
  * calls keep the round-2 entry sort (per-block counting sort of corner contributions, per-tile row sums).
- * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (47 MB at
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (15.6 MB at
  * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, a few MB are touched; 496 MB at Q=S), or 0 when
  * no workspace path applies (the plain entry point is then the only one).  The workspace is caller-owned DEVICE
  * memory, 16-byte aligned, needs no initialisation and may be reused by later calls on the same stream; with

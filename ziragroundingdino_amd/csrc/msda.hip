@@ -27,17 +27,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <stdlib.h>
-#include <string.h>
 
 #include "msda_internal.h"
 #include "zira_msda.h"
 
 #ifndef ZIRA_K1_GATHERS
 #define ZIRA_K1_GATHERS 8
-#endif
-#ifndef ZIRA_ABLATE
-#define ZIRA_ABLATE 0  // 9 = developer build with per-phase time stamps in K2 (scripts/k2_stamps.py); 0 in shipped builds
 #endif
 
 namespace {
@@ -1096,206 +1091,6 @@ __device__ __forceinline__ void rowsum_fold(const unsigned *part, float *__restr
     if (carry.row != kInvalidRow && slot == 0) flush_row(gv_t + carry.row * row_stride, carry.val, mode);
 }
 
-#if ZIRA_ABLATE == 9  // developer build: per-phase wall-clock stamps of K2 (100 MHz counter)
-__device__ unsigned long long zira_k2_stamps[8 * 8192];
-#define K2_STAMP(i)                                                                         \
-    do {                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) zira_k2_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); \
-    } while (0)
-#define K2W_STAMP(i)                                                                        \
-    do {                                                                                    \
-        if (lane == 0 && stamp_id < 8192) zira_k2_stamps[stamp_id * 8 + (i)] = wall_clock64();        \
-    } while (0)
-#else
-#define K2_STAMP(i)
-#define K2W_STAMP(i)
-#endif
-
-template <int D>
-__global__ __launch_bounds__(kK2Threads, ZIRA_K2_MINWAVES) void msda_bwd_tiles(
-    const float *__restrict__ grad_out, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ start, unsigned S, FastDiv Mdiv, unsigned Q, unsigned nvirt,
-    unsigned per_xcd, FastDiv Tdiv, FastDiv NTdiv, TilePlan plan, unsigned cap,
-    const unsigned *__restrict__ desc, const uint2 *__restrict__ region,
-    float *__restrict__ grad_value)
-{
-    constexpr unsigned NSLOT = 256 / D;  // entries per wave instruction
-    constexpr unsigned U = ZIRA_K2_U;    // grad_out rows in flight per lane
-    constexpr unsigned EPT = ZIRA_K2_EPT;  // entries a thread keeps in registers between passes
-    constexpr unsigned kInvalidRow = 0xFFFFFFFFu;
-    extern __shared__ unsigned lds_k2[];
-    const unsigned R = plan.rows;
-    unsigned *rowcnt = lds_k2;                // [R]      entries per row (this batch)
-    unsigned *rowbase = rowcnt + R;           // [R + 1]  exclusive prefix of rowcnt
-    unsigned *pre = rowbase + R + 1;          // [nblk + 1] exclusive prefix of the run lengths
-    unsigned *runoff = pre + plan.nblk + 1;   // [nblk]   position of the run in the head's region
-    unsigned *runblk = runoff + plan.nblk;    // [nblk]   K1 block of the run
-    unsigned *scratch = runblk + plan.nblk;   // [8]
-    uint2 *sorted = reinterpret_cast<uint2 *>(scratch + 8 + ((2 * R + 1 + 3 * plan.nblk + 1) & 1));
-    // sorted[cap]: (q << 12 | row), weight -- in row order; then kRowsumPartWords per wave
-    unsigned *part = reinterpret_cast<unsigned *>(sorted + cap);
-
-    K2_STAMP(0);
-    unsigned vb2;
-    if (!xcd_chunk_block(nvirt, per_xcd, vb2)) return;
-    const unsigned M = Mdiv.d;
-    const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
-    const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
-    const unsigned b = fast_div(g, Mdiv), m = g - b * M;
-    const unsigned hw = (unsigned)shapes[2 * l] * (unsigned)shapes[2 * l + 1];
-    const unsigned st = (unsigned)start[l];
-    const unsigned span = tile_span(hw, Tdiv);
-    const unsigned p0 = t * span;
-    if (p0 >= hw) return;  // block-uniform: tile past the end of a small level
-    const unsigned rows = (hw - p0 < span) ? hw - p0 : span;
-
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned slot = lane % NSLOT, cq = lane / NSLOT;
-    const float *g_bm = grad_out + ((size_t)b * Q * M + m) * D + cq * 4;
-    float *gv_t = grad_value + (((size_t)b * S + st + p0) * M + m) * D + cq * 4;
-    const size_t row_stride = (size_t)M * D;
-
-    // run-length prefix over the runs of this tile: either one (possibly empty) run per K1 block of
-    // the head (descriptor = offset << 16 | count) or the compact list K1 appended to
-    const uint2 *reg_g = region + (size_t)g * plan.nblk * plan.eblk;
-    const size_t tg = (size_t)g * plan.NT + tile;
-    const unsigned nruns = plan.runlist ? desc[tg] : plan.nblk;
-    const unsigned *dsc = desc + tg * plan.nblk;
-    const uint2 *runs = reinterpret_cast<const uint2 *>(desc + plan.run_base) + tg * plan.nblk;
-    unsigned N = 0;
-    for (unsigned c0 = 0; c0 < nruns; c0 += kK2Threads) {
-        const unsigned i = c0 + threadIdx.x;
-        unsigned n = 0, off = 0, rb = i;
-        if (i < nruns) {
-            if (plan.runlist) {
-                const uint2 rec = runs[i];
-                n = rec.x & 0xffffu; rb = rec.x >> 16; off = rec.y;
-            } else {
-                const unsigned dd = dsc[i];
-                n = dd & 0xffffu; off = dd >> 16;
-            }
-        }
-        unsigned tot;
-        const unsigned ex = block_exclusive_scan(n, scratch, tot);
-        if (i < nruns) { pre[i] = N + ex; runoff[i] = rb * plan.eblk + off; runblk[i] = rb; }
-        N += tot;
-    }
-    if (threadIdx.x == 0) pre[nruns] = N;
-    K2_STAMP(1);
-
-    // rows owned by this wave (same split in every batch)
-    const unsigned r0 = rows * wave / (kK2Threads / 64), r1 = rows * (wave + 1) / (kK2Threads / 64);
-
-    for (unsigned e_lo = 0; e_lo == 0 || e_lo < N; e_lo += cap) {
-        const bool first = e_lo == 0;
-        const unsigned nb = (N - e_lo < cap) ? N - e_lo : cap;
-        const bool in_regs = nb <= EPT * kK2Threads;  // block-uniform
-        for (unsigned i = threadIdx.x; i < rows; i += kK2Threads) rowcnt[i] = 0;
-        __syncthreads();  // also orders pre / runoff before their first use
-
-        // pass 1: count entries per row; small batches keep {entry, rank} in registers
-        unsigned keyr[EPT], wr[EPT], rankr[EPT];
-        if (in_regs) {
-            // groups of kFetchGroup entries: binary searches (LDS), then the entry loads (global)
-            // back to back, then the rank atomics (LDS) -- left alone the compiler waits for
-            // every load before it starts the next search
-            constexpr unsigned kFetchGroup = ZIRA_K2_FETCH_GROUP;
-#pragma unroll
-            for (unsigned u0 = 0; u0 < EPT; u0 += kFetchGroup) {
-                unsigned posr[kFetchGroup];
-                uint2 enr[kFetchGroup];
-#pragma unroll
-                for (unsigned v = 0; v < kFetchGroup; ++v) {
-                    const unsigned u = u0 + v, i = threadIdx.x + u * kK2Threads;
-                    keyr[u] = kInvalidRow;
-                    posr[v] = 0;
-                    if (i < nb) {
-                        const unsigned r = locate_run(pre, nruns, e_lo + i);
-                        posr[v] = runoff[r] + (e_lo + i - pre[r]);
-                        keyr[u] = runblk[r] * plan.ipb;
-                    }
-                }
-#pragma unroll
-                for (unsigned v = 0; v < kFetchGroup; ++v) enr[v] = reg_g[posr[v]];  // slot 0 if unused
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (unsigned v = 0; v < kFetchGroup; ++v) {
-                    const unsigned u = u0 + v;
-                    if (keyr[u] != kInvalidRow) {
-                        const unsigned row = enr[v].x & 0xffffu;
-                        keyr[u] = ((keyr[u] + (enr[v].x >> 16)) << 12) | row;
-                        wr[u] = enr[v].y;
-                        rankr[u] = atomicAdd(&rowcnt[row], 1u);
-                    }
-                }
-            }
-        } else {
-            for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
-                const unsigned r = locate_run(pre, nruns, e_lo + i);
-                const uint2 en = reg_g[runoff[r] + (e_lo + i - pre[r])];
-                atomicAdd(&rowcnt[en.x & 0xffffu], 1u);
-            }
-        }
-        __syncthreads();
-        K2_STAMP(2);
-        {   // exclusive prefix over the rows: each thread owns `rpt` consecutive rows
-            const unsigned rpt = (rows + kK2Threads - 1) / kK2Threads;
-            const unsigned ra = threadIdx.x * rpt;
-            const unsigned rb = (ra + rpt < rows) ? ra + rpt : rows;
-            unsigned c = 0;
-            for (unsigned r = ra; r < rb; ++r) c += rowcnt[r];
-            unsigned tot;
-            unsigned ex = block_exclusive_scan(c, scratch, tot);
-            for (unsigned r = ra; r < rb; ++r) {
-                const unsigned n = rowcnt[r];
-                rowbase[r] = ex;
-                if (!in_regs) rowcnt[r] = ex | (n ? 0x80000000u : 0u);  // cursor + "has entries"
-                ex += n;
-            }
-            if (threadIdx.x == 0) rowbase[rows] = tot;
-        }
-        __syncthreads();
-        K2_STAMP(3);
-        // pass 2: place entries in row order
-        if (in_regs) {
-#pragma unroll
-            for (unsigned u = 0; u < EPT; ++u)
-                if (keyr[u] != kInvalidRow)
-                    sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
-        } else {
-            for (unsigned i = threadIdx.x; i < nb; i += kK2Threads) {
-                const unsigned r = locate_run(pre, nruns, e_lo + i);
-                const uint2 en = reg_g[runoff[r] + (e_lo + i - pre[r])];
-                const unsigned row = en.x & 0xffffu;
-                const unsigned dst = atomicAdd(&rowcnt[row], 1u) & 0x7fffffffu;
-                sorted[dst] = make_uint2(((runblk[r] * plan.ipb + (en.x >> 16)) << 12) | row, en.y);
-            }
-        }
-        __syncthreads();
-        K2_STAMP(4);
-
-        // ---- per-wave row sums -------------------------------------------------------------
-        if (first) {  // rows nobody contributes to (in this batch) start as zeros
-            for (unsigned r = r0 + slot; r < r1; r += NSLOT)
-                if (rowbase[r + 1] == rowbase[r])
-                    *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        K2_STAMP(5);
-        if (nb) {  // block-uniform
-            rowsum_slices<NSLOT, U, kK2Threads / 64, false>(sorted, nb, g_bm, gv_t, row_stride,
-                                                     first ? kRowStore : kRowRmw, wave, slot, cq, part);
-            __syncthreads();
-            K2_STAMP(6);
-            if (wave == 0)
-                rowsum_fold<NSLOT, kK2Threads / 64>(part, gv_t, row_stride, first ? kRowStore : kRowRmw, slot,
-                                                    cq);
-        }
-        __syncthreads();  // LDS is reused by the next batch
-        K2_STAMP(7);
-    }
-}
-
 // K2, wave-per-tile variant for sparse calls (decoder cross-attention: a few hundred queries, a
 // few hundred entries per tile).  Same algorithm as msda_bwd_tiles, but every WAVE owns a tile
 // of <= kWaveTileRows rows and runs it start to finish on its own -- no block barriers, 20
@@ -1328,16 +1123,6 @@ constexpr unsigned kWaveTileRows = 512;   // rows per tile (upper bound)
 #ifndef ZIRA_K2W_MINWAVES
 #define ZIRA_K2W_MINWAVES 5  // waves per SIMD: 20 per CU (<= 96 VGPRs, ~7 KB of LDS per wave)
 #endif
-#ifndef ZIRA_DENSE_WAVE_K2
-#define ZIRA_DENSE_WAVE_K2 0   // 1: dense calls (encoder) on the wave-per-tile K2 as well.  Measured: its owners
-                               // take 292 us against 360 us for the block kernel, but with ~350 entries per tile
-                               // (NT <= 4096) a third of the tiles overflow the 512-entry sort: + 117 us of atomic
-                               // helper slices, or 442 us when the owners walk their slices; K1 + 30 us (4096 bins)
-#endif
-#ifndef ZIRA_DENSE_WAVE_ENTRIES
-#define ZIRA_DENSE_WAVE_ENTRIES 350
-#endif
-constexpr unsigned kDenseWaveEntries = ZIRA_DENSE_WAVE_ENTRIES;
 #ifndef ZIRA_K2W_HEAVY
 #define ZIRA_K2W_HEAVY 512
 #endif
@@ -1417,7 +1202,6 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             vb2 = item >> kQueueSliceBits;
             slice = item & ((1u << kQueueSliceBits) - 1);
         }
-        K2W_STAMP(0);
         bool more = false;  // dense calls: the owner walks the slices of an overfull tile itself
         const unsigned g = fast_div(vb2, NTdiv), tile = vb2 - g * plan.NT;
         const unsigned l = fast_div(tile, Tdiv), t = tile - l * plan.T;
@@ -1460,7 +1244,6 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
                 N += __shfl(incl, 63);
             }
             if (lane == 0) pre[nruns] = N;
-            K2W_STAMP(1);
 
             const bool heavy = N > kHeavyTile;  // wave-uniform
             if (!kHelpers && heavy && !kRunList && lane == 0) {  // publish slices 1 .. extra
@@ -1515,7 +1298,6 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            K2W_STAMP(2);
             unsigned run = 0;
             for (unsigned c0 = 0; c0 < rows; c0 += 64) {  // exclusive prefix over the rows
                 const unsigned r = c0 + lane;
@@ -1526,20 +1308,17 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             }
             if (lane == 0) rowbase[rows] = run;
             __builtin_amdgcn_wave_barrier();
-            K2W_STAMP(3);
 #pragma unroll
             for (unsigned u = 0; u < EPL; ++u)
                 if (keyr[u] != kInvalidRow)
                     sorted[rowbase[keyr[u] & 0xfffu] + rankr[u]] = make_uint2(keyr[u], wr[u]);
             __builtin_amdgcn_wave_barrier();
-            K2W_STAMP(4);
 
             if (!kHelpers && slice == 0) {  // rows nobody contributes to (in slice 0) are stored as zeros
                 for (unsigned r = slot; r < rows; r += NSLOT)
                     if (rowbase[r + 1] == rowbase[r])
                         *reinterpret_cast<float4 *>(gv_t + r * row_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            K2W_STAMP(5);
             if (nb) {
                 unsigned *part = reinterpret_cast<unsigned *>(sorted);
                 rowsum_slices<NSLOT, U, 1, true>(sorted, nb, g_bm, gv_t, row_stride, mode, 0, slot, cq, part);
@@ -1547,7 +1326,6 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
                 __builtin_amdgcn_wave_barrier();
                 rowsum_fold<NSLOT, 1>(part, gv_t, row_stride, mode, slot, cq);
             }
-            K2W_STAMP(6);
             __builtin_amdgcn_wave_barrier();
         }
         if (!kHelpers) {
@@ -1556,7 +1334,6 @@ __global__ __launch_bounds__(kWaveK2Waves * 64, kHelpers ? 4 : ZIRA_K2W_MINWAVES
             qi -= gridDim.x * kWaveK2Waves;  // (undo the loop increment: same wave, same tile)
         }
     }
-    K2W_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1804,72 +1581,31 @@ inline bool make_tile_plan(int B, int S, int M, int D, int L, int Q, int P, Tile
     if (!(D == 16 || D == 32 || D == 64) || !lean_ok(B, S, M, D, L, Q, P)) return false;
     const unsigned LP = (unsigned)L * P;
     p.chunks = (LP + 15) / 16;
-    // sparse calls (decoder: a few hundred queries) use small K1 blocks for balance across the
-    // chip; dense calls use 16-wave blocks so that the (tile x block) run table stays small
     const unsigned heads = (unsigned)B * M;
-    const bool dense = (unsigned long long)heads * Q >= 16 * 4096;
-    p.ipb = (dense ? kK1DenseWaves : 4u) * kItemsPerWave;
+    if ((unsigned long long)heads * Q >= 16 * 4096) return false;   // dense calls: csrc/msda_cells.hip (or the atomic kernels)
+    p.ipb = 4u * kItemsPerWave;    // small K1 blocks: balance across the chip for a few hundred queries
     p.eblk = p.ipb * p.chunks * 64;
     if (p.eblk >= 65536) return false;
-    // K2 runs one block per tile, 4 blocks per CU: aim for one full round of the chip (the
-    // per-tile critical path is a chain of dependent memory round trips, so rounds cost), with
-    // at most kMaxTileRows rows per tile (12-bit row field of the sorted entries)
-    p.wave_k2 = ZIRA_DENSE_WAVE_K2 || !dense;
-    p.qwords = 0;
+    // K2: a wave per tile of <= kWaveTileRows rows, as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD) so that the
+    // grid is one round (the per-tile critical path is a chain of dependent memory round trips: rounds cost)
+    p.wave_k2 = 1;
     p.runlist = 0;
     p.run_base = 0;
-    if (p.wave_k2) {  // a wave per tile: <= kWaveTileRows rows each
-        const unsigned t_min = ((unsigned)S + kWaveTileRows - 1) / kWaveTileRows;
-        unsigned t_want;
-        if (dense) {  // many rounds anyway: tiles of ~kDenseWaveEntries entries (runs come as lists)
-            const unsigned long long per_level = (unsigned long long)Q * P * 4;
-            t_want = (unsigned)((per_level + kDenseWaveEntries - 1) / kDenseWaveEntries);
-            if (t_want > 4096u / (unsigned)L) t_want = 4096u / (unsigned)L;
-        } else {      // as many tiles as wave slots (ZIRA_K2W_MINWAVES per SIMD): the grid is one round
-            t_want = (device_cu_count() * 4 * ZIRA_K2W_MINWAVES) / (heads * (unsigned)L);
-        }
-        p.T = t_want > t_min ? t_want : t_min;
-        if (p.T > (unsigned)S) p.T = (unsigned)S;
-        p.NT = (unsigned)L * p.T;
-        p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
-        p.rows = ((unsigned)S + p.T - 1) / p.T;
-        p.runlist = dense && p.nblk < (1u << 16) ? 1u : 0u;
-        p.run_base = (unsigned)((((size_t)heads * p.NT * sizeof(unsigned) + 255) & ~(size_t)255) / sizeof(unsigned));
-        const size_t per_wave = (size_t)wave_meta_words(p.rows, p.nblk) + kWaveSortWords;
-        // a heavy tile publishes ceil(N / kSliceEntries) - 1 slices: at most (all entries) / kSliceEntries in total
-        const unsigned long long all_entries = (unsigned long long)heads * Q * L * P * 4;
-        p.qwords = dense ? 0u : kQueueHeader + (unsigned)(all_entries / kSliceEntries) + 1;
-        if (p.NT <= 4096 && per_wave * 4 * kWaveK2Waves <= 64 * 1024 && Q < (1 << 20) &&
-            (!dense || p.runlist) && (unsigned long long)heads * p.nblk * p.eblk < (1ull << 32) &&
-            (unsigned long long)heads * p.NT < (1ull << (32 - kQueueSliceBits)) &&
-            ((size_t)p.NT + (size_t)p.eblk * 5) * 4 <= 150 * 1024)
-            return true;
-        p.qwords = 0;
-        p.runlist = 0;
-        p.wave_k2 = 0;  // does not fit: block-per-tile variant below
-    }
-    unsigned T = ((unsigned)S + kMaxTileRows - 1) / kMaxTileRows;
-    const unsigned want = (1024 + heads * L - 1) / (heads * L);
-    if (T < want) T = want;
-    // dense calls (encoder: every pixel is a query): keep ~kTargetTileEntries entries per tile so
-    // that one LDS batch holds a tile and the per-tile sort stays cheap
-    const unsigned long long per_level = (unsigned long long)Q * P * 4;
-    const unsigned t_dense = (unsigned)((per_level + kTargetTileEntries - 1) / kTargetTileEntries);
-    if (T < t_dense) T = t_dense;
-    if (T > (unsigned)S) T = (unsigned)S;
-    if (T < 1) T = 1;
-    p.T = T;
-    p.NT = (unsigned)L * T;
-    if (p.NT > 4096) return false;
+    const unsigned t_min = ((unsigned)S + kWaveTileRows - 1) / kWaveTileRows;
+    const unsigned t_want = (device_cu_count() * 4 * ZIRA_K2W_MINWAVES) / (heads * (unsigned)L);
+    p.T = t_want > t_min ? t_want : t_min;
+    if (p.T > (unsigned)S) p.T = (unsigned)S;
+    p.NT = (unsigned)L * p.T;
     p.nblk = ((unsigned)Q + p.ipb - 1) / p.ipb;
-    p.rows = ((unsigned)S + T - 1) / T;
-    if (p.rows > kMaxTileRows || Q >= (1 << 20)) return false;  // sorted entry = q:20 | row:12
-    if (((size_t)p.NT + (size_t)p.eblk * 5) * 4 > 150 * 1024) return false;  // K1 LDS
-    if ((unsigned long long)heads * p.nblk * p.eblk >= (1ull << 32)) return false;
-    // dense calls publish compact run lists (blk:16 | count:16, offset); counters first, 256-B aligned
-    p.runlist = dense && p.nblk < (1u << 16) ? 1u : 0u;
-    p.run_base = (unsigned)((((size_t)heads * p.NT * sizeof(unsigned) + 255) & ~(size_t)255) / sizeof(unsigned));
-    return true;
+    p.rows = ((unsigned)S + p.T - 1) / p.T;
+    const size_t per_wave = (size_t)wave_meta_words(p.rows, p.nblk) + kWaveSortWords;
+    // a heavy tile publishes ceil(N / kSliceEntries) - 1 slices: at most (all entries) / kSliceEntries in total
+    const unsigned long long all_entries = (unsigned long long)heads * Q * L * P * 4;
+    p.qwords = kQueueHeader + (unsigned)(all_entries / kSliceEntries) + 1;
+    return p.NT <= 4096 && per_wave * 4 * kWaveK2Waves <= 64 * 1024 && Q < (1 << 20) &&
+           (unsigned long long)heads * p.nblk * p.eblk < (1ull << 32) &&
+           (unsigned long long)heads * p.NT < (1ull << (32 - kQueueSliceBits)) &&
+           ((size_t)p.NT + (size_t)p.eblk * 5) * 4 <= 150 * 1024;
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1904,69 +1640,32 @@ int launch_bwd_tiled(const TilePlan &p, const float *grad_out, const float *valu
     const unsigned heads = (unsigned)B * M;
     const FastDiv Mdiv = make_fast_div((unsigned)M), Tdiv = make_fast_div(p.T);
 
-    if (p.runlist) {  // the per-tile run counters start at zero
-        hipError_t em = hipMemsetAsync(desc, 0, (size_t)heads * p.NT * sizeof(unsigned), st);
-        if (em != hipSuccess) return (int)em;
-    }
     const unsigned nv1 = heads * p.nblk, per1 = (nv1 + 7) >> 3;
     const size_t lds1 = ((size_t)p.NT + (size_t)p.eblk * 5) * 4;
-    const void *k1 = p.ipb == kK1DenseWaves * kItemsPerWave
-                         ? reinterpret_cast<const void *>(&msda_bwd_items<CQR, kK1DenseWaves>)
-                         : reinterpret_cast<const void *>(&msda_bwd_items<CQR, 4>);
     if (lds1 > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS (LP > 16 only)
-        hipError_t ea = hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_items<CQR, 4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (ea != hipSuccess) return (int)ea;
     }
-    if (p.ipb == kK1DenseWaves * kItemsPerWave)
-        hipLaunchKernelGGL((msda_bwd_items<CQR, kK1DenseWaves>), dim3(per1 * 8), dim3(kK1DenseWaves * 64), lds1, st,
-                           grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
-                           (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
-                           nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
-    else
-        hipLaunchKernelGGL((msda_bwd_items<CQR, 4>), dim3(per1 * 8), dim3(4 * 64), lds1, st,
-                           grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
-                           (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
-                           nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
+    hipLaunchKernelGGL((msda_bwd_items<CQR, 4>), dim3(per1 * 8), dim3(4 * 64), lds1, st,
+                       grad_out, value, shapes, start, loc, attn, (unsigned)S, Mdiv,
+                       (unsigned)(L * P), 1.0f / (float)P, (unsigned)Q, make_fast_div(p.nblk),
+                       nv1, per1, Tdiv, p, gl, ga, desc, region, queue);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
 
-    if (p.wave_k2) {
-        const unsigned nvw = heads * p.NT, perw = (nvw + 7) >> 3;
-        const unsigned blocks_per_xcd = (perw + kWaveK2Waves - 1) / kWaveK2Waves;
-        const size_t per_wave = (size_t)wave_meta_words(p.rows, p.nblk) + kWaveSortWords;
-        if (p.runlist) {  // dense calls: owners walk their slices, no helper launch
-            hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false, true>), dim3(blocks_per_xcd * 8),
-                               dim3(kWaveK2Waves * 64), per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start,
-                               (unsigned)S, Mdiv, (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc,
-                               region, queue, gv);
-            return (int)hipGetLastError();
-        }
-        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false, false>), dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
-                           per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
-                           (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
-        e = hipGetLastError();
-        if (e != hipSuccess) return (int)e;
-        // slices 1.. of heavy tiles (ends at once when there are none)
-        hipLaunchKernelGGL((msda_bwd_tiles_wave<D, true, false>), dim3(kWaveHelperBlocks), dim3(kWaveK2Waves * 64),
-                           per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
-                           (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
-        return (int)hipGetLastError();
-    }
-    const unsigned nv2 = heads * p.NT, per2 = (nv2 + 7) >> 3;
-    // LDS batch: ~2x the mean number of entries per tile, between 1K and 4K entries
-    const unsigned long long mean = (unsigned long long)Q * L * P * 4 / p.NT;
-    unsigned cap = 1024;
-    while (cap < 8192 && cap < 2 * mean) cap <<= 1;
-    const size_t lds2 = ((size_t)p.rows * 2 + 1 + 3 * p.nblk + 1 + 8 + 1 + (size_t)cap * 2 +
-                         (kK2Threads / 64) * kRowsumPartWords) * 4;
-    if (lds2 > 64 * 1024) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tiles<D>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (ea != hipSuccess) return (int)ea;
-    }
-    hipLaunchKernelGGL(msda_bwd_tiles<D>, dim3(per2 * 8), dim3(kK2Threads), lds2, st, grad_out,
-                       shapes, start, (unsigned)S, Mdiv, (unsigned)Q, nv2, per2, Tdiv,
-                       make_fast_div(p.NT), p, cap, desc, region, gv);
+    const unsigned nvw = heads * p.NT, perw = (nvw + 7) >> 3;
+    const unsigned blocks_per_xcd = (perw + kWaveK2Waves - 1) / kWaveK2Waves;
+    const size_t per_wave = (size_t)wave_meta_words(p.rows, p.nblk) + kWaveSortWords;
+    hipLaunchKernelGGL((msda_bwd_tiles_wave<D, false, false>), dim3(blocks_per_xcd * 8), dim3(kWaveK2Waves * 64),
+                       per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
+                       (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // slices 1.. of heavy tiles (ends at once when there are none)
+    hipLaunchKernelGGL((msda_bwd_tiles_wave<D, true, false>), dim3(kWaveHelperBlocks), dim3(kWaveK2Waves * 64),
+                       per_wave * 4 * kWaveK2Waves, st, grad_out, shapes, start, (unsigned)S, Mdiv,
+                       (unsigned)Q, nvw, perw, Tdiv, make_fast_div(p.NT), p, desc, region, queue, gv);
     return (int)hipGetLastError();
 }
 
@@ -2060,19 +1759,11 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
     return ZIRA_MSDA_EINVAL;
 }
 
-// Which sorted backward serves a call of the workspace entry point: the cell kernels
-// (csrc/msda_cells.hip: bin + LDS accumulate for D = 32, bin + walk for D = 16 / 64) for dense calls
-// (encoder self-attention: every pixel is a query), the entry
-// sort below for sparse ones (decoder cross-attention).  Developer switch for A/B runs:
-// ZIRA_MSDA_BWD=cells | tiled forces one of them where it applies.
+// Which workspace backward serves a call: the cell kernels (csrc/msda_cells.hip: bin + LDS accumulate for D = 32,
+// bin + walk for D = 16 / 64) for dense calls (encoder self-attention: every pixel is a query), plan + tile accumulate
+// (csrc/msda_tiles.hip) or the entry sort below for sparse ones (decoder cross-attention).
 static bool use_cells_path(int B, int M, int Q)
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("ZIRA_MSDA_BWD");
-        v = !e ? 2 : (strcmp(e, "tiled") == 0 ? 0 : (strcmp(e, "cells") == 0 ? 1 : 2));
-    }
-    if (v != 2) return v == 1;
     return (unsigned long long)B * M * Q >= 16 * 4096;
 }
 
@@ -2150,13 +1841,6 @@ int zira_msda_bwd_f64(const double *grad_out, const double *value, const int64_t
                                gl, ga, (hipStream_t)stream);
 }
 
-#if ZIRA_ABLATE == 9
-int zira_dev_read_k2_stamps(unsigned long long *host, int n)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(zira_k2_stamps), sizeof(unsigned long long) * n);
-}
-#endif
-
 const char *zira_msda_version(void) { return "zira_msda 0.1 gfx950"; }
 
 const char *zira_msda_variant_f32(int D)
@@ -2165,7 +1849,7 @@ const char *zira_msda_variant_f32(int D)
     // the call passes lean_ok(); the other specialised widths use the row-per-group kernels
     if (D == 16 || D == 32 || D == 64)
         return D == 32 ? "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_accum + msda_bwd_fold (dense calls) / "
-                         "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic"
+                         "msda_bwd_plan + msda_bwd_tile_accum (sparse calls); without: msda_bwd_lean_atomic"
                        : "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_walk + msda_bwd_fold (dense calls) / "
                          "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic";
     switch (lpr_for(D)) {

@@ -178,8 +178,7 @@ class GraphedTransformer:
     pool; the six image<->text fusion blocks between them stay eager.  Two things fault on the second
     replay on ROCm 7.2 / torch 2.10 and are avoided: ``torch.topk`` inside a graph (the graphed query
     selection takes the first k of a stable descending sort instead: same indices unless logits tie)
-    and graphs that contain three or more BiAttention blocks.  scripts/try_graph.py and
-    scripts/graph_bisect*.py hold the bisection.
+    and graphs that contain three or more BiAttention blocks (found by bisection in round 2).
     One set of graphs per input signature (image size / caption length); further signatures
     run eagerly after ``max_signatures``."""
 
