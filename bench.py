@@ -125,6 +125,12 @@ def msda_micro(dev):
     v, sh, st, loc, attn, go = make_msda_inputs(B, 900, M, D, shapes, P, 0, dev)
     cases = [("northstar_uniform", (v, sh, st, loc, attn, go), 900, 200),
              ("northstar_clustered", (v, sh, st, clustered_loc(B, 900, M, L, P, 1, dev), attn, go), 900, 200)]
+    captured = os.path.join(ROOT, "tests", "golden", "inmodel_decoder_locations.npz")
+    if os.path.exists(captured):   # sampling locations / attention weights captured from a training step of the full-size model
+        import numpy as np
+        with np.load(captured) as z:
+            cases.append(("northstar_inmodel", (v, sh, st, torch.from_numpy(z["loc"].astype(np.float32)).to(dev),
+                                                torch.from_numpy(z["attn"].astype(np.float32)).to(dev), go), 900, 200))
     ve, _, _, _, attne, goe = make_msda_inputs(B, S, M, D, shapes, P, 2, dev)
     cases.append(("encoder_grid", (ve, sh, st, encoder_loc(B, M, shapes, P, 3, dev), attne, goe), S, 50))
     out = {}

@@ -285,6 +285,42 @@ def test_backward_with_one_outsized_head(oracle, path):
             assert err <= 5e-5, "head (%d, %d): %.3e of its own largest entry" % (b, m, err)
 
 
+def test_sparse_backward_time_does_not_depend_on_clustering():
+    """The decoder-shape backward must cost about the same wherever the queries look: the locations captured from
+    a training step (objects: a few tiles take most samples), all queries on three spots, all queries AT three
+    pixels -- each within 1.3x of uniform locations (round 2's entry sort took 1.6-1.7x there).  hipGraph replays of
+    10 launches, best of 5."""
+    def timed(case_kw):
+        value, sh, start, loc, attn, go = _random_case(2, 900, 8, 32, NORTH_STAR_SHAPES, 4, seed=11, **case_kw)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        args = list(map(t, (value, sh, start, loc, attn, go)))
+        fn = lambda: _C.ms_deform_attn_backward(*args, 64)
+        for _ in range(3):
+            fn()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                fn()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 100.0)   # us per launch
+        return best
+    uniform = timed(dict(lo=0.0, hi=1.0))
+    for name, kw in (("inmodel", dict(inmodel=True)), ("hot", dict(hot=True)), ("pinpoint", dict(hot=2))):
+        us = timed(kw)
+        assert us <= 1.3 * uniform, "%s: %.1f us against %.1f us on uniform locations" % (name, us, uniform)
+
+
 def test_dense_backward_is_run_to_run_identical():
     value, sh, start, loc, attn, go = _dense_case(6)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)

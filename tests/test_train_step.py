@@ -223,6 +223,9 @@ def test_two_training_steps_match_reference(msda_backend):
     trainer.flat_grad.zero_()
 
     # the model's own total (what the trainer back-propagates) is the sum of the entries, value and gradients
+    # (two backward passes over one forward: eager launches -- a hipGraph-replayed transformer, the model's default on
+    # the GPU, supports one backward per forward like every torch.cuda.make_graphed_callables callable)
+    graph_default, model.use_transformer_graph = model.use_transformer_graph, False
     ld = run_slice_step(model, *data)
     assert ld.total is not None
     close(ld.total, sum(ld.values()).reshape(()), 1e-6, "LossDict.total")
@@ -230,6 +233,7 @@ def test_two_training_steps_match_reference(msda_backend):
     gb = torch.autograd.grad(sum(ld.values()), [named[n] for n in g["trainable_names"]])
     for n, x, y in zip(g["trainable_names"], ga, gb):
         close(x, y, 1e-6, "grad via total " + n)
+    model.use_transformer_graph = graph_default
 
     # two optimizer steps through the harness
     for it in range(2):

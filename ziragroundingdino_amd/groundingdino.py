@@ -204,6 +204,7 @@ class GroundingDINO(nn.Module):
         # frozen -- every ZiRa task; up to two input signatures, further ones run eagerly); see
         # graphs.GraphedTransformer.  On by default since round 3 (2000-step soak over rotating minibatches,
         # scripts/soak_graph.py; two ranks sharing a GPU, tests/test_model_gpu.py); False launches eagerly.
+        # As with any torch.cuda.make_graphed_callables callable: ONE backward per forward (no retain_graph re-runs).
         self.use_transformer_graph = True
         self.overlap_text_and_image = True   # frozen BERT replayed on a side stream while the frozen Swin runs
         self._text_stream = None
