@@ -119,6 +119,23 @@ int zira_msda_bwd_cpu_f32(const float *grad_out, const float *value, const int64
                           const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
                           float *grad_value, float *grad_sampling_loc, float *grad_attn_weight);
 
+/* ---- small fp32 attention of the cross-modal decoder ------------------------------------------
+ * out = softmax(q k^T * scale + key_mask) v per (batch, head), head width d = 32: what nn.MultiheadAttention computes
+ * between its projections for the decoder's self-attention over the queries and its cross-attention to the text tokens
+ * (reference transformer_for_adapter.py:1029-1054).  q [L, B, H*32], k / v [S, B, H*32] with row strides ldq / ldk / ldv
+ * (floats between consecutive (l, b) rows: slices of fused projections are used in place; 16-byte aligned, strides
+ * multiples of 4); key_mask: optional additive [B, S] (0 or -inf); out [L, B, H*32] contiguous; lse [B, H, L] (the
+ * row-wise log-sum-exp the backward recomputes the probabilities from).  One launch, scores never leave registers
+ * (v_mfma_f32_32x32x2_f32: exact fp32 products).  A query whose keys are all masked gets a zero row (torch gives NaN). */
+int zira_attn_fwd_f32(const float *q, const float *k, const float *v, const float *key_mask, int L, int S, int B, int H,
+                      int d, int ldq, int ldk, int ldv, float scale, float *out, float *lse, void *stream);
+
+/* Gradients of the above: dq [L, B, H*32], dk / dv [S, B, H*32] contiguous, every element written; delta [B, H, L] is
+ * scratch (<dout, out> per query).  Two launches (dq; dk + dv), no atomics. */
+int zira_attn_bwd_f32(const float *q, const float *k, const float *v, const float *key_mask, const float *out,
+                      const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
+                      float scale, float *dq, float *dk, float *dv, float *delta, void *stream);
+
 /* ---- ZiRa reparameterizable side branch (RSB): fused epilogue ---------------------------
  * Replaces the elementwise / reduction tail of RepZeroConv2d.forward and
  * RepZeroLinear.forward in training mode (reference

@@ -20,7 +20,7 @@ SYMBOLS = (
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32", "zira_add_layernorm_fwd_f32",
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32",
-    "zira_sine_embed_f32",
+    "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -49,6 +49,11 @@ def load():
         f.argtypes, f.restype = fwd_args, i
         f = getattr(lib, "zira_msda_bwd_" + suffix)
         f.argtypes, f.restype = bwd_args, i
+    f32 = ctypes.c_float
+    lib.zira_attn_fwd_f32.argtypes = [vp] * 4 + [i] * 8 + [f32, vp, vp, vp]
+    lib.zira_attn_fwd_f32.restype = i
+    lib.zira_attn_bwd_f32.argtypes = [vp] * 7 + [i] * 8 + [f32] + [vp] * 5
+    lib.zira_attn_bwd_f32.restype = i
     lib.zira_msda_fwd_cpu_f32.argtypes, lib.zira_msda_fwd_cpu_f32.restype = fwd_args[:-1], i   # host pointers, no stream
     lib.zira_msda_bwd_cpu_f32.argtypes, lib.zira_msda_bwd_cpu_f32.restype = bwd_args[:-1], i
     lib.zira_msda_bwd_workspace_bytes.argtypes = [i] * 7

@@ -97,6 +97,16 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
         q = F.linear(query, w[:E], b[:E])
         k = F.linear(key, w[E:2 * E], b[E:2 * E])
         v = F.linear(value, w[2 * E:], b[2 * E:])
+    dropout_p = mha.dropout if mha.training else 0.0
+    if (Switches.fused_attention and attn_mask is None and dropout_p == 0.0 and hd == 32 and query.is_cuda
+            and query.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")):
+        # the decoder's two small attentions: one HIP launch forward, two backward, scores in registers (attention.py)
+        from . import attention
+        kpm = key_padding_mask
+        if kpm is not None and kpm.dtype == torch.bool:
+            kpm = _additive_mask(kpm, q.dtype)
+        if attention.supported(q, k, v, H, kpm):
+            return F.linear(attention.fused_attention(q, k, v, H, kpm), mha.out_proj.weight, mha.out_proj.bias)
     q = q.reshape(L, B * H, hd).transpose(0, 1).view(B, H, L, hd)
     k = k.reshape(S, B * H, hd).transpose(0, 1).view(B, H, S, hd)
     v = v.reshape(S, B * H, hd).transpose(0, 1).view(B, H, S, hd)
@@ -111,7 +121,6 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
             kpm = _additive_mask(kpm, q.dtype)
         kpm = kpm.view(B, 1, 1, S)
         mask = kpm if mask is None else mask + kpm
-    dropout_p = mha.dropout if mha.training else 0.0
     if Switches.small_attention and B * H * L * S <= SMALL_ATTENTION_SCORES:
         out = _attention_small(q, k, v, mask, dropout_p)
     else:
@@ -147,6 +156,7 @@ class Switches:
     """Module-level implementation switches (True = the leaner equivalent path)."""
     lean_mha = True
     small_attention = True   # lean_mha: materialised scores instead of the fused SDPA kernel for small problems
+    fused_attention = True   # lean_mha: csrc/attn.hip for fp32 heads of width 32 without attention mask / dropout (the decoder's)
     sort_for_topk = False    # select_queries: stable sort instead of torch.topk everywhere (developer switch)
 
 
