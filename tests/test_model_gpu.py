@@ -362,6 +362,51 @@ def test_two_ranks_on_one_gpu_match_one_process(tmp_path):
         assert float(d.max()) < 0.2 * 4 * 1e-3, (n, float(d.max()))
 
 
+def test_fused_query_projection_of_the_msda_module():
+    """MultiScaleDeformableAttention with frozen weights projects the query ONCE for sampling offsets and attention
+    weights (concatenated weights, one GEMM each way): same output and input gradients as the two projections; the
+    cache follows in-place weight updates."""
+    from ziragroundingdino_amd.ms_deform_attn import MultiScaleDeformableAttention as M
+
+    torch.manual_seed(0)
+    mod = M(embed_dim=256, num_heads=8, num_levels=3, num_points=4, batch_first=True).cuda()
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.1)
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    shapes = torch.tensor([[16, 20], [8, 10], [4, 5]], device="cuda")
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    q = torch.randn(2, 50, 256, device="cuda", requires_grad=True)
+    v = torch.randn(2, S, 256, device="cuda", requires_grad=True)
+    ref = torch.rand(2, 50, 3, 2, device="cuda")
+    g = torch.randn(2, 50, 256, device="cuda")
+
+    def run():
+        out = mod(query=q, value=v, reference_points=ref, spatial_shapes=shapes, level_start_index=start)
+        return (out,) + torch.autograd.grad(out, [q, v], g)
+
+    try:
+        M.fuse_query_projections = False
+        want = run()
+        M.fuse_query_projections = True
+        got = run()
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+        assert mod._fused_query_projection() is not None
+        with torch.no_grad():
+            mod.attention_weights.bias.add_(0.5)          # in-place update: the cached concatenation must follow
+        M.fuse_query_projections = False
+        want = run()
+        M.fuse_query_projections = True
+        got = run()
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    finally:
+        M.fuse_query_projections = True
+
+
 def test_frontend_prefetch_gives_the_same_steps():
     """ZiraTrainer.run_step(data, next_data=...) queues the frozen front end of the next minibatch on a second stream
     and the next step picks it up: same losses and weights as without (no stochastic depth / dropout in this model)."""

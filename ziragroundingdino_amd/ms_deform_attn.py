@@ -210,6 +210,26 @@ class MultiScaleDeformableAttention(nn.Module):
         self.attention_weights.weight.requires_grad = False
         self.attention_weights.bias.requires_grad = False
 
+    fuse_query_projections = True   # class-level switch (tests compare both ways)
+
+    def _fused_query_projection(self):
+        """``sampling_offsets`` and ``attention_weights`` read the same query: while both are frozen (every ZiRa task)
+        their weights are kept concatenated -- rebuilt when either tensor changes (load_state_dict, .to())."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        if (not self.fuse_query_projections or so.weight.requires_grad or aw.weight.requires_grad
+                or so.bias is None or aw.bias is None or so.bias.requires_grad or aw.bias.requires_grad
+                or not so.weight.is_cuda):
+            return None
+        key = (so.weight.data_ptr(), so.weight._version, aw.weight.data_ptr(), aw.weight._version,
+               so.bias.data_ptr(), so.bias._version, aw.bias.data_ptr(), aw.bias._version, so.weight.dtype)
+        cached = getattr(self, "_fused_qp", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                w = torch.cat([so.weight, aw.weight], 0).contiguous()
+                b = torch.cat([so.bias, aw.bias], 0).contiguous()
+            cached = self._fused_qp = (key, w, b)
+        return cached[1], cached[2]
+
     def project(self, query, value, key_padding_mask, reference_points, spatial_shapes):
         """Everything of ``forward`` up to the native call (reference :286-325), batch-first.
         Returns (value[B,S,M,D], sampling_locations[B,Q,M,L,P,2], attention_weights[B,Q,M,L,P])."""
@@ -220,8 +240,15 @@ class MultiScaleDeformableAttention(nn.Module):
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], float(0))
         value = value.view(bs, num_value, M, -1)
-        offsets = self.sampling_offsets(query).view(bs, num_query, M, L, P, 2)
-        attn = self.attention_weights(query).view(bs, num_query, M, L * P)
+        fused = self._fused_query_projection()
+        if fused is not None:   # one GEMM for the two projections of the query (both frozen: one dgrad GEMM, no add)
+            oa = F.linear(query, fused[0], fused[1])
+            offsets, attn = oa.split([M * L * P * 2, M * L * P], dim=-1)   # (split: its backward is one cat)
+            offsets = offsets.reshape(bs, num_query, M, L, P, 2)
+            attn = attn.reshape(bs, num_query, M, L * P)
+        else:
+            offsets = self.sampling_offsets(query).view(bs, num_query, M, L, P, 2)
+            attn = self.attention_weights(query).view(bs, num_query, M, L * P)
         attn = attn.softmax(-1).view(bs, num_query, M, L, P)
         loc = sampling_locations_from_reference_points(reference_points, offsets, spatial_shapes, P)
         return value, loc, attn
