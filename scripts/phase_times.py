@@ -17,6 +17,7 @@ def run():
     from ziragroundingdino_amd import transformer as T
     dev = torch.device("cuda"); torch.manual_seed(0)
     model = build_model(zira_swint_config(device="cuda")).to(dev).train()
+    model.use_transformer_graph = False   # eager launches: the hooks below sit inside the pieces a graph would hold
     trainer = ZiraTrainer(model)
     data = synthetic_batch(2, 800, 1333, device=dev)
     scratch = torch.empty(MARK0 + 4096 * 64, device=dev)

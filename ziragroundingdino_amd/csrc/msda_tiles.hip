@@ -14,23 +14,35 @@
 // 193.  So the destination can simply be SUMMED IN LDS IN DOUBLE, in any order, and a pile-up on a few
 // pixels costs nothing extra.  What is left to balance is the number of samples per work item, and every
 // (head, level) unit holds exactly Q * P of them however they are spread: a cheap pass over the sampling
-// locations counts them per tile and cuts busy tiles by query range.
+// locations counts them per tile, sorts them by tile and cuts busy tiles by record range.
 //
-//   plan   (msda_bwd_plan)  one block per (head, level) unit.  A thread per query: pixel coordinates of the
-//          unit's samples -> a 4-byte CELL WORD per sample (top-left pixel + 1, or "outside") in
-//          unit-major order, a histogram of samples per tile (16 x 8 pixels) in LDS, zero gradients for
-//          samples outside the window.  Then per tile: K = ceil(samples / cap) query shares; shares 1..K-1
-//          become extra work items; the pixels of split tiles are zeroed (their shares meet through global
-//          fp32 atomics).  No value / grad_out traffic.
-//   accum  (msda_bwd_tile_accum)  persistent blocks, a work item = (head, level, tile, query share).  The block
-//          scans the cell words of its share (Q * P / K contiguous words), keeps the samples whose 2 x 2
-//          corner block touches the tile, and handles each of them with 8 lanes x 4 channels: the grad_out
-//          row (one 128-byte gather), the four corner terms w * (attn * g) added to the tile's accumulators
-//          (`ds_add_f64`; the two samples of a 16-lane group use different bank halves), and -- in the tile
-//          that owns the sample -- the four value rows, their dot products with the grad_out row and
-//          grad_sampling_loc / grad_attn_weight.  The tile is then written once: plain 16-byte stores of
-//          every pixel for unsplit tiles (no zero-fill of grad_value anywhere), fp32 atomics of the non-zero
-//          pixels for split ones.
+//   plan   (msda_bwd_plan)  one 1024-thread block per (head, level) unit; no value / grad_out traffic.  Pass 1: a
+//          thread per query computes the pixel coordinates of its samples and counts each sample into every tile
+//          (16 x 8 pixels) its 2 x 2 corner block touches (LDS histogram); samples outside the window get zero
+//          gradients.  A block scan turns the histogram into record offsets.  Pass 2 writes one 16-byte RECORD per
+//          (sample, touched tile): {sample id : 18 | home position : 7 | flags : 7, the four corner positions
+//          inside the tile as bytes (255 = corner not in this tile), lw, lh}, sorted by tile.  Then per tile a
+//          16-byte header {first record, count (0 when split), origin, level | split}; a tile with more than `cap`
+//          records is SPLIT: all its K = ceil(n / cap) shares become extra work items {first record, count,
+//          origin, level}, and its pixels are zeroed here (the shares meet through global fp32 atomics).
+//   accum  (msda_bwd_tile_accum)  persistent blocks (256 threads, 4 per CU) dealing out the work items of one XCD's
+//          heads in turn: split shares first, then tiles from the coarsest level down.  Per item: 32 records per
+//          block step, 8 lanes x 4 channels per record: the grad_out row (one 128-byte gather), the corner terms
+//          w * (attn * g) added to the tile's accumulators in LDS (`ds_add_f64`; the two records of a 16-lane
+//          group use different bank halves), and -- in the tile that owns the sample -- the four value rows,
+//          their dot products with the grad_out row and grad_sampling_loc / grad_attn_weight.  The loop is a
+//          two-stage software pipeline (loads of step i + 1 in flight while step i is added), all loads and stores
+//          unconditional (clamped record index, dump line) so that the compiler's in-order vmcnt waits stay exact;
+//          the next item's header, records and first loads are issued before the current tile is flushed.
+//          Flush: plain 16-byte stores of every pixel for unsplit tiles (no zero-fill of grad_value anywhere), fp32
+//          atomics of the non-zero pixels for shares of split tiles.
+//
+// Measured (MI355X, decoder shape B=2 S=22223 M=8 L=4 Q=900 P=4): plan 12 us + accumulate 38-40 us; uniform
+// 51-53, in-model locations 50-52, all queries on 5 % of the map 46, on one pixel block 42 us (round 2:
+// 46 / 75-80 / - / -).  Two other decompositions were measured in round 3 and lost: handing
+// the items out through a counter per XCD (same-address returning atomics from 128 blocks: 74 us), and sorting
+// the corner terms by destination pixel so that a wave gathers a packet of rows (49-60 us: latency-bound
+// chains of dependent loads per wave).
 //
 // The sums are formed in double from exact products of fp32 factors (w and attn * g rounded to fp32 as in
 // the reference, cuh:117-147) and rounded to fp32 once: at least as close to the reference as an fp32
@@ -766,7 +778,7 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
         }
     };
     run(std::true_type{}, v, E);
-    run(std::false_type{}, v, nh * NT);
+    run(std::false_type{}, (v + vstep - E % vstep) % vstep, nh * NT);   // (the deal goes on where the extra items left it: item counts differ by one at most)
     TSTAMP_FLUSH;
 }
 
