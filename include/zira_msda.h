@@ -130,11 +130,14 @@ int zira_msda_bwd_cpu_f32(const float *grad_out, const float *value, const int64
 int zira_attn_fwd_f32(const float *q, const float *k, const float *v, const float *key_mask, int L, int S, int B, int H,
                       int d, int ldq, int ldk, int ldv, float scale, float *out, float *lse, void *stream);
 
-/* Gradients of the above: dq [L, B, H*32], dk / dv [S, B, H*32] contiguous, every element written; delta [B, H, L] is
- * scratch (<dout, out> per query).  Two launches (dq; dk + dv), no atomics. */
+/* Gradients of the above: dq [L, B, H*32], dk / dv [S, B, H*32] contiguous, every element written.  `scratch`
+ * (16-byte aligned, zira_attn_bwd_scratch_floats() floats; B*H*L is the minimum) holds <dout, out> per query and, when
+ * there are few key blocks, the partial dk / dv sums of the shares of the query range, which a third launch adds up in
+ * a fixed order (no atomics: the result does not depend on the run). */
+size_t zira_attn_bwd_scratch_floats(int L, int S, int B, int H);
 int zira_attn_bwd_f32(const float *q, const float *k, const float *v, const float *key_mask, const float *out,
                       const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
-                      float scale, float *dq, float *dk, float *dv, float *delta, void *stream);
+                      float scale, float *dq, float *dk, float *dv, float *scratch, size_t scratch_floats, void *stream);
 
 /* ---- ZiRa reparameterizable side branch (RSB): fused epilogue ---------------------------
  * Replaces the elementwise / reduction tail of RepZeroConv2d.forward and
@@ -271,6 +274,19 @@ int zira_cat_logits_bwd_f32(const float *grad_out, const int32_t *argmax, const 
 int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *bias_t, int B, int H, int W, int heads,
                          int head_dim, int window, int shift, float scale, float *out, void *stream);
 
+
+/* ---- MSDA module: attention softmax + sampling locations, forward and backward ---------------------
+ * zira_msda_sampling_{fwd,bwd}_f32 replace what MultiScaleDeformableAttention.forward does between its query projections
+ * and the native op (groundingdino/models/GroundingDINO/ms_deform_attn.py:295-325): softmax of the attention logits
+ * over the L*P samples of a (query, head), and sampling_locations = reference point + offset / (W_l, H_l)  (R = 2) or
+ * reference box centre + offset / P * box size * 0.5  (R = 4), each operation rounded as in the reference.
+ * proj [N, ld] holds, per query row, M*L*P*2 offsets followed by M*L*P logits (ld >= 3*M*L*P, even); ref [N, L, R];
+ * shapes int64 [L, 2] on the device; loc [N, M, L, P, 2], attn [N, M, L, P] contiguous.  L*P must be a power of two
+ * <= 64.  The backward writes both parts of every row of grad_proj (reference points get no gradient). */
+int zira_msda_sampling_fwd_f32(const float *proj, int ld, const float *ref, int R, const int64_t *shapes, long long N, int M,
+                               int L, int P, float *loc, float *attn, void *stream);
+int zira_msda_sampling_bwd_f32(const float *grad_loc, const float *grad_attn, const float *attn, const float *ref, int R,
+                               const int64_t *shapes, long long N, int M, int L, int P, float *grad_proj, int ld, void *stream);
 
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):

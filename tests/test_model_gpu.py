@@ -407,6 +407,60 @@ def test_fused_query_projection_of_the_msda_module():
         M.fuse_query_projections = True
 
 
+@pytest.mark.parametrize("R", [2, 4])
+def test_sampling_plan_of_the_msda_module(R):
+    """softmax + sampling locations in one native launch each way (csrc/sampling.hip) against the PyTorch op chain of the
+    reference module (ms_deform_attn.py:295-325): the sampling locations bit for bit (the reference's roundings), the
+    attention weights and the gradient of the projection within fp32 rounding; the module gives the same output and
+    input gradients either way."""
+    from ziragroundingdino_amd import ms_deform_attn as mda
+    M = mda.MultiScaleDeformableAttention
+
+    torch.manual_seed(1)
+    mod = M(embed_dim=256, num_heads=8, num_levels=4, num_points=4, batch_first=True).cuda()
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.05)
+        mod.attention_weights.weight.normal_(0, 0.2)
+    for p in mod.parameters():
+        p.requires_grad_(False)
+    shapes = torch.tensor([[16, 20], [8, 10], [4, 5], [2, 3]], device="cuda")
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    q = torch.randn(2, 77, 256, device="cuda", requires_grad=True)
+    v = torch.randn(2, S, 256, device="cuda", requires_grad=True)
+    ref = torch.rand(2, 77, 4, R, device="cuda") * 0.6 + 0.2
+    g = torch.randn(2, 77, 256, device="cuda")
+
+    def run():
+        value, loc, attn = mod.project(q, v, None, ref, shapes)
+        out = mod(query=q, value=v, reference_points=ref, spatial_shapes=shapes, level_start_index=start)
+        return (loc, attn, out) + torch.autograd.grad(out, [q, v], g)
+
+    try:
+        M.fuse_sampling_plan = False
+        want = run()
+        M.fuse_sampling_plan = True
+        assert mda._sampling_plan_ok(torch.empty(1, 1, 384, device="cuda"), ref, shapes, 4, 4)
+        got = run()
+        assert torch.equal(got[0], want[0])                                   # sampling locations: the reference's roundings
+        for a, b in zip(got[1:], want[1:]):
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+        # the Function alone, with arbitrary incoming gradients
+        proj = torch.randn(2, 77, 384, device="cuda", requires_grad=True)
+        gl, ga = torch.randn(2, 77, 8, 4, 4, 2, device="cuda"), torch.randn(2, 77, 8, 4, 4, device="cuda")
+        loc, attn = mda._SamplingPlan.apply(proj, ref, shapes, 8, 4, 4)
+        gp = torch.autograd.grad([loc, attn], [proj], [gl, ga])[0]
+        off, lg = proj.split([256, 128], dim=-1)
+        loc_w = mda.sampling_locations_from_reference_points(ref, off.reshape(2, 77, 8, 4, 4, 2), shapes, 4)
+        attn_w = lg.reshape(2, 77, 8, 16).softmax(-1).view(2, 77, 8, 4, 4)
+        gp_w = torch.autograd.grad([loc_w, attn_w], [proj], [gl, ga])[0]
+        assert torch.equal(loc, loc_w)
+        torch.testing.assert_close(attn, attn_w, rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(gp, gp_w, rtol=2e-5, atol=1e-6)
+    finally:
+        M.fuse_sampling_plan = True
+
+
 def test_frontend_prefetch_gives_the_same_steps():
     """ZiraTrainer.run_step(data, next_data=...) queues the frozen front end of the next minibatch on a second stream
     and the next step picks it up: same losses and weights as without (no stochastic depth / dropout in this model)."""

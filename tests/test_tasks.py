@@ -186,7 +186,7 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     import bench
 
     calls = {}
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 4)   # (counted from the environment / sysfs, never through HIP)
     monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)
     with pytest.raises(SystemExit) as e:
         bench.spawn_ranks(4, ["--gpus", "4", "--steps", "3"])

@@ -20,7 +20,7 @@ SYMBOLS = (
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32", "zira_add_layernorm_fwd_f32",
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32",
-    "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32",
+    "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -52,8 +52,10 @@ def load():
     f32 = ctypes.c_float
     lib.zira_attn_fwd_f32.argtypes = [vp] * 4 + [i] * 8 + [f32, vp, vp, vp]
     lib.zira_attn_fwd_f32.restype = i
-    lib.zira_attn_bwd_f32.argtypes = [vp] * 7 + [i] * 8 + [f32] + [vp] * 5
+    lib.zira_attn_bwd_f32.argtypes = [vp] * 7 + [i] * 8 + [f32] + [vp] * 4 + [ctypes.c_size_t, vp]
     lib.zira_attn_bwd_f32.restype = i
+    lib.zira_attn_bwd_scratch_floats.argtypes = [i] * 4
+    lib.zira_attn_bwd_scratch_floats.restype = ctypes.c_size_t
     lib.zira_msda_fwd_cpu_f32.argtypes, lib.zira_msda_fwd_cpu_f32.restype = fwd_args[:-1], i   # host pointers, no stream
     lib.zira_msda_bwd_cpu_f32.argtypes, lib.zira_msda_bwd_cpu_f32.restype = bwd_args[:-1], i
     lib.zira_msda_bwd_workspace_bytes.argtypes = [i] * 7
@@ -97,6 +99,10 @@ def load():
     lib.zira_cat_logits_bwd_f32.restype = i
     lib.zira_window_attn_f32.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, f32, vp, vp]
     lib.zira_window_attn_f32.restype = i
+    lib.zira_msda_sampling_fwd_f32.argtypes = [vp, i, vp, i, vp, ll, i, i, i, vp, vp, vp]
+    lib.zira_msda_sampling_fwd_f32.restype = i
+    lib.zira_msda_sampling_bwd_f32.argtypes = [vp, vp, vp, vp, i, vp, ll, i, i, i, vp, i, vp]
+    lib.zira_msda_sampling_bwd_f32.restype = i
     lib.zira_sine_embed_f32.argtypes = [vp, vp, ll, i, i, f32, vp, vp]
     lib.zira_sine_embed_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p

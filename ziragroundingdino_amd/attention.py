@@ -67,12 +67,13 @@ class _FusedAttention(torch.autograd.Function):
         dq = torch.empty((L, B, E), dtype=torch.float32, device=q.device)
         dk = torch.empty((S, B, E), dtype=torch.float32, device=q.device)
         dv = torch.empty((S, B, E), dtype=torch.float32, device=q.device)
-        delta = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        nscr = lib.zira_attn_bwd_scratch_floats(L, S, B, H)
+        scratch = torch.empty((nscr,), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             rc = lib.zira_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), km.data_ptr() if km is not None else None,
                                        out.data_ptr(), dout.data_ptr(), lse.data_ptr(), L, S, B, H, 32,
                                        _row_stride(q), _row_stride(k), _row_stride(v), 1.0 / math.sqrt(32.0),
-                                       dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), _stream())
+                                       dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), scratch.data_ptr(), nscr, _stream())
         if rc != 0:
             raise RuntimeError("zira_attn_bwd_f32 failed with code %d" % rc)
         return dq, dk, dv, None, None

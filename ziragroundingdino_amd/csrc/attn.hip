@@ -279,13 +279,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(const float *__restrict__ q, 
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, dK and dV: a block per 32 keys, the waves split the query tiles
+// backward, dK and dV: a block per 32 keys and share z of the query tiles (tiles z, z + QS, ...), the waves split the
+// share.  With QS > 1 the blocks write partial sums part[z][S][B][E] that attn_sum_parts adds up in a fixed order: the
+// text side has 32 tokens -- one key block per (image, head), 16 blocks on 256 CUs, 40 us; 12 + 4 us in seven shares.
 // ------------------------------------------------------------------------------------------
 template <bool MASK>
 __global__ __launch_bounds__(256) void attn_bwd_dkv(const float *__restrict__ q, const float *__restrict__ k,
                                                     const float *__restrict__ v, const float *__restrict__ kpm,
                                                     const float *__restrict__ dout, const float *__restrict__ lse,
-                                                    const float *__restrict__ delta, AttnDims A, float *__restrict__ dk,
+                                                    const float *__restrict__ delta, AttnDims A, int QS, float *__restrict__ dk,
                                                     float *__restrict__ dv)
 {
     __shared__ float sk[32][33], sv[32][33];
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const float *__restrict__ q,
 #pragma unroll
     for (int i = 0; i < 16; ++i) { adk[i] = 0.f; adv[i] = 0.f; }
 
-    for (int qt = (int)wave; qt < nqt; qt += 4) {
+    for (int qt = (int)blockIdx.z + QS * (int)wave; qt < nqt; qt += 4 * QS) {
         const int q0 = qt * 32;
         const int qr = q0 + (int)r < A.L ? q0 + (int)r : A.L - 1;
         float qa[16], da[16], qc[16], dc[16];
@@ -320,11 +322,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const float *__restrict__ q,
 #pragma unroll
         for (int t = 0; t < 16; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da[t], vb[t], dp, 0, 0, 0);
         // s / dp [reg] = S / dP [query q0 + rowmap(reg, hh)][key k0 + r]
+        // (lse / delta of the tile's 32 queries: one load per lane, handed round with ds_bpermute instead of 32 loads: 62 -> 55 us)
+        const float lse_r = lse[(size_t)bh * A.L + qr], del_r = delta[(size_t)bh * A.L + qr];
 #pragma unroll
         for (unsigned reg = 0; reg < 16; ++reg) {
             const int qi = q0 + (int)rowmap(reg, hh);
-            const int qc_ = qi < A.L ? qi : A.L - 1;
-            const float lq = lse[(size_t)bh * A.L + qc_], dl = delta[(size_t)bh * A.L + qc_];
+            const float lq = __shfl(lse_r, (int)rowmap(reg, hh)), dl = __shfl(del_r, (int)rowmap(reg, hh));
             const float p = (qi < A.L && kvalid && lq != -INFINITY) ? __expf(s[reg] + km - lq) : 0.f;
             s[reg] = p;                        // P
             dp[reg] = p * (dp[reg] - dl);      // dS
@@ -349,11 +352,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const float *__restrict__ q,
     __syncthreads();
     const unsigned kk = tid >> 3, d4 = tid & 7;
     if (k0 + (int)kk < A.S) {
-        const size_t o = ((size_t)(k0 + kk) * A.B + b) * E + h * kD + d4 * 4;
+        const size_t o = (((size_t)blockIdx.z * A.S + (k0 + kk)) * A.B + b) * E + h * kD + d4 * 4;   // (share z of the partial sums)
         const float *a = &sk[kk][d4 * 4], *c = &sv[kk][d4 * 4];
         *reinterpret_cast<float4 *>(dk + o) = make_float4(a[0] * A.scale, a[1] * A.scale, a[2] * A.scale, a[3] * A.scale);
         *reinterpret_cast<float4 *>(dv + o) = make_float4(c[0], c[1], c[2], c[3]);
     }
+}
+
+// out[i] = part[0][i] + part[1][i] + ... (n4 float4 elements per part)
+__global__ __launch_bounds__(256) void attn_sum_parts(const float4 *__restrict__ pk, const float4 *__restrict__ pv, int parts, size_t n4,
+                                                      float4 *__restrict__ dk, float4 *__restrict__ dv)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = pk[i], c = pv[i];
+    for (int z = 1; z < parts; ++z) {
+        const float4 x = pk[z * n4 + i], y = pv[z * n4 + i];
+        a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        c.x += y.x; c.y += y.y; c.z += y.z; c.w += y.w;
+    }
+    dk[i] = a;
+    dv[i] = c;
+}
+
+// shares of the query tiles in the dK / dV kernel when there are few key blocks: enough blocks for ~1000, at least one
+// tile per wave
+int dkv_query_shares(int L, int S, int B, int H)
+{
+    const int nqt = (L + 31) / 32, blocks = ((S + 31) / 32) * B * H;
+    if (blocks >= 128) return 1;   // (measured at 900 keys: 62 us with one share, 70 with three)
+    int qs = (1024 + blocks - 1) / blocks;
+    qs = qs > 8 ? 8 : qs;
+    qs = qs > nqt / 4 ? nqt / 4 : qs;
+    return qs < 1 ? 1 : qs;
 }
 
 bool attn_args_ok(const void *q, const void *k, const void *v, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv)
@@ -386,22 +417,38 @@ int zira_attn_fwd_f32(const float *q, const float *k, const float *v, const floa
     return (int)hipGetLastError();
 }
 
+size_t zira_attn_bwd_scratch_floats(int L, int S, int B, int H)
+{
+    if (L <= 0 || S <= 0 || B <= 0 || H <= 0) return 0;
+    const int qs = dkv_query_shares(L, S, B, H);
+    return (size_t)B * H * L + (qs > 1 ? 2 * (size_t)qs * S * B * H * kD : 0);
+}
+
 int zira_attn_bwd_f32(const float *q, const float *k, const float *v, const float *key_mask, const float *out,
                       const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
-                      float scale, float *dq, float *dk, float *dv, float *delta, void *stream)
+                      float scale, float *dq, float *dk, float *dv, float *scratch, size_t scratch_floats, void *stream)
 {
-    if (!attn_args_ok(q, k, v, L, S, B, H, d, ldq, ldk, ldv) || !out || !dout || !lse || !dq || !dk || !dv || !delta)
+    if (!attn_args_ok(q, k, v, L, S, B, H, d, ldq, ldk, ldv) || !out || !dout || !lse || !dq || !dk || !dv || !scratch ||
+        scratch_floats < (size_t)B * H * L || ((uintptr_t)scratch & 15))
         return ZIRA_MSDA_EINVAL;
     const AttnDims A = {L, S, B, H, ldq, ldk, ldv, scale};
     hipStream_t st = (hipStream_t)stream;
     const int nqt = (L + 31) / 32, nkt = (S + 31) / 32;
+    float *delta = scratch;                                   // [B, H, L]
+    const size_t n = (size_t)S * B * H * kD, doff = (((size_t)B * H * L + 3) / 4) * 4;
+    int qs = dkv_query_shares(L, S, B, H);
+    if (scratch_floats < doff + 2 * (size_t)qs * n) qs = 1;   // (no room for partial sums: one share)
+    float *pk = qs > 1 ? scratch + doff : dk, *pv = qs > 1 ? scratch + doff + (size_t)qs * n : dv;
     if (key_mask) {
         hipLaunchKernelGGL((attn_bwd_dq<true>), dim3(nqt, B * H), dim3(256), 0, st, q, k, v, key_mask, out, dout, lse, A, dq, delta);
-        hipLaunchKernelGGL((attn_bwd_dkv<true>), dim3(nkt, B * H), dim3(256), 0, st, q, k, v, key_mask, dout, lse, delta, A, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dkv<true>), dim3(nkt, B * H, qs), dim3(256), 0, st, q, k, v, key_mask, dout, lse, delta, A, qs, pk, pv);
     } else {
         hipLaunchKernelGGL((attn_bwd_dq<false>), dim3(nqt, B * H), dim3(256), 0, st, q, k, v, key_mask, out, dout, lse, A, dq, delta);
-        hipLaunchKernelGGL((attn_bwd_dkv<false>), dim3(nkt, B * H), dim3(256), 0, st, q, k, v, key_mask, dout, lse, delta, A, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dkv<false>), dim3(nkt, B * H, qs), dim3(256), 0, st, q, k, v, key_mask, dout, lse, delta, A, qs, pk, pv);
     }
+    if (qs > 1)
+        hipLaunchKernelGGL(attn_sum_parts, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(pk),
+                           reinterpret_cast<const float4 *>(pv), qs, n / 4, reinterpret_cast<float4 *>(dk), reinterpret_cast<float4 *>(dv));
     return (int)hipGetLastError();
 }
 

@@ -55,6 +55,58 @@ class MultiScaleDeformableAttnFunction(Function):
 FUSED_LOCATIONS = True   # module-level switch for A/B runs
 
 
+class _SamplingPlan(Function):
+    """softmax of the attention logits + sampling locations from the ONE projection of the query (``[B, Q, 3*M*L*P]``:
+    offsets, then logits), one native launch each way (csrc/sampling.hip); reference ms_deform_attn.py:295-325.
+    The reference points get no gradient (callers check ``requires_grad``)."""
+
+    @staticmethod
+    def forward(ctx, proj, reference_points, spatial_shapes, M, L, P):
+        from . import _lib
+        lib = _lib.load()
+        B, Q, ld = proj.shape
+        proj = proj.contiguous()
+        ref = reference_points.contiguous()
+        R = ref.shape[-1]
+        loc = torch.empty((B, Q, M, L, P, 2), dtype=torch.float32, device=proj.device)
+        attn = torch.empty((B, Q, M, L, P), dtype=torch.float32, device=proj.device)
+        with torch.cuda.device(proj.device):
+            rc = lib.zira_msda_sampling_fwd_f32(proj.data_ptr(), ld, ref.data_ptr(), R, spatial_shapes.data_ptr(), B * Q, M, L, P,
+                                                loc.data_ptr(), attn.data_ptr(), torch.cuda.current_stream(proj.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_msda_sampling_fwd_f32 failed with code %d" % rc)
+        ctx.save_for_backward(attn, ref, spatial_shapes)
+        ctx.dims = (B, Q, ld, M, L, P, R)
+        return loc, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loc, grad_attn):
+        from . import _lib
+        lib = _lib.load()
+        attn, ref, spatial_shapes = ctx.saved_tensors
+        B, Q, ld, M, L, P, R = ctx.dims
+        grad_loc, grad_attn = grad_loc.contiguous(), grad_attn.contiguous()
+        grad_proj = torch.empty((B, Q, ld), dtype=torch.float32, device=attn.device)
+        if ld != 3 * M * L * P:
+            grad_proj.zero_()
+        with torch.cuda.device(attn.device):
+            rc = lib.zira_msda_sampling_bwd_f32(grad_loc.data_ptr(), grad_attn.data_ptr(), attn.data_ptr(), ref.data_ptr(), R,
+                                                spatial_shapes.data_ptr(), B * Q, M, L, P, grad_proj.data_ptr(), ld,
+                                                torch.cuda.current_stream(attn.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_msda_sampling_bwd_f32 failed with code %d" % rc)
+        return grad_proj, None, None, None, None, None
+
+
+def _sampling_plan_ok(proj, reference_points, spatial_shapes, L, P):
+    LP = L * P
+    return (proj.is_cuda and proj.dtype == torch.float32 and reference_points.dtype == torch.float32
+            and not reference_points.requires_grad and reference_points.shape[-1] in (2, 4)
+            and LP <= 64 and (LP & (LP - 1)) == 0 and spatial_shapes.is_cuda and spatial_shapes.dtype == torch.int64
+            and spatial_shapes.is_contiguous() and not torch.is_autocast_enabled())
+
+
 def sampling_locations_from_reference_points(reference_points, sampling_offsets, spatial_shapes,
                                              num_points):
     """Sampling-location arithmetic of the reference module (ms_deform_attn.py:305-325).
@@ -211,6 +263,7 @@ class MultiScaleDeformableAttention(nn.Module):
         self.attention_weights.bias.requires_grad = False
 
     fuse_query_projections = True   # class-level switch (tests compare both ways)
+    fuse_sampling_plan = True       # ... softmax + sampling locations in one native launch each way (needs the fused projection)
 
     def _fused_query_projection(self):
         """``sampling_offsets`` and ``attention_weights`` read the same query: while both are frozen (every ZiRa task)
@@ -243,6 +296,9 @@ class MultiScaleDeformableAttention(nn.Module):
         fused = self._fused_query_projection()
         if fused is not None:   # one GEMM for the two projections of the query (both frozen: one dgrad GEMM, no add)
             oa = F.linear(query, fused[0], fused[1])
+            if self.fuse_sampling_plan and _sampling_plan_ok(oa, reference_points, spatial_shapes, L, P):
+                loc, attn = _SamplingPlan.apply(oa, reference_points, spatial_shapes, M, L, P)
+                return value, loc, attn
             offsets, attn = oa.split([M * L * P * 2, M * L * P], dim=-1)   # (split: its backward is one cat)
             offsets = offsets.reshape(bs, num_query, M, L, P, 2)
             attn = attn.reshape(bs, num_query, M, L * P)
