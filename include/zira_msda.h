@@ -277,7 +277,7 @@ int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *b
 
 /* ---- MSDA module: attention softmax + sampling locations, forward and backward ---------------------
  * zira_msda_sampling_{fwd,bwd}_f32 replace what MultiScaleDeformableAttention.forward does between its query projections
- * and the native op (groundingdino/models/GroundingDINO/ms_deform_attn.py:295-325): softmax of the attention logits
+ * and the native op (groundingdino/models/GroundingDINO/ms_deform_attn.py:290-325): softmax of the attention logits
  * over the L*P samples of a (query, head), and sampling_locations = reference point + offset / (W_l, H_l)  (R = 2) or
  * reference box centre + offset / P * box size * 0.5  (R = 4), each operation rounded as in the reference.
  * proj [N, ld] holds, per query row, M*L*P*2 offsets followed by M*L*P logits (ld >= 3*M*L*P, even); ref [N, L, R];

@@ -410,7 +410,7 @@ def test_fused_query_projection_of_the_msda_module():
 @pytest.mark.parametrize("R", [2, 4])
 def test_sampling_plan_of_the_msda_module(R):
     """softmax + sampling locations in one native launch each way (csrc/sampling.hip) against the PyTorch op chain of the
-    reference module (ms_deform_attn.py:295-325): the sampling locations bit for bit (the reference's roundings), the
+    reference module (ms_deform_attn.py:290-325): the sampling locations bit for bit (the reference's roundings), the
     attention weights and the gradient of the projection within fp32 rounding; the module gives the same output and
     input gradients either way."""
     from ziragroundingdino_amd import ms_deform_attn as mda

@@ -1,6 +1,6 @@
 """Fused small attention on the GPU (C ABI ``zira_attn_{fwd,bwd}_f32``, csrc/attn.hip): what
 ``nn.MultiheadAttention`` computes between its projections for the decoder's self-attention over the queries and its
-cross-attention to the text tokens (reference transformer_for_adapter.py:1029-1054), forward and backward, with the
+cross-attention to the text tokens (reference transformer_for_adapter.py:1043-1058), forward and backward, with the
 scores kept in registers.  fp32, head width 32, no dropout, optional additive key-padding mask."""
 import math
 

@@ -1,6 +1,6 @@
 // attn.hip -- softmax(Q K^T * scale + key mask) V for the small fp32 attentions of the cross-modal decoder
 // (self-attention over the 900 queries, cross-attention to the <= 256 text tokens; reference
-// transformer_for_adapter.py:1029-1054 through nn.MultiheadAttention), forward and backward, head width 32.
+// transformer_for_adapter.py:1043-1058 through nn.MultiheadAttention), forward and backward, head width 32.
 //
 // Why.  As two batched GEMMs and a softmax the decoder's self-attention core takes 82 us forward and 237 us with its
 // backward per layer on MI355X (six score-sized tensors of 52 MB each go through HBM, the batched 900 x 32 x 900

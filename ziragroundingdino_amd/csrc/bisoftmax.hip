@@ -26,7 +26,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileFloats = 4096;  // LDS tile: rows * HT <= 4096 floats
+constexpr int kTileFloats = 2048;  // LDS tile: rows * HT <= 2048 floats (two tiles per block)
 constexpr float kClamp = 50000.f;
 
 __device__ __forceinline__ float clampf(float x, int clamp_lo, int clamp_hi)
@@ -64,38 +64,34 @@ __global__ __launch_bounds__(kThreads) void bis_colmax_partial(const float *__re
 }
 
 // fold partials over chunks: out[b][j] = op over chunk of part[b][chunk][j] (+ addend[b][j]);
-// op 0 = max, 1 = sum.  One block per batch element; the threads beyond the HT columns take every
-// phases-th chunk each and LDS joins them in a fixed order.
+// op 0 = max, 1 = sum.  One block per batch element and slab of kFoldCols columns: thread (column, phase) takes every
+// kFoldPhases-th chunk and LDS joins the phases in a fixed order.  (One block per batch element with a thread per column
+// read 512 partials in sequence per thread at H * T >= 128: 47 us, 16 calls per step; 32 columns per block: 14 us.)
+constexpr int kFoldCols = 8, kFoldPhases = kThreads / kFoldCols;
 __global__ __launch_bounds__(kThreads) void bis_fold(const float *__restrict__ part, int chunks, int HT,
                                                      int op, const float *__restrict__ addend,
                                                      float *__restrict__ out)
 {
     __shared__ float red[kThreads];
-    const int b = blockIdx.x;
-    for (int j0 = 0; j0 < HT; j0 += kThreads) {
-        const int cols = min(HT - j0, kThreads);
-        const int phases = kThreads / cols;
-        const int j = threadIdx.x % cols, ph = threadIdx.x / cols;
-        float acc = op ? 0.f : -INFINITY;
-        if (ph < phases) {
-            const float *p = part + (size_t)b * chunks * HT + j0 + j;
-            for (int c = ph; c < chunks; c += phases) {
-                const float v = p[(size_t)c * HT];
-                acc = op ? acc + v : fmaxf(acc, v);
-            }
+    const int b = blockIdx.x, j = blockIdx.y * kFoldCols + threadIdx.x % kFoldCols, ph = threadIdx.x / kFoldCols;
+    float acc = op ? 0.f : -INFINITY;
+    if (j < HT) {
+        const float *p = part + (size_t)b * chunks * HT + j;
+        for (int c = ph; c < chunks; c += kFoldPhases) {
+            const float v = p[(size_t)c * HT];
+            acc = op ? acc + v : fmaxf(acc, v);
         }
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (threadIdx.x < cols) {
-            for (int q = 1; q < phases; ++q) {
-                const float v = red[q * cols + threadIdx.x];
-                acc = op ? acc + v : fmaxf(acc, v);
-            }
-            const int i = b * HT + j0 + threadIdx.x;
-            if (addend) acc += addend[i];
-            out[i] = acc;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ph == 0 && j < HT) {
+        for (int q = 1; q < kFoldPhases; ++q) {
+            const float v = red[q * kFoldCols + threadIdx.x];
+            acc = op ? acc + v : fmaxf(acc, v);
         }
-        __syncthreads();
+        const int i = b * HT + j;
+        if (addend) acc += addend[i];
+        out[i] = acc;
     }
 }
 
@@ -114,7 +110,10 @@ __global__ __launch_bounds__(kThreads) void bis_global_max(const float *__restri
     if (threadIdx.x == 0) gmax[0] = red[0];
 }
 
-// rows: p_v, e and the partial column sums of e
+// rows: p_v, e and the partial column sums of e.  All global traffic is whole-tile and coalesced; the softmax over the T
+// text tokens of a (row, head) is one thread's walk through LDS, each thread starting at another token (rh % T) so that
+// the lanes of a wave hit different banks whatever T is (with T = 32 and every thread starting at token 0, the 64 lanes
+// of a wave shared two banks: 85 us for a 136 MB pass).
 __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
     const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
     const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l /* [B,T] or null */,
@@ -122,54 +121,79 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
     int stable, int clamp_lo, int clamp_hi, float *__restrict__ pv, float *__restrict__ e,
     float *__restrict__ part_sum)
 {
-    extern __shared__ float tile[];  // [rows][HT]: x1, then e;  then colacc[HT]
+    extern __shared__ float tile[];  // [rows][HT]: x1;  [rows][HT]: p_v, then e;  colacc[HT];  text mask [T] as floats
     const int HT = H * T;
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
-    float *colacc = tile + (size_t)rows_per_block * HT;
+    float *tile2 = tile + (size_t)rows_per_block * HT;
+    float *colacc = tile2 + (size_t)rows_per_block * HT;
+    float *live = colacc + HT;   // 1 = text token takes part, 0 = padded
     for (int j = threadIdx.x; j < HT; j += kThreads) colacc[j] = 0.f;
+    for (int t = threadIdx.x; t < T; t += kThreads) live[t] = (mask_l && mask_l[b * T + t]) ? 0.f : 1.f;
     const float g = stable ? gmax[0] : 0.f;
     const float *cb = c + (size_t)b * HT;
+    const float *cm = colmax + (size_t)b * HT;
+    const int j_first = threadIdx.x % HT, r_first = threadIdx.x / HT, j_step = kThreads % HT, r_step = kThreads / HT;
+    int G = 0;   // lanes per (row, head) group: the power of two >= T, or 0 when T > 64
+    if (T <= 64) for (G = 1; G < T; G <<= 1) {}
     const int ntiles = (N + rows_per_block - 1) / rows_per_block;
     for (int tl = chunk; tl < ntiles; tl += chunks) {
-    const int n0 = tl * rows_per_block, rows = min(rows_per_block, N - n0);
-    const float *xb = xm + ((size_t)b * N + n0) * HT;
-    __syncthreads();
-    for (int i = threadIdx.x; i < rows * HT; i += kThreads)
-        tile[i] = clampf(xb[i] + cb[i % HT] - g, clamp_lo, clamp_hi);  // x1
-    __syncthreads();
-    // one (row, head) per thread: softmax over the T text tokens
-    float *pvb = pv + ((size_t)b * N + n0) * HT;
-    for (int rh = threadIdx.x; rh < rows * H; rh += kThreads) {
-        const int r = rh / H, h = rh - r * H;
-        const float *x1 = tile + r * HT + h * T;
-        float m = -INFINITY;
-        for (int t = 0; t < T; ++t)
-            if (!mask_l || !mask_l[b * T + t]) m = fmaxf(m, x1[t]);
-        float s = 0.f;
-        for (int t = 0; t < T; ++t)
-            if (!mask_l || !mask_l[b * T + t]) s += expf(x1[t] - m);
-        const float inv = 1.f / s;  // all text tokens masked: 0 * inf = nan, as torch.softmax of all -inf
-        float *o = pvb + (size_t)r * HT + h * T;
-        for (int t = 0; t < T; ++t) o[t] = (!mask_l || !mask_l[b * T + t]) ? expf(x1[t] - m) * inv : 0.f;
-    }
-    __syncthreads();
-    // e = exp(clamp(x1 - colmax1)), 0 on padded image tokens
-    const float *cm = colmax + (size_t)b * HT;
-    float *eb = e + ((size_t)b * N + n0) * HT;
-    for (int i = threadIdx.x; i < rows * HT; i += kThreads) {
-        const int r = i / HT, j = i - r * HT;
-        const float cm1 = clampf(cm[j] - g, clamp_lo, clamp_hi);  // max_n x1 (clamp is monotone)
-        float v = expf(clampf(tile[i] - cm1, clamp_lo, clamp_hi));
-        if (mask_v && mask_v[(size_t)b * N + n0 + r]) v = 0.f;
-        tile[i] = v;
-        eb[i] = v;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < HT; j += kThreads) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += tile[r * HT + j];
-        colacc[j] += s;
-    }
+        const int n0 = tl * rows_per_block, rows = min(rows_per_block, N - n0);
+        const size_t base = ((size_t)b * N + n0) * HT;
+        __syncthreads();
+        // (column / row of element i without a division per element: i advances by kThreads)
+        for (int i = threadIdx.x, j = j_first; i < rows * HT; i += kThreads, j = j + j_step >= HT ? j + j_step - HT : j + j_step)
+            tile[i] = clampf(xm[base + i] + cb[j] - g, clamp_lo, clamp_hi);  // x1
+        __syncthreads();
+        // softmax over the T text tokens of a (row, head): a group of G >= T lanes with wave reductions for T <= 64 ...
+        if (G) {
+            const int lane_t = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = kThreads / G;
+            const bool on = lane_t < T && live[lane_t < T ? lane_t : 0] != 0.f;
+            for (int rh0 = 0; rh0 < rows * H; rh0 += ngrp) {   // (whole waves stay in the loop: the reductions are wave-wide)
+                const int rh = rh0 + grp;
+                const bool in = rh < rows * H && lane_t < T;
+                const int idx = in ? (rh / H) * HT + (rh % H) * T + lane_t : 0;
+                const float x = (in && on) ? tile[idx] : -INFINITY;
+                float m = x;
+                for (int d = 1; d < G; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+                const float ex = (in && on) ? expf(x - m) : 0.f;
+                float sum = ex;
+                for (int d = 1; d < G; d <<= 1) sum += __shfl_xor(sum, d);
+                if (in) tile2[idx] = on ? ex * (1.f / sum) : 0.f;   // all text tokens masked: 0 * inf = nan, as torch.softmax of all -inf
+            }
+        } else
+        // ... or one thread's walk for longer texts
+        for (int rh = threadIdx.x; rh < rows * H; rh += kThreads) {
+            const int r = rh / H, h = rh - r * H, t0 = rh % T;
+            const float *x1 = tile + r * HT + h * T;
+            float m = -INFINITY;
+            for (int k = 0, t = t0; k < T; ++k, t = t + 1 == T ? 0 : t + 1)
+                if (live[t] != 0.f) m = fmaxf(m, x1[t]);
+            float s = 0.f;
+            for (int k = 0, t = t0; k < T; ++k, t = t + 1 == T ? 0 : t + 1)
+                if (live[t] != 0.f) s += expf(x1[t] - m);
+            const float inv = 1.f / s;  // all text tokens masked: 0 * inf = nan, as torch.softmax of all -inf
+            float *o = tile2 + r * HT + h * T;
+            for (int k = 0, t = t0; k < T; ++k, t = t + 1 == T ? 0 : t + 1)
+                o[t] = live[t] != 0.f ? expf(x1[t] - m) * inv : 0.f;
+        }
+        __syncthreads();
+        // p_v out; e = exp(clamp(x1 - colmax1)), 0 on padded image tokens
+        for (int i = threadIdx.x, j = j_first, r = r_first; i < rows * HT; i += kThreads) {
+            pv[base + i] = tile2[i];
+            const float cm1 = clampf(cm[j] - g, clamp_lo, clamp_hi);  // max_n x1 (clamp is monotone)
+            float v = expf(clampf(tile[i] - cm1, clamp_lo, clamp_hi));
+            if (mask_v && mask_v[(size_t)b * N + n0 + r]) v = 0.f;
+            tile2[i] = v;
+            e[base + i] = v;
+            r += r_step + (j + j_step >= HT ? 1 : 0);
+            j = j + j_step >= HT ? j + j_step - HT : j + j_step;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < HT; j += kThreads) {
+            float s = 0.f;
+            for (int r = 0; r < rows; ++r) s += tile2[r * HT + j];
+            colacc[j] += s;
+        }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < HT; j += kThreads) part_sum[((size_t)b * chunks + chunk) * HT + j] = colacc[j];
@@ -182,55 +206,76 @@ __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
     const float *__restrict__ g_colsum, int N, int H, int T, int rows_per_block, int stable,
     int clamp_lo, int clamp_hi, float *__restrict__ g_xm, float *__restrict__ part_gc)
 {
-    extern __shared__ float tile[];  // [rows][HT]: gradient w.r.t. x1 from the p_v branch, then g_x; colacc[HT]
+    extern __shared__ float tile[];  // [rows][HT]: p_v, then the gradient w.r.t. x1 from the p_v branch, then g_x;  [rows][HT]: g_pv;  colacc[HT]
     const int HT = H * T;
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
-    float *colacc = tile + (size_t)rows_per_block * HT;
+    float *tile2 = tile + (size_t)rows_per_block * HT;
+    float *colacc = tile2 + (size_t)rows_per_block * HT;
     for (int j = threadIdx.x; j < HT; j += kThreads) colacc[j] = 0.f;
     const float g = stable ? gmax[0] : 0.f;
-    const int ntiles = (N + rows_per_block - 1) / rows_per_block;
-    for (int tl = chunk; tl < ntiles; tl += chunks) {
-    const int n0 = tl * rows_per_block, rows = min(rows_per_block, N - n0);
-    const size_t base = ((size_t)b * N + n0) * HT;
-    __syncthreads();
-    // softmax backward per (row, head): p * (g - <g, p>)
-    for (int rh = threadIdx.x; rh < rows * H; rh += kThreads) {
-        const int r = rh / H, h = rh - r * H;
-        const float *p = pv + base + (size_t)r * HT + h * T;
-        const float *gp = g_pv + base + (size_t)r * HT + h * T;
-        float dot = 0.f;
-        for (int t = 0; t < T; ++t) dot = fmaf(gp[t], p[t], dot);
-        float *o = tile + r * HT + h * T;
-        for (int t = 0; t < T; ++t) o[t] = p[t] * (gp[t] - dot);  // 0 on masked text tokens (p = 0)
-    }
-    __syncthreads();
     const float *cb = c + (size_t)b * HT;
     const float *cm = colmax + (size_t)b * HT;
     const float *gcs = g_colsum + (size_t)b * HT;
-    for (int i = threadIdx.x; i < rows * HT; i += kThreads) {
-        const int j = i % HT;
-        const float xs = xm[base + i] + cb[j] - g;                 // before clamp 1
-        const float x1 = clampf(xs, clamp_lo, clamp_hi);
-        const float cm1 = clampf(cm[j] - g, clamp_lo, clamp_hi);
-        const float d2 = x1 - cm1;                                 // before clamp 2
-        const bool pass2 = !((clamp_lo && d2 < -kClamp) || (clamp_hi && d2 > kClamp));
-        const bool pass1 = !((clamp_lo && xs < -kClamp) || (clamp_hi && xs > kClamp));
-        float gl = (g_e[base + i] + gcs[j]) * e[base + i];         // through exp (e = 0 on padded image tokens)
-        if (!pass2) gl = 0.f;
-        float gx = tile[i] + gl;
-        if (!pass1) gx = 0.f;
-        tile[i] = gx;
-        g_xm[base + i] = gx;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < HT; j += kThreads) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += tile[r * HT + j];
-        colacc[j] += s;
-    }
+    const int j_first = threadIdx.x % HT, j_step = kThreads % HT;
+    int G = 0;   // lanes per (row, head) group: the power of two >= T, or 0 when T > 64
+    if (T <= 64) for (G = 1; G < T; G <<= 1) {}
+    const int ntiles = (N + rows_per_block - 1) / rows_per_block;
+    for (int tl = chunk; tl < ntiles; tl += chunks) {
+        const int n0 = tl * rows_per_block, rows = min(rows_per_block, N - n0);
+        const size_t base = ((size_t)b * N + n0) * HT;
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * HT; i += kThreads) {
+            tile[i] = pv[base + i];
+            tile2[i] = g_pv[base + i];
+        }
+        __syncthreads();
+        // softmax backward per (row, head): p * (g - <g, p>): a lane group per (row, head) for T <= 64 ...
+        if (G) {
+            const int lane_t = threadIdx.x & (G - 1), grp = threadIdx.x / G, ngrp = kThreads / G;
+            for (int rh0 = 0; rh0 < rows * H; rh0 += ngrp) {
+                const int rh = rh0 + grp;
+                const bool in = rh < rows * H && lane_t < T;
+                const int idx = in ? (rh / H) * HT + (rh % H) * T + lane_t : 0;
+                const float pp = in ? tile[idx] : 0.f, gg = in ? tile2[idx] : 0.f;
+                float dot = pp * gg;
+                for (int d = 1; d < G; d <<= 1) dot += __shfl_xor(dot, d);
+                if (in) tile[idx] = pp * (gg - dot);   // 0 on masked text tokens (p = 0)
+            }
+        } else
+        // ... or one thread's walk, the threads starting at different tokens (see bis_rows_fwd)
+        for (int rh = threadIdx.x; rh < rows * H; rh += kThreads) {
+            const int r = rh / H, h = rh - r * H, t0 = rh % T;
+            float *p = tile + r * HT + h * T;
+            const float *gp = tile2 + r * HT + h * T;
+            float dot = 0.f;
+            for (int k = 0, t = t0; k < T; ++k, t = t + 1 == T ? 0 : t + 1) dot = fmaf(gp[t], p[t], dot);
+            for (int k = 0, t = t0; k < T; ++k, t = t + 1 == T ? 0 : t + 1) p[t] = p[t] * (gp[t] - dot);  // 0 on masked text tokens (p = 0)
+        }
+        __syncthreads();
+        for (int i = threadIdx.x, j = j_first; i < rows * HT; i += kThreads, j = j + j_step >= HT ? j + j_step - HT : j + j_step) {
+            const float xs = xm[base + i] + cb[j] - g;                 // before clamp 1
+            const float x1 = clampf(xs, clamp_lo, clamp_hi);
+            const float cm1 = clampf(cm[j] - g, clamp_lo, clamp_hi);
+            const float d2 = x1 - cm1;                                 // before clamp 2
+            const bool pass2 = !((clamp_lo && d2 < -kClamp) || (clamp_hi && d2 > kClamp));
+            const bool pass1 = !((clamp_lo && xs < -kClamp) || (clamp_hi && xs > kClamp));
+            float gl = (g_e[base + i] + gcs[j]) * e[base + i];         // through exp (e = 0 on padded image tokens)
+            if (!pass2) gl = 0.f;
+            float gx = tile[i] + gl;
+            if (!pass1) gx = 0.f;
+            tile[i] = gx;
+            g_xm[base + i] = gx;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < HT; j += kThreads) {
+            float s = 0.f;
+            for (int r = 0; r < rows; ++r) s += tile[r * HT + j];
+            colacc[j] += s;
+        }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < HT; j += kThreads) part_gc[((size_t)b * chunks + chunk) * HT + j] = colacc[j];
+    (void)mask_l;
 }
 
 inline int rows_per_block(int HT)
@@ -238,7 +283,7 @@ inline int rows_per_block(int HT)
     int r = kTileFloats / HT;
     return r < 1 ? 1 : (r > 64 ? 64 : r);
 }
-inline int colmax_chunks(int N) { int c = (N + 255) / 256; return c > 128 ? 128 : (c < 1 ? 1 : c); }
+inline int colmax_chunks(int N) { int c = (N + 63) / 64; return c > 512 ? 512 : (c < 1 ? 1 : c); }   // (87 chunks of 256 rows: 174 blocks, 24 us for 23 MB)
 // row kernels: at most kMaxRowBlocks blocks per batch element, each striding over the row tiles
 constexpr int kMaxRowBlocks = 512;
 inline int row_blocks(int N, int HT)
@@ -273,12 +318,12 @@ int zira_bisoftmax_fwd_f32(const float *xm, const float *c, const uint8_t *mask_
     (void)total;
     const int cchunks = colmax_chunks(N), crow = (N + cchunks - 1) / cchunks;
     hipLaunchKernelGGL(bis_colmax_partial, dim3(cchunks, B), dim3(kThreads), 0, st, xm, N, HT, crow, workspace);
-    hipLaunchKernelGGL(bis_fold, dim3(B), dim3(kThreads), 0, st, workspace, cchunks, HT, 0, c, colmax);
+    hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, cchunks, HT, 0, c, colmax);
     hipLaunchKernelGGL(bis_global_max, dim3(1), dim3(kThreads), 0, st, colmax, total, gmax);
     const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
-    hipLaunchKernelGGL(bis_rows_fwd, dim3(rchunks, B), dim3(kThreads), ((size_t)R + 1) * HT * sizeof(float), st,
+    hipLaunchKernelGGL(bis_rows_fwd, dim3(rchunks, B), dim3(kThreads), (((size_t)2 * R + 1) * HT + T) * sizeof(float), st,
                        xm, c, colmax, gmax, mask_l, mask_v, N, H, T, R, stable, clamp_lo, clamp_hi, pv, e, workspace);
-    hipLaunchKernelGGL(bis_fold, dim3(B), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
+    hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
                        (const float *)nullptr, colsum);
     return (int)hipGetLastError();
 }
@@ -294,10 +339,10 @@ int zira_bisoftmax_bwd_f32(const float *xm, const float *c, const uint8_t *mask_
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int HT = H * T;
     const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
-    hipLaunchKernelGGL(bis_rows_bwd, dim3(rchunks, B), dim3(kThreads), ((size_t)R + 1) * HT * sizeof(float), st,
+    hipLaunchKernelGGL(bis_rows_bwd, dim3(rchunks, B), dim3(kThreads), ((size_t)2 * R + 1) * HT * sizeof(float), st,
                        xm, c, colmax, gmax, mask_l, pv, e, g_pv, g_e, g_colsum, N, H, T, R, stable, clamp_lo,
                        clamp_hi, g_xm, workspace);
-    hipLaunchKernelGGL(bis_fold, dim3(B), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
+    hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
                        (const float *)nullptr, g_c);
     return (int)hipGetLastError();
 }

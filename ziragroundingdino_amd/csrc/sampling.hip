@@ -1,7 +1,7 @@
 // sampling.hip -- what the MSDA module does between its query projection and the native op, in one launch each way
 // (C ABI: zira_msda_sampling_fwd_f32 / zira_msda_sampling_bwd_f32).
 //
-// Reference: MultiScaleDeformableAttention.forward, groundingdino/models/GroundingDINO/ms_deform_attn.py:295-325:
+// Reference: MultiScaleDeformableAttention.forward, groundingdino/models/GroundingDINO/ms_deform_attn.py:290-325:
 //   sampling_offsets(query).view(B, Q, M, L, P, 2); attention_weights(query).view(B, Q, M, L * P).softmax(-1);
 //   reference_points [.., 2]:  loc = ref[:, :, None, :, None, :] + offsets / (W_l, H_l)
 //   reference_points [.., 4]:  loc = ref_xy + offsets / P * ref_wh * 0.5

@@ -201,7 +201,7 @@ def _bis_workspace(lib, dev, B, N, H, T):
 
 
 def bi_softmax_supported(xm, H, T, dropout_active):
-    return (xm.is_cuda and xm.dtype == torch.float32 and not dropout_active and H * T <= 4096
+    return (xm.is_cuda and xm.dtype == torch.float32 and not dropout_active and H * T <= 2048
             and not torch.is_autocast_enabled())
 
 

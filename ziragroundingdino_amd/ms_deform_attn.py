@@ -57,7 +57,7 @@ FUSED_LOCATIONS = True   # module-level switch for A/B runs
 
 class _SamplingPlan(Function):
     """softmax of the attention logits + sampling locations from the ONE projection of the query (``[B, Q, 3*M*L*P]``:
-    offsets, then logits), one native launch each way (csrc/sampling.hip); reference ms_deform_attn.py:295-325.
+    offsets, then logits), one native launch each way (csrc/sampling.hip); reference ms_deform_attn.py:290-325.
     The reference points get no gradient (callers check ``requires_grad``)."""
 
     @staticmethod
