@@ -118,10 +118,10 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
     const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
     const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l /* [B,T] or null */,
     const uint8_t *__restrict__ mask_v /* [B,N] or null */, int N, int H, int T, int rows_per_block,
-    int stable, int clamp_lo, int clamp_hi, float *__restrict__ pv, float *__restrict__ e,
+    int stable, int clamp_lo, int clamp_hi, int vec, float *__restrict__ pv, float *__restrict__ e,
     float *__restrict__ part_sum)
 {
-    extern __shared__ float tile[];  // [rows][HT]: x1;  [rows][HT]: p_v, then e;  colacc[HT];  text mask [T] as floats
+    extern __shared__ __align__(16) float tile[];  // [rows][HT]: x1;  [rows][HT]: p_v, then e;  colacc[HT];  text mask [T] as floats
     const int HT = H * T;
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
     float *tile2 = tile + (size_t)rows_per_block * HT;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
     const float *cb = c + (size_t)b * HT;
     const float *cm = colmax + (size_t)b * HT;
     const int j_first = threadIdx.x % HT, r_first = threadIdx.x / HT, j_step = kThreads % HT, r_step = kThreads / HT;
+    const int j4_first = (4 * threadIdx.x) % HT, r4_first = (4 * threadIdx.x) / HT, j4_step = (4 * kThreads) % HT, r4_step = (4 * kThreads) / HT;
     int G = 0;   // lanes per (row, head) group: the power of two >= T, or 0 when T > 64
     if (T <= 64) for (G = 1; G < T; G <<= 1) {}
     const int ntiles = (N + rows_per_block - 1) / rows_per_block;
@@ -140,9 +141,19 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
         const int n0 = tl * rows_per_block, rows = min(rows_per_block, N - n0);
         const size_t base = ((size_t)b * N + n0) * HT;
         __syncthreads();
-        // (column / row of element i without a division per element: i advances by kThreads)
-        for (int i = threadIdx.x, j = j_first; i < rows * HT; i += kThreads, j = j + j_step >= HT ? j + j_step - HT : j + j_step)
-            tile[i] = clampf(xm[base + i] + cb[j] - g, clamp_lo, clamp_hi);  // x1
+        // (column / row of element i without a division per element: i advances by kThreads; 16-byte accesses when H * T is
+        // a multiple of 4 and the tensors are 16-byte aligned)
+        if (vec) {
+            for (int i = 4 * threadIdx.x, j = j4_first; i < rows * HT; i += 4 * kThreads, j = j + j4_step >= HT ? j + j4_step - HT : j + j4_step) {
+                const float4 x = *reinterpret_cast<const float4 *>(xm + base + i), cc = *reinterpret_cast<const float4 *>(cb + j);
+                *reinterpret_cast<float4 *>(tile + i) =
+                    make_float4(clampf(x.x + cc.x - g, clamp_lo, clamp_hi), clampf(x.y + cc.y - g, clamp_lo, clamp_hi),
+                                clampf(x.z + cc.z - g, clamp_lo, clamp_hi), clampf(x.w + cc.w - g, clamp_lo, clamp_hi));
+            }
+        } else {
+            for (int i = threadIdx.x, j = j_first; i < rows * HT; i += kThreads, j = j + j_step >= HT ? j + j_step - HT : j + j_step)
+                tile[i] = clampf(xm[base + i] + cb[j] - g, clamp_lo, clamp_hi);  // x1
+        }
         __syncthreads();
         // softmax over the T text tokens of a (row, head): a group of G >= T lanes with wave reductions for T <= 64 ...
         if (G) {
@@ -178,6 +189,22 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
         }
         __syncthreads();
         // p_v out; e = exp(clamp(x1 - colmax1)), 0 on padded image tokens
+        if (vec) {
+            for (int i = 4 * threadIdx.x, j = j4_first, r = r4_first; i < rows * HT; i += 4 * kThreads) {
+                *reinterpret_cast<float4 *>(pv + base + i) = *reinterpret_cast<const float4 *>(tile2 + i);
+                const float4 x = *reinterpret_cast<const float4 *>(tile + i), cc = *reinterpret_cast<const float4 *>(cm + j);
+                const bool dead = mask_v && mask_v[(size_t)b * N + n0 + r];
+                float4 v;
+                v.x = dead ? 0.f : expf(clampf(x.x - clampf(cc.x - g, clamp_lo, clamp_hi), clamp_lo, clamp_hi));
+                v.y = dead ? 0.f : expf(clampf(x.y - clampf(cc.y - g, clamp_lo, clamp_hi), clamp_lo, clamp_hi));
+                v.z = dead ? 0.f : expf(clampf(x.z - clampf(cc.z - g, clamp_lo, clamp_hi), clamp_lo, clamp_hi));
+                v.w = dead ? 0.f : expf(clampf(x.w - clampf(cc.w - g, clamp_lo, clamp_hi), clamp_lo, clamp_hi));
+                *reinterpret_cast<float4 *>(tile2 + i) = v;
+                *reinterpret_cast<float4 *>(e + base + i) = v;
+                r += r4_step + (j + j4_step >= HT ? 1 : 0);
+                j = j + j4_step >= HT ? j + j4_step - HT : j + j4_step;
+            }
+        } else
         for (int i = threadIdx.x, j = j_first, r = r_first; i < rows * HT; i += kThreads) {
             pv[base + i] = tile2[i];
             const float cm1 = clampf(cm[j] - g, clamp_lo, clamp_hi);  // max_n x1 (clamp is monotone)
@@ -204,9 +231,9 @@ __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
     const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l, const float *__restrict__ pv,
     const float *__restrict__ e, const float *__restrict__ g_pv, const float *__restrict__ g_e,
     const float *__restrict__ g_colsum, int N, int H, int T, int rows_per_block, int stable,
-    int clamp_lo, int clamp_hi, float *__restrict__ g_xm, float *__restrict__ part_gc)
+    int clamp_lo, int clamp_hi, int vec, float *__restrict__ g_xm, float *__restrict__ part_gc)
 {
-    extern __shared__ float tile[];  // [rows][HT]: p_v, then the gradient w.r.t. x1 from the p_v branch, then g_x;  [rows][HT]: g_pv;  colacc[HT]
+    extern __shared__ __align__(16) float tile[];  // [rows][HT]: p_v, then the gradient w.r.t. x1 from the p_v branch, then g_x;  [rows][HT]: g_pv;  colacc[HT]
     const int HT = H * T;
     const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
     float *tile2 = tile + (size_t)rows_per_block * HT;
@@ -217,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
     const float *cm = colmax + (size_t)b * HT;
     const float *gcs = g_colsum + (size_t)b * HT;
     const int j_first = threadIdx.x % HT, j_step = kThreads % HT;
+    const int j4_first = (4 * threadIdx.x) % HT, j4_step = (4 * kThreads) % HT;
     int G = 0;   // lanes per (row, head) group: the power of two >= T, or 0 when T > 64
     if (T <= 64) for (G = 1; G < T; G <<= 1) {}
     const int ntiles = (N + rows_per_block - 1) / rows_per_block;
@@ -224,9 +252,16 @@ __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
         const int n0 = tl * rows_per_block, rows = min(rows_per_block, N - n0);
         const size_t base = ((size_t)b * N + n0) * HT;
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * HT; i += kThreads) {
-            tile[i] = pv[base + i];
-            tile2[i] = g_pv[base + i];
+        if (vec) {
+            for (int i = 4 * threadIdx.x; i < rows * HT; i += 4 * kThreads) {
+                *reinterpret_cast<float4 *>(tile + i) = *reinterpret_cast<const float4 *>(pv + base + i);
+                *reinterpret_cast<float4 *>(tile2 + i) = *reinterpret_cast<const float4 *>(g_pv + base + i);
+            }
+        } else {
+            for (int i = threadIdx.x; i < rows * HT; i += kThreads) {
+                tile[i] = pv[base + i];
+                tile2[i] = g_pv[base + i];
+            }
         }
         __syncthreads();
         // softmax backward per (row, head): p * (g - <g, p>): a lane group per (row, head) for T <= 64 ...
@@ -252,17 +287,33 @@ __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
             for (int k = 0, t = t0; k < T; ++k, t = t + 1 == T ? 0 : t + 1) p[t] = p[t] * (gp[t] - dot);  // 0 on masked text tokens (p = 0)
         }
         __syncthreads();
-        for (int i = threadIdx.x, j = j_first; i < rows * HT; i += kThreads, j = j + j_step >= HT ? j + j_step - HT : j + j_step) {
-            const float xs = xm[base + i] + cb[j] - g;                 // before clamp 1
+        auto grad_x = [&](float xmv, float cbv, float cmv, float gev, float gcv, float ev, float gpv) {
+            const float xs = xmv + cbv - g;                            // before clamp 1
             const float x1 = clampf(xs, clamp_lo, clamp_hi);
-            const float cm1 = clampf(cm[j] - g, clamp_lo, clamp_hi);
+            const float cm1 = clampf(cmv - g, clamp_lo, clamp_hi);
             const float d2 = x1 - cm1;                                 // before clamp 2
             const bool pass2 = !((clamp_lo && d2 < -kClamp) || (clamp_hi && d2 > kClamp));
             const bool pass1 = !((clamp_lo && xs < -kClamp) || (clamp_hi && xs > kClamp));
-            float gl = (g_e[base + i] + gcs[j]) * e[base + i];         // through exp (e = 0 on padded image tokens)
+            float gl = (gev + gcv) * ev;                               // through exp (e = 0 on padded image tokens)
             if (!pass2) gl = 0.f;
-            float gx = tile[i] + gl;
+            float gx = gpv + gl;
             if (!pass1) gx = 0.f;
+            return gx;
+        };
+        if (vec) {
+            for (int i = 4 * threadIdx.x, j = j4_first; i < rows * HT; i += 4 * kThreads, j = j + j4_step >= HT ? j + j4_step - HT : j + j4_step) {
+                const float4 x = *reinterpret_cast<const float4 *>(xm + base + i), ge = *reinterpret_cast<const float4 *>(g_e + base + i);
+                const float4 ev = *reinterpret_cast<const float4 *>(e + base + i), gp = *reinterpret_cast<const float4 *>(tile + i);
+                const float4 c4 = *reinterpret_cast<const float4 *>(cb + j), m4 = *reinterpret_cast<const float4 *>(cm + j);
+                const float4 s4 = *reinterpret_cast<const float4 *>(gcs + j);
+                const float4 o = make_float4(grad_x(x.x, c4.x, m4.x, ge.x, s4.x, ev.x, gp.x), grad_x(x.y, c4.y, m4.y, ge.y, s4.y, ev.y, gp.y),
+                                             grad_x(x.z, c4.z, m4.z, ge.z, s4.z, ev.z, gp.z), grad_x(x.w, c4.w, m4.w, ge.w, s4.w, ev.w, gp.w));
+                *reinterpret_cast<float4 *>(tile + i) = o;
+                *reinterpret_cast<float4 *>(g_xm + base + i) = o;
+            }
+        } else
+        for (int i = threadIdx.x, j = j_first; i < rows * HT; i += kThreads, j = j + j_step >= HT ? j + j_step - HT : j + j_step) {
+            const float gx = grad_x(xm[base + i], cb[j], cm[j], g_e[base + i], gcs[j], e[base + i], tile[i]);
             tile[i] = gx;
             g_xm[base + i] = gx;
         }
@@ -321,8 +372,9 @@ int zira_bisoftmax_fwd_f32(const float *xm, const float *c, const uint8_t *mask_
     hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, cchunks, HT, 0, c, colmax);
     hipLaunchKernelGGL(bis_global_max, dim3(1), dim3(kThreads), 0, st, colmax, total, gmax);
     const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
+    const int vec = (HT % 4 == 0) && !(((uintptr_t)xm | (uintptr_t)c | (uintptr_t)colmax | (uintptr_t)pv | (uintptr_t)e) & 15);
     hipLaunchKernelGGL(bis_rows_fwd, dim3(rchunks, B), dim3(kThreads), (((size_t)2 * R + 1) * HT + T) * sizeof(float), st,
-                       xm, c, colmax, gmax, mask_l, mask_v, N, H, T, R, stable, clamp_lo, clamp_hi, pv, e, workspace);
+                       xm, c, colmax, gmax, mask_l, mask_v, N, H, T, R, stable, clamp_lo, clamp_hi, vec, pv, e, workspace);
     hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
                        (const float *)nullptr, colsum);
     return (int)hipGetLastError();
@@ -339,9 +391,11 @@ int zira_bisoftmax_bwd_f32(const float *xm, const float *c, const uint8_t *mask_
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int HT = H * T;
     const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
+    const int vec = (HT % 4 == 0) && !(((uintptr_t)xm | (uintptr_t)c | (uintptr_t)colmax | (uintptr_t)pv | (uintptr_t)e | (uintptr_t)g_pv |
+                                        (uintptr_t)g_e | (uintptr_t)g_colsum | (uintptr_t)g_xm) & 15);
     hipLaunchKernelGGL(bis_rows_bwd, dim3(rchunks, B), dim3(kThreads), ((size_t)2 * R + 1) * HT * sizeof(float), st,
                        xm, c, colmax, gmax, mask_l, pv, e, g_pv, g_e, g_colsum, N, H, T, R, stable, clamp_lo,
-                       clamp_hi, g_xm, workspace);
+                       clamp_hi, vec, g_xm, workspace);
     hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
                        (const float *)nullptr, g_c);
     return (int)hipGetLastError();

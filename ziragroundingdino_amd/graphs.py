@@ -163,9 +163,26 @@ class _DecoderPiece(torch.nn.Module):
         return (*hs, *refs)
 
 
-def _graph(mod, args):
-    sample = tuple(x.detach().clone().requires_grad_(x.requires_grad) for x in args)
+def _graph(mod, args, shared=()):
+    """Graph ``mod`` on copies of ``args``; the tensors listed in ``shared`` become static inputs AS THEY ARE (a replay
+    skips the copy of an argument that already is the static input: ``_shared_inputs``)."""
+    sample = tuple(x if any(x is y for y in shared) else x.detach().clone().requires_grad_(x.requires_grad) for x in args)
     return torch.cuda.make_graphed_callables(mod, sample, num_warmup_iters=3, allow_unused_input=True)
+
+
+def _shared_inputs(entry, **tensors):
+    """Per-step constants that every piece reads (the level position embedding -- 45 MB at the bench size -- reference
+    points, masks): one persistent buffer each, filled once per call and handed to all seven graphs as their static input,
+    instead of one 45 MB copy per graph and step.  Only tensors without gradient qualify."""
+    out = []
+    for name, x in tensors.items():
+        assert not x.requires_grad, name
+        buf = entry["shared"].get(name)
+        if buf is None:
+            buf = entry["shared"][name] = torch.empty_like(x)
+        buf.copy_(x)
+        out.append(buf)
+    return out
 
 
 class GraphedTransformer:
@@ -214,7 +231,12 @@ class GraphedTransformer:
 
         entry = self._cache.get(key)
         if entry is None:
-            entry = self._cache[key] = {"layers": [], "fusion": [], "decode": None}
+            entry = self._cache[key] = {"layers": [], "fusion": [], "decode": None, "shared": {}}
+        shared = ()
+        if not lvl_pos.requires_grad and not reference_points.requires_grad and not pos_text.requires_grad:
+            shared = _shared_inputs(entry, lvl_pos=lvl_pos, reference_points=reference_points, mask_flat=mask_flat,
+                                    text_attention_mask=text_attention_mask, pos_text=pos_text, tsm=tsm)
+            lvl_pos, reference_points, mask_flat, text_attention_mask, pos_text, tsm = shared
         output = src
         for i in range(len(enc.layers)):
             if enc.fusion_layers and self.graph_fusion:   # one graph pair per block (developer switch)
@@ -230,7 +252,7 @@ class GraphedTransformer:
                     pos_text, tsm)
             if len(entry["layers"]) <= i:
                 piece = _EncoderLayerPiece(enc, i, spatial_shapes, level_start_index, no_padding)
-                entry["layers"].append(_graph(piece, args) if self.graph_encoder else piece)
+                entry["layers"].append(_graph(piece, args, shared) if self.graph_encoder else piece)
             output, memory_text = entry["layers"][i](*args)
         text_dict["encoded_text"] = memory_text
 
@@ -240,14 +262,14 @@ class GraphedTransformer:
                     text_dict["text_token_mask"])
             if entry["decode"] is None:
                 piece = _DecoderPiece(t, spatial_shapes, level_start_index, no_padding)
-                entry["decode"] = (_graph(piece, args) if self.graph_decoder else piece, piece)
+                entry["decode"] = (_graph(piece, args, shared) if self.graph_decoder else piece, piece)
             graphed, piece = entry["decode"]
             out = graphed(*args)
             return list(out[:piece.n_hs]), list(out[piece.n_hs:]), hs_enc, ref_enc, init_box
         args = (output, memory_text, mask_flat, lvl_pos, valid_ratios, text_dict["text_token_mask"])
         if entry["decode"] is None:
             piece = _SelectDecodePiece(t, shapes, spatial_shapes, level_start_index, no_padding)
-            entry["decode"] = (_graph(piece, args) if self.graph_decoder else piece, piece)
+            entry["decode"] = (_graph(piece, args, shared) if self.graph_decoder else piece, piece)
         graphed, piece = entry["decode"]
         out = graphed(*args)
         nh, nr = piece.n_hs, piece.n_refs
