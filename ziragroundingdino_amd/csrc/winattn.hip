@@ -31,6 +31,7 @@ __device__ __forceinline__ int region(int x, int Xp, int ws, int shift)
     return x < Xp - ws ? 0 : (x < Xp - shift ? 1 : 2);
 }
 
+template <int kChunk>   // 7: 7 x 7 windows, a window row of keys per softmax step; 0: any window up to 16 x 16, a key per step
 __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ qkv_bias,
                                                           const float *__restrict__ bias_t, int B, int H, int W, int heads,
                                                           int ws, int shift, float scale, int nitems, int lds_per_wave,
@@ -85,6 +86,48 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
             o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
         }
         float m = -INFINITY, l = 0.f;
+        if (kChunk > 0) {
+            // Online softmax a window row (kChunk keys) at a time: the accumulator is rescaled once per chunk instead of once
+            // per key (o * corr + p * v is two instructions per output pair), and a dot product runs on two packed
+            // accumulators instead of one 32-long dependent chain.
+            for (int j0 = 0; j0 < N; j0 += kChunk) {
+                float sc[kChunk > 0 ? kChunk : 1];
+                float mc = m;
+#pragma unroll
+                for (int jj = 0; jj < kChunk; ++jj) {
+                    const int j = j0 + jj;
+                    const float *kj = ks + j * kRowPad;
+                    float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int c = 0; c < kHD; c += 4) {
+                        const float4 k4 = *reinterpret_cast<const float4 *>(kj + c);
+                        a0.x = fmaf(q[c], k4.x, a0.x); a0.y = fmaf(q[c + 1], k4.y, a0.y);
+                        a1.x = fmaf(q[c + 2], k4.z, a1.x); a1.y = fmaf(q[c + 3], k4.w, a1.y);
+                    }
+                    float sj = (a0.x + a0.y) + (a1.x + a1.y) + bt[(size_t)j * N + r];
+                    if (shift && reg[j] != rid) sj -= 100.0f;
+                    sc[jj] = sj;
+                    mc = fmaxf(mc, sj);
+                }
+                const float corr = __expf(m - mc);
+                l *= corr;
+#pragma unroll
+                for (int c = 0; c < kHD; ++c) o[c] *= corr;
+#pragma unroll
+                for (int jj = 0; jj < kChunk; ++jj) {
+                    const float p = __expf(sc[jj] - mc);
+                    l += p;
+                    const float *vj = vs + (j0 + jj) * kRowPad;
+#pragma unroll
+                    for (int c = 0; c < kHD; c += 4) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(vj + c);
+                        o[c] = fmaf(p, v4.x, o[c]); o[c + 1] = fmaf(p, v4.y, o[c + 1]);
+                        o[c + 2] = fmaf(p, v4.z, o[c + 2]); o[c + 3] = fmaf(p, v4.w, o[c + 3]);
+                    }
+                }
+                m = mc;
+            }
+        } else
         for (int j = 0; j < N; ++j) {
             const float *kj = ks + j * kRowPad;
             float s = 0.f;
@@ -137,9 +180,14 @@ int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *b
     if (waves > 4) waves = 4;
     if (waves < 1) return ZIRA_MSDA_EINVAL;
     const unsigned blocks = (unsigned)((nitems + waves - 1) / waves);
-    hipLaunchKernelGGL(window_attn_kernel, dim3(blocks), dim3(waves * 64), (size_t)waves * lds_per_wave * 4,
-                       (hipStream_t)stream, qkv, qkv_bias, bias_t, B, H, W, heads, window, shift, scale, (int)nitems,
-                       lds_per_wave, out);
+    if (window == 7)
+        hipLaunchKernelGGL(window_attn_kernel<7>, dim3(blocks), dim3(waves * 64), (size_t)waves * lds_per_wave * 4,
+                           (hipStream_t)stream, qkv, qkv_bias, bias_t, B, H, W, heads, window, shift, scale, (int)nitems,
+                           lds_per_wave, out);
+    else
+        hipLaunchKernelGGL(window_attn_kernel<0>, dim3(blocks), dim3(waves * 64), (size_t)waves * lds_per_wave * 4,
+                           (hipStream_t)stream, qkv, qkv_bias, bias_t, B, H, W, heads, window, shift, scale, (int)nitems,
+                           lds_per_wave, out);
     return (int)hipGetLastError();
 }
 
