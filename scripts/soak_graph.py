@@ -18,6 +18,9 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()
 model.use_transformer_graph = True
+if os.environ.get("ZIRA_GRAPH_FUSION"):   # A/B: the fusion blocks replayed from graph pairs of their own (1) or launched eagerly (0)
+    from ziragroundingdino_amd.graphs import GraphedTransformer
+    GraphedTransformer.graph_fusion = os.environ["ZIRA_GRAPH_FUSION"] == "1"
 trainer = ZiraTrainer(model)
 batches = [synthetic_batch(2, 800, 1333, n_categories=15, seed=i, device=dev) for i in range(4)]
 t0 = time.perf_counter()

@@ -36,6 +36,7 @@ def close(a, b, tol, what):
     (37, 50, 3, 2, True, False),
     (64, 257, 1, 4, False, False),
     (5, 3, 2, 1, True, False),
+    (301, 40, 1, 4, True, False),      # few key blocks, ragged tiles: dK / dV in two query shares + ordered sum
 ])
 def test_fused_attention_matches_composition(L, S, B, H, masked, strided):
     g = torch.Generator().manual_seed(L * 131 + S)
