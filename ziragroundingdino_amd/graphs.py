@@ -233,7 +233,8 @@ class GraphedTransformer:
         if entry is None:
             entry = self._cache[key] = {"layers": [], "fusion": [], "decode": None, "shared": {}}
         shared = ()
-        if not lvl_pos.requires_grad and not reference_points.requires_grad and not pos_text.requires_grad:
+        consts = (lvl_pos, reference_points, mask_flat, text_attention_mask, pos_text, tsm)
+        if all(torch.is_tensor(x) and not x.requires_grad for x in consts):
             shared = _shared_inputs(entry, lvl_pos=lvl_pos, reference_points=reference_points, mask_flat=mask_flat,
                                     text_attention_mask=text_attention_mask, pos_text=pos_text, tsm=tsm)
             lvl_pos, reference_points, mask_flat, text_attention_mask, pos_text, tsm = shared
