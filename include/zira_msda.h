@@ -288,6 +288,13 @@ int zira_msda_sampling_fwd_f32(const float *proj, int ld, const float *ref, int 
 int zira_msda_sampling_bwd_f32(const float *grad_loc, const float *grad_attn, const float *attn, const float *ref, int R,
                                const int64_t *shapes, long long N, int M, int L, int P, float *grad_proj, int ld, void *stream);
 
+/* ---- Frozen FFN backward: GEMM with the ReLU gradient in its epilogue --------------------------
+ * C[M, N] = (A[M, K] * B[K, N]) where H[M, N] > 0, else 0 (all row-major, contiguous; N % 128 == 0, K % 16 == 0; A and B
+ * 16-byte aligned).  For linear2(relu(linear1(x))) with frozen weights (transformer_for_adapter.py:883-886, :1001-1006):
+ * A = grad of the block's output, B = linear2.weight [d_model, d_ffn], H = relu(linear1(x)) -> C = the gradient in front of
+ * the ReLU; replaces autograd's  mm + threshold_backward. */
+int zira_gemm_drelu_f32(const float *A, const float *B, const float *H, int M, int N, int K, float *C, void *stream);
+
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):
  *   pos [rows, C] (x, y[, w, h]), C = 2 or 4;  dim_t [T] = temperature^(2 (i // 2) / T);  scale = 2 pi;

@@ -157,6 +157,7 @@ class Switches:
     lean_mha = True
     small_attention = True   # lean_mha: materialised scores instead of the fused SDPA kernel for small problems
     fused_attention = True   # lean_mha: csrc/attn.hip for fp32 heads of width 32 without attention mask / dropout (the decoder's)
+    fused_ffn_backward = True  # frozen FFNs: (gy @ W2) * (h > 0) in one native GEMM (csrc/gemm_drelu.hip) instead of mm + threshold_backward
     sort_for_topk = False    # select_queries: stable sort instead of torch.topk everywhere (developer switch)
 
 
@@ -186,6 +187,41 @@ class _LinearReLU(torch.autograd.Function):
         gw = g.t() @ x if ctx.needs_input_grad[1] else None
         gb = g.sum(0) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
+
+
+class _FrozenFFN(torch.autograd.Function):
+    """linear2(relu(linear1(x))) with FROZEN weights (every ZiRa task): bias + ReLU in the first GEMM's epilogue, and in the
+    backward the product  gy @ W2  masked by  h > 0  in ONE native kernel (csrc/gemm_drelu.hip) -- the separate
+    threshold_backward pass over the [rows, d_ffn] gradient (1.1 GB of traffic per encoder layer) does not exist.
+    x [N, K], W1 [F, K], W2 [K2, F]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        h = torch._addmm_activation(b1, x, w1.t())
+        ctx.save_for_backward(w1, w2, h)
+        return torch.addmm(b2, h, w2.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        w1, w2, h = ctx.saved_tensors
+        gy = gy.contiguous()
+        g = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            rc = _lib.load().zira_gemm_drelu_f32(gy.data_ptr(), w2.data_ptr(), h.data_ptr(), h.shape[0], h.shape[1], gy.shape[1],
+                                                 g.data_ptr(), torch.cuda.current_stream(h.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_gemm_drelu_f32 failed with code %d" % rc)
+        return g @ w1, None, None, None, None
+
+
+def _frozen_ffn_ok(x, lin1, lin2):
+    """The fused backward needs frozen fp32 weights with biases, d_ffn a multiple of 128 and d_model a multiple of 16."""
+    return (Switches.fused_ffn_backward and x.is_cuda and x.dtype == torch.float32 and lin1.bias is not None
+            and lin2.bias is not None and lin1.weight.dtype == torch.float32 and lin2.weight.dtype == torch.float32
+            and not any(p.requires_grad for p in (lin1.weight, lin1.bias, lin2.weight, lin2.bias))
+            and lin1.weight.is_contiguous() and lin2.weight.is_contiguous()
+            and lin1.out_features % 128 == 0 and lin2.out_features % 16 == 0 and lin2.in_features == lin1.out_features)
 
 
 def _max_over_tokens(x: Tensor) -> Tensor:
@@ -453,8 +489,13 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward_ffn(self, src):
         if (self.fuse_bias_relu and self.activation is F.relu and src.is_cuda and src.dtype == torch.float32
                 and (self.dropout2.p == 0.0 or not self.training) and not torch.is_autocast_enabled()):
-            h = _LinearReLU.apply(src.reshape(-1, src.shape[-1]), self.linear1.weight, self.linear1.bias)
-            src2 = self.linear2(h.view(*src.shape[:-1], -1))
+            x2 = src.reshape(-1, src.shape[-1])
+            if _frozen_ffn_ok(x2, self.linear1, self.linear2):
+                src2 = _FrozenFFN.apply(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                        self.linear2.bias).view(*src.shape[:-1], -1)
+            else:
+                h = _LinearReLU.apply(x2, self.linear1.weight, self.linear1.bias)
+                src2 = self.linear2(h.view(*src.shape[:-1], -1))
         else:
             src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
         return self.norm2.add_norm(src, self.dropout3(src2)), src.new_zeros(1)   # (residual add inside the LN kernel)
@@ -517,8 +558,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
         with torch.amp.autocast("cuda", enabled=False):  # reference :1004 keeps the FFN in fp32
             if (self.fuse_bias_relu and self.activation is F.relu and tgt.is_cuda and tgt.dtype == torch.float32
                     and (getattr(self.dropout3, "p", 0.0) == 0.0 or not self.training)):
-                h = _LinearReLU.apply(tgt.reshape(-1, tgt.shape[-1]), self.linear1.weight, self.linear1.bias)
-                tgt2 = self.linear2(h.view(*tgt.shape[:-1], -1))
+                x2 = tgt.reshape(-1, tgt.shape[-1])
+                if _frozen_ffn_ok(x2, self.linear1, self.linear2):
+                    tgt2 = _FrozenFFN.apply(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                            self.linear2.bias).view(*tgt.shape[:-1], -1)
+                else:
+                    h = _LinearReLU.apply(x2, self.linear1.weight, self.linear1.bias)
+                    tgt2 = self.linear2(h.view(*tgt.shape[:-1], -1))
             else:
                 tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
         return self.norm3(tgt + self.dropout4(tgt2)), tgt.new_zeros(1)
