@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kThreads, ZIRA_GD_OCC) void gemm_nn_drelu(const flo
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         // (measured and not kept: all operand reads of the step ahead of its MFMAs, 525 against 497 us; the hand-over
-        // below in the middle of the MFMA sequence, 523-528 against 511-515 on the same box; three blocks per CU, 536)
+        // below in the middle of the MFMA sequence, 523-528 against 511-515 on the same box; three blocks per CU, 536; the
+        // tiles of the last, partial round of blocks as 128 x 64 halves in a second launch, 458 + 69 against 500 us)
         if (kt + 1 < nk) {
             stage(buf ^ 1);      // (the other buffer: last read a step ago, behind the barrier at its end)
             __syncthreads();
