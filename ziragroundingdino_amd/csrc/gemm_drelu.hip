@@ -9,7 +9,9 @@
 // No GEMM library on this stack has a ReLU-gradient epilogue (hipBLASLt: dGELU only), so the first product and the mask are
 // one kernel here: fp32 MFMA (v_mfma_f32_32x32x2_f32), 128 x 128 tiles of C per block, four waves of 64 x 64, K in steps of
 // 16 through double-buffered LDS (A transposed to [k][m] on the way in and both tiles swizzled, so that every operand read
-// is one conflict-free dword per lane), the next step's global loads in flight during the MFMAs; the epilogue reads h where it writes C.
+// is one conflict-free dword per lane), the next step's global loads in flight during the MFMAs; the epilogue reads h where it
+// writes C.  Measured at M = 44446, N = 2048, K = 256: 480-490 us (97 TF/s; rocBLAS / hipBLASLt run the bare product in 350 us, at
+// ~100 % of the MFMA cycles of the 2.05 GHz the chip holds under this load) against 350 + 190 us for mm + threshold_backward.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
