@@ -32,8 +32,8 @@ def test_frozen_ffn_backward_matches_module_chain():
     layer = T.DeformableTransformerEncoderLayer(256, 2048, 0.0, "relu", 4, 8, 4).cuda().train()
     for p in layer.parameters():
         p.requires_grad_(False)
-    x = torch.randn(2, 3001, 256, device="cuda", requires_grad=True)
-    go = torch.randn(2, 3001, 256, device="cuda")
+    x = torch.randn(2, 5001, 256, device="cuda", requires_grad=True)
+    go = torch.randn(2, 5001, 256, device="cuda")
     res = {}
     try:
         for flag in (False, True):
@@ -44,3 +44,10 @@ def test_frozen_ffn_backward_matches_module_chain():
         T.Switches.fused_ffn_backward = True
     assert torch.equal(res[True][0], res[False][0])                      # the forward is the same two GEMMs
     torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-4, atol=1e-4)
+    # ... and so is the one-node form with the residual LayerNorm (what forward_ffn takes when everything is frozen)
+    x2 = x.reshape(-1, 256)
+    assert T._frozen_ffn_norm_ok(x2, layer.linear1, layer.linear2, layer.norm2)
+    src2 = T._FrozenFFN.apply(x2, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias)
+    want = layer.norm2.add_norm(x, src2.view_as(x))
+    torch.testing.assert_close(res[True][0], want, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(res[True][1], torch.autograd.grad(want, [x], go)[0], rtol=1e-4, atol=1e-4)

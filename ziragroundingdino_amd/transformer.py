@@ -215,6 +215,56 @@ class _FrozenFFN(torch.autograd.Function):
         return g @ w1, None, None, None, None
 
 
+class _FrozenFFNNorm(torch.autograd.Function):
+    """norm(x + linear2(relu(linear1(x)))) with FROZEN FFN and LayerNorm weights: _FrozenFFN followed by the residual
+    LayerNorm kernel (dense._AddLayerNorm), as one autograd node so that the backward can add the gradient that reaches x
+    through the residual connection inside the last GEMM (``addmm`` with beta = 1) instead of in a pass of its own
+    (45 MB per tensor at the encoder shape).  x [N, K]."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, eps):
+        from . import _lib
+        h = torch._addmm_activation(b1, x, w1.t())
+        y = torch.addmm(b2, h, w2.t())
+        rows, C = x.shape
+        out, s = torch.empty_like(x), torch.empty_like(x)
+        stats = torch.empty((2, rows), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().zira_add_layernorm_fwd_f32(x.data_ptr(), y.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), rows, C,
+                                                        float(eps), s.data_ptr(), out.data_ptr(), stats[0].data_ptr(),
+                                                        stats[1].data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_add_layernorm_fwd_f32 failed with code %d" % rc)
+        ctx.save_for_backward(w1, w2, h, s, ln_w, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import _lib
+        w1, w2, h, s, ln_w, stats = ctx.saved_tensors
+        lib = _lib.load()
+        gout = gout.contiguous()
+        rows, C = s.shape
+        gs, g = torch.empty_like(s), torch.empty_like(h)
+        with torch.cuda.device(s.device):
+            st = torch.cuda.current_stream(s.device).cuda_stream
+            rc = lib.zira_layernorm_bwd_f32(gout.data_ptr(), s.data_ptr(), ln_w.data_ptr(), stats[0].data_ptr(),
+                                            stats[1].data_ptr(), rows, C, gs.data_ptr(), st)
+            if rc == 0:   # gs: the gradient of x + ffn(x), i.e. of the FFN output and of x through the residual connection
+                rc = lib.zira_gemm_drelu_f32(gs.data_ptr(), w2.data_ptr(), h.data_ptr(), rows, h.shape[1], C, g.data_ptr(), st)
+        if rc != 0:
+            raise RuntimeError("frozen FFN + LayerNorm backward failed with code %d" % rc)
+        return (torch.addmm(gs, g, w1),) + (None,) * 7
+
+
+def _frozen_ffn_norm_ok(x, lin1, lin2, norm):
+    from .dense import layer_norm_supported
+    return (_frozen_ffn_ok(x, lin1, lin2) and isinstance(norm, LayerNorm) and norm.fused and LayerNorm.fused_residual
+            and LayerNorm.fused_backward and norm.weight is not None and norm.bias is not None
+            and not norm.weight.requires_grad and not norm.bias.requires_grad and x.is_contiguous()
+            and layer_norm_supported(x, tuple(norm.normalized_shape), norm.weight, norm.bias))
+
+
 def _frozen_ffn_ok(x, lin1, lin2):
     """The fused backward needs frozen fp32 weights with biases, d_ffn a multiple of 128 and d_model a multiple of 16."""
     return (Switches.fused_ffn_backward and x.is_cuda and x.dtype == torch.float32 and lin1.bias is not None
@@ -490,6 +540,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
         if (self.fuse_bias_relu and self.activation is F.relu and src.is_cuda and src.dtype == torch.float32
                 and (self.dropout2.p == 0.0 or not self.training) and not torch.is_autocast_enabled()):
             x2 = src.reshape(-1, src.shape[-1])
+            if self.dropout3.p == 0.0 and _frozen_ffn_norm_ok(x2, self.linear1, self.linear2, self.norm2):
+                return _FrozenFFNNorm.apply(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                            self.norm2.weight, self.norm2.bias, self.norm2.eps).view_as(src), src.new_zeros(1)
             if _frozen_ffn_ok(x2, self.linear1, self.linear2):
                 src2 = _FrozenFFN.apply(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight,
                                         self.linear2.bias).view(*src.shape[:-1], -1)
