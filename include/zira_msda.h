@@ -69,13 +69,12 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
  * corner rows per sample are summed in LDS in 64-bit fixed point (scale per (image, head) from max|grad_out| *
  * max|attn| of that head: the sums are exact and grad_value is identical from run to run; non-finite gradients fall
  * back to a float walk of the same tiles), for D = 16 / 64 the tiles are walked with the window's accumulators in
- * registers.  Sparse calls (decoder cross-attention) with D = 32, P <= 4 take "plan + tile accumulate"
- * (csrc/msda_tiles.hip): a plan kernel bins the samples per 16 x 8-pixel tile into 16-byte records and cuts busy
- * tiles by record count, a persistent kernel sums each tile in LDS in double (ds_add_f64: no cost for pile-ups on a
- * few pixels, inf / NaN propagate) and writes it once; shares of cut tiles meet through fp32 atomics.  Other sparse
- * calls keep the round-2 entry sort (per-block counting sort of corner contributions, per-tile row sums).
- * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (15.6 MB at
- * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, a few MB are touched; 496 MB at Q=S), or 0 when
+ * registers.  Sparse calls (decoder cross-attention) with D = 32 take "plan + tile accumulate" (csrc/msda_tiles.hip,
+ * see the planned entry points below): without a plan from the forward pass this call plans first, the workspace being
+ * the plan buffer.  Other sparse calls keep the round-2 entry sort (per-block counting sort of corner contributions,
+ * per-tile row sums).
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (34 MB at
+ * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, about a third is touched; 496 MB at Q=S), or 0 when
  * no workspace path applies (the plain entry point is then the only one).  The workspace is caller-owned DEVICE
  * memory, 16-byte aligned, needs no initialisation and may be reused by later calls on the same stream; with
  * workspace == NULL or too small the call degrades to zira_msda_bwd_f32.  Every element of grad_value,
@@ -91,6 +90,39 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
                          const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
                          float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* Planned backward for sparse calls (decoder cross-attention: B*M*Q < 65536, D = 32).  How the backward's work is cut
+ * -- which samples add to which 16 x 8-pixel tile of grad_value, which tiles are split, which CU takes which tile --
+ * depends on spatial_shapes / level_start_index / sampling_loc only, all of which exist in the FORWARD pass
+ * (reference ms_deform_attn.py:50: the autograd Function saves them there).  So the planning is a call of its own:
+ *
+ *   zira_msda_plan_bytes      size of the plan buffer for these dimensions on the current device (0: no planned path;
+ *                             use zira_msda_bwd_f32_ws)
+ *   zira_msda_plan_f32        enqueue the planning kernel on `stream`: writes the plan (records sorted by tile, work
+ *                             items, a balanced schedule) into the caller's DEVICE buffer; reads no value / attention
+ *                             data, so a binding can run it on a second stream beside zira_msda_fwd_f32 (~13 us on 64
+ *                             CUs at the north-star shape) and keep the buffer with the tensors saved for backward
+ *   zira_msda_fwd_plan_f32    convenience: forward, then the plan, on one stream
+ *   zira_msda_bwd_planned_f32 the backward from a plan: a small launch that zeroes the split tiles + the accumulate
+ *                             kernel.  `plan` must come from zira_msda_plan_* for the same dimensions, level tables and
+ *                             sampling_loc (those three arguments are not read again); it is only read and may serve
+ *                             several backward calls.  Same outputs / contract as zira_msda_bwd_f32_ws.
+ * The plan buffer needs no initialisation, 16-byte alignment, and must not be written by anyone else between the
+ * plan and the last backward that uses it. */
+size_t zira_msda_plan_bytes(int B, int S, int M, int D, int L, int Q, int P);
+
+int zira_msda_plan_f32(const int64_t *spatial_shapes, const int64_t *level_start_index, const float *sampling_loc,
+                       int B, int S, int M, int D, int L, int Q, int P, void *plan, size_t plan_bytes, void *stream);
+
+int zira_msda_fwd_plan_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                           const float *sampling_loc, const float *attn_weight, int B, int S, int M, int D, int L,
+                           int Q, int P, float *out, void *plan, size_t plan_bytes, void *stream);
+
+int zira_msda_bwd_planned_f32(const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start_index, const float *sampling_loc,
+                              const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
+                              float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
+                              const void *plan, size_t plan_bytes, void *stream);
 
 /* float64 twins: the reference dispatches AT_DISPATCH_FLOATING_TYPES = {float, double}
  * (ms_deform_attn_cuda.cu:65, :135). */

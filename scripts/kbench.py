@@ -69,7 +69,22 @@ def main():
         print("%-18s fwd med %8.2f us (min %8.2f) %7.0f GB/s | bwd med %8.2f us (min %8.2f) %7.0f GB/s"
               % (name, np.median(tf), min(tf), fb / np.median(tf) / 1e3,
                  np.median(tb), min(tb), bb / np.median(tb) / 1e3), flush=True)
-
+        plan = _C.ms_deform_attn_plan(v, sh, st, loc, 64)
+        if plan is not None:   # sparse calls: the plan made right behind the forward gather, the backward from the plan
+            fwdp = lambda: (_C.ms_deform_attn_forward(v, sh, st, loc, attn, 64), _C.ms_deform_attn_plan(v, sh, st, loc, 64))
+            bwdp = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64, plan=plan)
+            planonly = lambda: _C.ms_deform_attn_plan(v, sh, st, loc, 64)
+            for _ in range(3):
+                fwdp(); bwdp()
+            gfp, gbp, gpo = graphed(fwdp, per), graphed(bwdp, per), graphed(planonly, per)
+            tf, tb, tp = [], [], []
+            for _ in range(rounds):
+                tf.append(timeit(gfp, max(1, iters // per)) / per)
+                tb.append(timeit(gbp, max(1, iters // per)) / per)
+                tp.append(timeit(gpo, max(1, iters // per)) / per)
+            print("%-18s fwd+plan med %6.2f us (min %6.2f) | planned bwd med %6.2f us (min %6.2f) | pair %6.2f us = %.3f of 8 TB/s | plan alone %6.2f us"
+                  % (name, np.median(tf), min(tf), np.median(tb), min(tb), np.median(tf) + np.median(tb),
+                     (fb + bb) / (np.median(tf) + np.median(tb)) / 1e3 / 8000.0, np.median(tp)), flush=True)
 
 if __name__ == "__main__":
     main()

@@ -1,4 +1,4 @@
-"""Per-block phase times of msda_bwd_tile_accum (library built with -DZIRA_TILE_STAMPS=1, ZIRA_MSDA_LIB=...):
+"""Per-block phase times of msda_bwd_tile_accum (library built with -DZIRA_DEV_STAMPS=1, ZIRA_MSDA_LIB=...):
    python scripts/tile_stamps.py [uniform|inmodel]"""
 import ctypes, os, sys
 import numpy as np, torch
@@ -20,10 +20,9 @@ lib.zira_dev_read_tile_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.zira_dev_read_tile_stamps(buf, n) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16).astype(np.int64)
 a = a[a[:, 8] > 0]
-names = ["prologue (levels, extras prefix)", "first header + records", "zero + first loads + barrier", "steps",
-         "next item + barrier", "flush"]
+names = ["prologue (items, first loads, clear)", "steps", "barrier + next item's first loads", "flush + barrier"]
 print("blocks with items:", len(a), " items per block mean %.2f max %d" % (a[:, 8].mean(), a[:, 8].max()))
-tot = a[:, :6].sum(1) / 100.0
+tot = a[:, :4].sum(1) / 100.0
 print("block busy time (us): mean %.2f  p50 %.2f  max %.2f" % (tot.mean(), np.median(tot), tot.max()))
 for i, nme in enumerate(names):
     x = a[:, i] / 100.0
@@ -34,6 +33,6 @@ assert lib.zira_dev_read_plan_stamps(buf, n) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16).astype(np.int64)
 a = a[a[:, 8] > 0]
 print("plan blocks:", len(a))
-for i, nme in enumerate(["levels + clear", "pass 1 (loc, cells, ranks)", "scan + tile table", "pass 2 (records)", "tail (extras, zero split tiles)"]):
+for i, nme in enumerate(["levels + clear", "pass 1 (loc, cells, ranks)", "scan + classes + ring atomics", "pass 2 (records)", "ring answers + barrier", "items"]):
     x = a[:, i] / 100.0
     print("  %-34s mean %6.2f us  max %6.2f" % (nme, x.mean(), x.max()))

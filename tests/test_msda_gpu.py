@@ -510,3 +510,119 @@ def test_dense_backward_with_garbage_workspace(oracle, fill):
         torch.cuda.synchronize()
         for g, w, name in zip((gv, gl, ga), want, ("grad_value", "grad_loc", "grad_attn")):
             _close(g, w, 5e-5 if name == "grad_value" else 2e-5, name)
+
+
+# ---- planned backward: the plan is made in the forward pass (zira_msda_plan_f32), the backward takes it as a handle ----
+PLANNED_CASES = [("northstar_decoder", dict(lo=0.0, hi=1.0)), ("northstar_inmodel", dict(inmodel=True)),
+                 ("northstar_pinpoint", dict(hot=2)), ("oob", dict(lo=-0.5, hi=1.5))]
+
+
+@pytest.mark.parametrize("name,kw", PLANNED_CASES, ids=[c[0] for c in PLANNED_CASES])
+def test_planned_backward_through_the_c_abi(oracle, name, kw):
+    """zira_msda_plan_bytes / zira_msda_fwd_plan_f32 / zira_msda_bwd_planned_f32 called directly: a garbage plan buffer,
+    the plan written once and used by two backward calls (it is only read), outputs poisoned before each call."""
+    from ziragroundingdino_amd import _lib
+
+    lib = _lib.load()
+    B, Q, M, D, shapes, P = 2, 900, 8, 32, NORTH_STAR_SHAPES, 4
+    S = sum(h * w for h, w in shapes)
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=31, **kw)
+    want_out = oracle.msda_forward(value, sh, start, loc, attn)
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    n = lib.zira_msda_plan_bytes(B, S, M, D, 4, Q, P)
+    assert n > 0 and n == lib.zira_msda_bwd_workspace_bytes(B, S, M, D, 4, Q, P)
+    plan = torch.full((n,), 0xAB, dtype=torch.uint8, device=DEV)
+    out = torch.full((B, Q, M * D), float("nan"), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.zira_msda_fwd_plan_f32(v.data_ptr(), tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), tattn.data_ptr(),
+                                      B, S, M, D, 4, Q, P, out.data_ptr(), plan.data_ptr(), n, st) == 0
+    _close(out, want_out, 2e-5, "output")
+    for scale in (1.0, -3.0):
+        gv, gl, ga = torch.full_like(v, float("nan")), torch.full_like(tloc, float("nan")), torch.full_like(tattn, float("nan"))
+        g = (tgo * scale).contiguous()
+        assert lib.zira_msda_bwd_planned_f32(g.data_ptr(), v.data_ptr(), tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(),
+                                             tattn.data_ptr(), B, S, M, D, 4, Q, P, gv.data_ptr(), gl.data_ptr(),
+                                             ga.data_ptr(), plan.data_ptr(), n, st) == 0
+        torch.cuda.synchronize()
+        for got, w, nm in zip((gv, gl, ga), want, ("grad_value", "grad_loc", "grad_attn")):
+            if nm == "grad_loc":
+                ok = _away_from_pixel_borders(loc, sh)
+                got, w = got.cpu().numpy() * ok[..., None], w * ok[..., None]
+            _close(got, w * scale, 2e-5 * abs(scale), "planned %s (x %g)" % (nm, scale))
+    # argument errors are returned, not raised: no planned path for a dense call, a short plan buffer
+    assert lib.zira_msda_plan_bytes(B, S, M, D, 4, S, P) == 0
+    assert lib.zira_msda_plan_f32(tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), B, S, M, D, 4, Q, P, plan.data_ptr(), n - 1, st) != 0
+    assert lib.zira_msda_bwd_planned_f32(tgo.data_ptr(), v.data_ptr(), tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(),
+                                         tattn.data_ptr(), B, S, M, D, 4, Q, P, gv.data_ptr(), gl.data_ptr(),
+                                         ga.data_ptr(), plan.data_ptr(), n - 1, st) != 0
+
+
+def test_forward_plan_eager_side_stream_and_in_a_graph(oracle):
+    """The autograd Function plans right behind the forward gather (`_C.ms_deform_attn_plan`) and hands the plan to the
+    backward: same gradients as planning inside the backward call, eagerly, from a side stream, and when forward and
+    backward are captured into a hipGraph and replayed on new inputs."""
+    B, Q, M, D, shapes, P = 2, 300, 8, 32, [(40, 61), (20, 31), (10, 16), (5, 8)], 4
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=32, lo=-0.2, hi=1.2)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    tsh, tst = t(sh), t(start)
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+
+    def run(v_, loc_, attn_, go_):
+        v_, loc_, attn_ = v_.detach().requires_grad_(), loc_.detach().requires_grad_(), attn_.detach().requires_grad_()
+        out = MultiScaleDeformableAttnFunction.apply(v_, tsh, tst, loc_, attn_, 64)
+        assert out.grad_fn.plan is not None or not _C.USE_FORWARD_PLAN
+        out.backward(go_)
+        return out.detach(), v_.grad, loc_.grad, attn_.grad
+
+    got = run(t(value), t(loc), t(attn), t(go))
+    _C.USE_FORWARD_PLAN = False
+    try:
+        ref = run(t(value), t(loc), t(attn), t(go))
+    finally:
+        _C.USE_FORWARD_PLAN = True
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-5, atol=1e-6 * float(ref[1].abs().max()))
+    for g_, w, nm in zip(got[1:], want, ("grad_value", "grad_loc", "grad_attn")):
+        if nm == "grad_loc":
+            ok = _away_from_pixel_borders(loc, sh)
+            g_, w = g_.cpu().numpy() * ok[..., None], w * ok[..., None]
+        _close(g_, w, 2e-5, nm)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got_s = run(t(value), t(loc), t(attn), t(go))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(got_s[2], got[2]) and torch.equal(got_s[3], got[3])
+    # captured: static inputs, forward + backward in one graph, replayed on other data
+    sv, sl, sa, sg = t(value).requires_grad_(), t(loc).requires_grad_(), t(attn).requires_grad_(), t(go)
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        for _ in range(2):
+            MultiScaleDeformableAttnFunction.apply(sv, tsh, tst, sl, sa, 64).backward(sg)
+    torch.cuda.current_stream().wait_stream(warm)
+    sv.grad = sl.grad = sa.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        MultiScaleDeformableAttnFunction.apply(sv, tsh, tst, sl, sa, 64).backward(sg)
+    value2, _, _, loc2, attn2, go2 = _random_case(B, Q, M, D, shapes, P, seed=33, hot=True)
+    want2 = oracle.msda_backward(go2, value2, sh, start, loc2, attn2)
+    eager2 = run(t(value2), t(loc2), t(attn2), t(go2))
+    with torch.no_grad():
+        sv.copy_(t(value2)); sl.copy_(t(loc2)); sa.copy_(t(attn2)); sg.copy_(t(go2))
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    errs = []
+    for what, got3 in (("eager", eager2[1:]), ("replayed", (sv.grad, sl.grad, sa.grad))):
+        for g_, w, nm in zip(got3, want2, ("grad_value", "grad_loc", "grad_attn")):
+            if nm == "grad_loc":
+                ok = _away_from_pixel_borders(loc2, sh)
+                g_, w = g_.cpu().numpy() * ok[..., None], w * ok[..., None]
+            g_ = g_.detach().cpu().numpy() if torch.is_tensor(g_) else g_
+            errs.append((what, nm, float(np.abs(g_ - w).max()) / max(1.0, float(np.abs(w).max()))))
+    assert all(e[2] <= 2e-5 for e in errs), errs

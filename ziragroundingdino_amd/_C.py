@@ -59,6 +59,7 @@ def _dims(value, spatial_shapes, sampling_loc, im2col_step):
 
 
 USE_TILED_BACKWARD = True  # False forces the atomic backward (tests compare the two)
+USE_FORWARD_PLAN = True    # False: sparse backward calls plan inside the backward call (zira_msda_bwd_f32_ws)
 # Optional launch timing for bench.py: when TIMING is a list, every call appends
 # (kind, (B, S, M, D, L, Q, P), start_event, end_event) recorded on the launch stream.
 TIMING = None
@@ -115,10 +116,45 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+_PLAN_CACHE = {}
+
+
+def _plan_bytes(lib, *dims):
+    n = _PLAN_CACHE.get(dims)
+    if n is None:
+        n = _PLAN_CACHE[dims] = int(lib.zira_msda_plan_bytes(*dims))
+    return n
+
+
+def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
+    """-> plan (an opaque uint8 device tensor) or None.  The backward of a sparse float32 call (decoder
+    cross-attention) is cut into tiles by a plan that depends on the level tables and the sampling locations only, so
+    it can be made in the forward pass, off the backward's critical path: this enqueues the planning kernel on the
+    current stream (C ABI ``zira_msda_plan_f32``); hand the result to ``ms_deform_attn_backward(..., plan=plan)``.
+    None where no planned backward exists (CPU tensors, dense calls, other dtypes / widths) or with
+    ``USE_FORWARD_PLAN`` off: the backward then plans by itself."""
+    if not (USE_FORWARD_PLAN and USE_TILED_BACKWARD and value.is_cuda and sampling_loc.is_cuda
+            and value.dtype == torch.float32 and sampling_loc.dtype == torch.float32 and sampling_loc.is_contiguous()
+            and spatial_shapes.is_cuda and level_start_index.is_cuda and value.dim() == 4 and sampling_loc.dim() == 6):
+        return None
+    dims = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    lib = _lib.load()
+    nbytes = _plan_bytes(lib, *dims)
+    if not nbytes:
+        return None
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+    with torch.cuda.device(value.device), _Timed("plan", dims):
+        rc = lib.zira_msda_plan_f32(spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                    *dims, plan.data_ptr(), nbytes, _stream())
+    _raise_on(rc, "ms_deform_attn_plan")
+    return plan
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step):
+                            grad_output, im2col_step, plan=None):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight].
-    Reference: ms_deform_attn_cuda_backward (ms_deform_attn_cuda.cu:84-154)."""
+    Reference: ms_deform_attn_cuda_backward (ms_deform_attn_cuda.cu:84-154).  ``plan``: the second result of
+    ``ms_deform_attn_forward_planned`` for the same level tables and sampling locations (optional)."""
     _check_common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                   extra=(("grad_output", grad_output),))
     B, S, M, D, L, Q, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
@@ -131,6 +167,14 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     args = (grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
             B, S, M, D, L, Q, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+    if plan is not None:
+        if value.dtype != torch.float32 or plan.dtype != torch.uint8 or not plan.is_cuda \
+                or plan.numel() < _plan_bytes(lib, B, S, M, D, L, Q, P) or not _plan_bytes(lib, B, S, M, D, L, Q, P):
+            raise RuntimeError("ms_deform_attn_backward: plan does not belong to this call")
+        with torch.cuda.device(value.device), _Timed("bwd", (B, S, M, D, L, Q, P)):
+            rc = lib.zira_msda_bwd_planned_f32(*args, plan.data_ptr(), plan.numel(), _stream())
+        _raise_on(rc, "ms_deform_attn_backward")
+        return [grad_value, grad_loc, grad_attn]
     ws_bytes = _workspace_bytes(lib, B, S, M, D, L, Q, P) if value.dtype == torch.float32 else 0
     tiled = bool(ws_bytes) and USE_TILED_BACKWARD
     if tiled:  # atomic-free two-kernel backward; scratch comes from torch's caching allocator

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ZIRA_MSDA_LIB") or os.path.join(_HERE, "libzira_msda.
 SYMBOLS = (
     "zira_msda_fwd_f32", "zira_msda_bwd_f32", "zira_msda_fwd_f64", "zira_msda_bwd_f64",
     "zira_msda_bwd_workspace_bytes", "zira_msda_bwd_f32_ws",
+    "zira_msda_plan_bytes", "zira_msda_plan_f32", "zira_msda_fwd_plan_f32", "zira_msda_bwd_planned_f32",
     "zira_msda_fwd_cpu_f32", "zira_msda_bwd_cpu_f32",
     "zira_rsb_workspace_floats", "zira_rsb_fwd_f32", "zira_rsb_bwd_f32",
     "zira_xty_workspace_floats", "zira_xty_f32",
@@ -62,6 +63,14 @@ def load():
     lib.zira_msda_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.zira_msda_bwd_f32_ws.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]
     lib.zira_msda_bwd_f32_ws.restype = i
+    lib.zira_msda_plan_bytes.argtypes = [i] * 7
+    lib.zira_msda_plan_bytes.restype = ctypes.c_size_t
+    lib.zira_msda_plan_f32.argtypes = [vp, vp, vp] + [i] * 7 + [vp, ctypes.c_size_t, vp]
+    lib.zira_msda_plan_f32.restype = i
+    lib.zira_msda_fwd_plan_f32.argtypes = fwd_args[:-1] + [vp, ctypes.c_size_t, vp]
+    lib.zira_msda_fwd_plan_f32.restype = i
+    lib.zira_msda_bwd_planned_f32.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]
+    lib.zira_msda_bwd_planned_f32.restype = i
     sz = ctypes.c_size_t
     lib.zira_rsb_workspace_floats.argtypes = [sz]
     lib.zira_rsb_workspace_floats.restype = sz

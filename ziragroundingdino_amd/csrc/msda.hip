@@ -1779,7 +1779,7 @@ size_t zira_msda_bwd_workspace_bytes(int B, int S, int M, int D, int L, int Q, i
         const size_t n = zira::cells_workspace_bytes(B, S, M, D, L, Q, P);
         if (n) return n;
     } else if (ZIRA_SPARSE_TILES) {
-        const size_t n = zira::tiles_workspace_bytes(B, S, M, D, L, Q, P);
+        const size_t n = zira::tiles_plan_bytes(B, S, M, D, L, Q, P);
         if (n) return n;
     }
     if (!make_tile_plan(B, S, M, D, L, Q, P, p)) return 0;
@@ -1801,10 +1801,13 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
                                             gv, gl, ga, workspace, workspace_bytes, (hipStream_t)stream);
     }
     if (ZIRA_SPARSE_TILES && workspace && !use_cells_path(B, M, Q) && !((uintptr_t)workspace & 15)) {
-        const size_t need = zira::tiles_workspace_bytes(B, S, M, D, L, Q, P);
+        // no plan from the forward pass: plan here, in front of the accumulate kernel (the workspace is the plan buffer)
+        const size_t need = zira::tiles_plan_bytes(B, S, M, D, L, Q, P);
         if (need && workspace_bytes >= need) {
-            const int rc = zira::tiles_backward_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
-                                                    gv, gl, ga, workspace, workspace_bytes, (hipStream_t)stream);
+            int rc = zira::tiles_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, workspace, workspace_bytes, (hipStream_t)stream);
+            if (rc == 0)
+                rc = zira::tiles_backward_planned_f32(grad_out, value, attn, B, S, M, D, L, Q, P, gv, gl, ga, workspace,
+                                                      workspace_bytes, (hipStream_t)stream);
             if (rc != -1) return rc;
         }
     }
@@ -1817,6 +1820,46 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
     if (D == 16) return launch_bwd_tiled<1>(p, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, workspace, st);
     if (D == 32) return launch_bwd_tiled<2>(p, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, workspace, st);
     return launch_bwd_tiled<4>(p, grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, workspace, st);
+}
+
+size_t zira_msda_plan_bytes(int B, int S, int M, int D, int L, int Q, int P)
+{
+    if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0) return 0;
+    if (!ZIRA_SPARSE_TILES || use_cells_path(B, M, Q)) return 0;
+    return zira::tiles_plan_bytes(B, S, M, D, L, Q, P);
+}
+
+int zira_msda_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc, int B, int S, int M, int D, int L,
+                       int Q, int P, void *plan, size_t plan_bytes, void *stream)
+{
+    if (!shapes || !start || !loc || !plan || B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0)
+        return ZIRA_MSDA_EINVAL;
+    const size_t need = zira_msda_plan_bytes(B, S, M, D, L, Q, P);
+    if (!need || plan_bytes < need || ((uintptr_t)plan & 15)) return ZIRA_MSDA_EINVAL;
+    const int rc = zira::tiles_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, plan, plan_bytes, (hipStream_t)stream);
+    return rc == -1 ? ZIRA_MSDA_EINVAL : rc;
+}
+
+int zira_msda_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t *start, const float *loc,
+                           const float *attn, int B, int S, int M, int D, int L, int Q, int P, float *out, void *plan,
+                           size_t plan_bytes, void *stream)
+{
+    const int rc = zira_msda_fwd_f32(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out, stream);
+    if (rc != 0) return rc;
+    return zira_msda_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, plan, plan_bytes, stream);
+}
+
+int zira_msda_bwd_planned_f32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
+                              const float *loc, const float *attn, int B, int S, int M, int D, int L, int Q, int P,
+                              float *gv, float *gl, float *ga, const void *plan, size_t plan_bytes, void *stream)
+{
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv || !gl || !ga || !plan)
+        return ZIRA_MSDA_EINVAL;
+    const size_t need = zira_msda_plan_bytes(B, S, M, D, L, Q, P);
+    if (!need || plan_bytes < need || ((uintptr_t)plan & 15)) return ZIRA_MSDA_EINVAL;
+    const int rc = zira::tiles_backward_planned_f32(grad_out, value, attn, B, S, M, D, L, Q, P, gv, gl, ga, plan, plan_bytes,
+                                                    (hipStream_t)stream);
+    return rc == -1 ? ZIRA_MSDA_EINVAL : rc;
 }
 
 int zira_msda_fwd_f64(const double *value, const int64_t *shapes, const int64_t *start,
@@ -1849,7 +1892,7 @@ const char *zira_msda_variant_f32(int D)
     // the call passes lean_ok(); the other specialised widths use the row-per-group kernels
     if (D == 16 || D == 32 || D == 64)
         return D == 32 ? "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_accum + msda_bwd_fold (dense calls) / "
-                         "msda_bwd_plan + msda_bwd_tile_accum (sparse calls); without: msda_bwd_lean_atomic"
+                         "msda_plan + msda_bwd_zero_split + msda_bwd_tile_accum (sparse calls); without: msda_bwd_lean_atomic"
                        : "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_walk + msda_bwd_fold (dense calls) / "
                          "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic";
     switch (lpr_for(D)) {

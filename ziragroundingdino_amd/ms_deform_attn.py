@@ -39,6 +39,10 @@ class MultiScaleDeformableAttnFunction(Function):
         ctx.im2col_step = im2col_step
         output = _C.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                            sampling_locations, attention_weights, im2col_step)
+        # how the backward is cut into tiles depends on the sampling locations only: planned here, off the backward's
+        # critical path (None for CPU tensors, dense calls or when nothing needs a gradient)
+        ctx.plan = _C.ms_deform_attn_plan(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                          im2col_step) if any(ctx.needs_input_grad) else None
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output
@@ -47,8 +51,9 @@ class MultiScaleDeformableAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, start, loc, attn = ctx.saved_tensors
+        kw = {} if ctx.plan is None else {"plan": ctx.plan}
         grad_value, grad_loc, grad_attn = _C.ms_deform_attn_backward(
-            value, shapes, start, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+            value, shapes, start, loc, attn, grad_output.contiguous(), ctx.im2col_step, **kw)
         return grad_value, None, None, grad_loc, grad_attn, None
 
 
