@@ -71,7 +71,7 @@ def main():
                  np.median(tb), min(tb), bb / np.median(tb) / 1e3), flush=True)
         plan = _C.ms_deform_attn_plan(v, sh, st, loc, 64)
         if plan is not None:   # sparse calls: the plan made right behind the forward gather, the backward from the plan
-            fwdp = lambda: (_C.ms_deform_attn_forward(v, sh, st, loc, attn, 64), _C.ms_deform_attn_plan(v, sh, st, loc, 64))
+            fwdp = lambda: _C.ms_deform_attn_forward_plan(v, sh, st, loc, attn, 64)
             bwdp = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64, plan=plan)
             planonly = lambda: _C.ms_deform_attn_plan(v, sh, st, loc, 64)
             for _ in range(3):

@@ -33,6 +33,6 @@ assert lib.zira_dev_read_plan_stamps(buf, n) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16).astype(np.int64)
 a = a[a[:, 8] > 0]
 print("plan blocks:", len(a))
-for i, nme in enumerate(["levels + clear", "pass 1 (loc, cells, ranks)", "scan + classes + ring atomics", "pass 2 (records)", "ring answers + barrier", "items"]):
+for i, nme in enumerate(["levels + clear", "pass 1 (loc, cells, ranks)", "scan + classes", "pass 2 (records)", "counts", "items"]):
     x = a[:, i] / 100.0
     print("  %-34s mean %6.2f us  max %6.2f" % (nme, x.mean(), x.max()))

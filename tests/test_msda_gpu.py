@@ -539,7 +539,10 @@ def test_planned_backward_through_the_c_abi(oracle, name, kw):
     assert lib.zira_msda_fwd_plan_f32(v.data_ptr(), tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), tattn.data_ptr(),
                                       B, S, M, D, 4, Q, P, out.data_ptr(), plan.data_ptr(), n, st) == 0
     _close(out, want_out, 2e-5, "output")
-    for scale in (1.0, -3.0):
+    # the plan alone (zira_msda_plan_f32) serves the same backward
+    plan2 = torch.full((n,), 0x5C, dtype=torch.uint8, device=DEV)
+    assert lib.zira_msda_plan_f32(tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), B, S, M, D, 4, Q, P, plan2.data_ptr(), n, st) == 0
+    for scale, plan in ((1.0, plan), (-3.0, plan), (1.0, plan2)):
         gv, gl, ga = torch.full_like(v, float("nan")), torch.full_like(tloc, float("nan")), torch.full_like(tattn, float("nan"))
         g = (tgo * scale).contiguous()
         assert lib.zira_msda_bwd_planned_f32(g.data_ptr(), v.data_ptr(), tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(),

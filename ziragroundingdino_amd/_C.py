@@ -126,28 +126,62 @@ def _plan_bytes(lib, *dims):
     return n
 
 
-def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
-    """-> plan (an opaque uint8 device tensor) or None.  The backward of a sparse float32 call (decoder
-    cross-attention) is cut into tiles by a plan that depends on the level tables and the sampling locations only, so
-    it can be made in the forward pass, off the backward's critical path: this enqueues the planning kernel on the
-    current stream (C ABI ``zira_msda_plan_f32``); hand the result to ``ms_deform_attn_backward(..., plan=plan)``.
-    None where no planned backward exists (CPU tensors, dense calls, other dtypes / widths) or with
-    ``USE_FORWARD_PLAN`` off: the backward then plans by itself."""
+def _plan_dims(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
+    """Dimensions and plan size of a call the planned backward serves, else None."""
     if not (USE_FORWARD_PLAN and USE_TILED_BACKWARD and value.is_cuda and sampling_loc.is_cuda
             and value.dtype == torch.float32 and sampling_loc.dtype == torch.float32 and sampling_loc.is_contiguous()
             and spatial_shapes.is_cuda and level_start_index.is_cuda and value.dim() == 4 and sampling_loc.dim() == 6):
         return None
     dims = _dims(value, spatial_shapes, sampling_loc, im2col_step)
-    lib = _lib.load()
-    nbytes = _plan_bytes(lib, *dims)
-    if not nbytes:
+    nbytes = _plan_bytes(_lib.load(), *dims)
+    return (dims, nbytes) if nbytes else None
+
+
+def plan_applies(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
+    """True where ``ms_deform_attn_forward_plan`` / ``ms_deform_attn_plan`` return a plan: sparse float32 calls on the
+    GPU (decoder cross-attention) with D = 32; False for CPU tensors, dense calls, other dtypes / widths."""
+    return _plan_dims(value, spatial_shapes, level_start_index, sampling_loc, im2col_step) is not None
+
+
+def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
+    """-> plan (an opaque uint8 device tensor) or None.  The backward of a sparse float32 call (decoder
+    cross-attention) is cut into tiles by a plan that depends on the level tables and the sampling locations only, so
+    it can be made in the forward pass, off the backward's critical path: this enqueues the planning kernel on the
+    current stream (C ABI ``zira_msda_plan_f32``); hand the result to ``ms_deform_attn_backward(..., plan=plan)``.
+    None where no planned backward exists (``plan_applies``) or with ``USE_FORWARD_PLAN`` off: the backward then plans
+    by itself."""
+    pd = _plan_dims(value, spatial_shapes, level_start_index, sampling_loc, im2col_step)
+    if pd is None:
         return None
+    dims, nbytes = pd
+    lib = _lib.load()
     plan = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
     with torch.cuda.device(value.device), _Timed("plan", dims):
         rc = lib.zira_msda_plan_f32(spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                                     *dims, plan.data_ptr(), nbytes, _stream())
     _raise_on(rc, "ms_deform_attn_plan")
     return plan
+
+
+def ms_deform_attn_forward_plan(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """-> (output[B, Q, M*D], plan): ``ms_deform_attn_forward`` and ``ms_deform_attn_plan`` in ONE launch (C ABI
+    ``zira_msda_fwd_plan_f32``: the plan's blocks run beside the gather's, the only way the two overlap on this stack).
+    Only where ``plan_applies``."""
+    _check_common(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    pd = _plan_dims(value, spatial_shapes, level_start_index, sampling_loc, im2col_step)
+    if pd is None:
+        raise RuntimeError("ms_deform_attn_forward_plan: no planned backward for this call (see plan_applies)")
+    dims, nbytes = pd
+    B, S, M, D, L, Q, P = dims
+    lib = _lib.load()
+    out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+    with torch.cuda.device(value.device), _Timed("fwd", dims):
+        rc = lib.zira_msda_fwd_plan_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                        sampling_loc.data_ptr(), attn_weight.data_ptr(), *dims, out.data_ptr(),
+                                        plan.data_ptr(), nbytes, _stream())
+    _raise_on(rc, "ms_deform_attn_forward_plan")
+    return out, plan
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,

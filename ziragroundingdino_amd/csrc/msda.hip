@@ -284,103 +284,9 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_rows_atomic(
 //   * because all SLOTS partial sums of a channel live in one DPP row, the final reduction
 //     is log2(SLOTS) v_add_f32_dpp row rotations -- no cross-row traffic, no LDS.
 // ------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x)
-{
-    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
-}
-
-struct ItemId {
-    unsigned item;  // flat (b, q, m)
-    unsigned b, m;
-    bool ok;
-};
-
-// n / d for n < 2^31 with a host-prepared multiplier (no hardware integer divide on the GPU:
-// a plain `/` costs ~30 scalar instructions per wave, and the scalar unit is shared by the CU)
-struct FastDiv {
-    unsigned mul, shift, d;
-};
-__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f)
-{
-    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
-}
-
-// head-major placement (see head_major_item), wave-uniform / scalar, 32-bit
-__device__ __forceinline__ ItemId lean_item(unsigned nitems, unsigned per, FastDiv Q, FastDiv M)
-{
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const unsigned t0 = xcd * per;
-    const unsigned t = t0 + idx * kWavesPerBlock + wave;
-    const unsigned t1 = (t0 + per < nitems) ? t0 + per : nitems;
-    ItemId r;
-    r.ok = t < t1;
-    const unsigned g = fast_div(t, Q), q = t - g * Q.d;
-    r.b = fast_div(g, M);
-    r.m = g - r.b * M.d;
-    r.item = (r.b * Q.d + q) * M.d + r.m;
-    return r;
-}
-
-struct Entry {
-    float w;        // bilinear weight x attention weight, 0 for a corner that contributes nothing
-    unsigned offb;  // BYTE offset of the corner's value row inside the batch element (0 if unused)
-    // backward only
-    float wb, cx, cy, a, Wf, Hf;
-    unsigned lvl, pix, hw;  // level, pixel index inside the level, pixels in the level
-    bool inb;
-};
-
-template <bool kNeedGrad>
-__device__ __forceinline__ Entry entry_setup(const int64_t *__restrict__ shapes,
-                                             const int64_t *__restrict__ start,
-                                             const float *__restrict__ loc_i,
-                                             const float *__restrict__ att_i, unsigned s,
-                                             unsigned c, unsigned LP, float invP, unsigned M,
-                                             unsigned D, unsigned m)
-{
-#pragma clang fp contract(off)
-    Entry k;
-    const bool act = s < LP;
-    const unsigned sc = act ? s : 0u;
-    const unsigned l = (unsigned)(((float)sc + 0.5f) * invP);  // == sc / P
-    // low dwords of the int64 level table (sizes are < 2^31)
-    const int2 hw = make_int2(reinterpret_cast<const int *>(shapes)[4 * l],
-                              reinterpret_cast<const int *>(shapes)[4 * l + 2]);
-    const int st = reinterpret_cast<const int *>(start)[2 * l];
-    const float2 xy = *reinterpret_cast<const float2 *>(loc_i + 2 * sc);
-    const float a = att_i[sc];
-    const float Hf = (float)hw.x, Wf = (float)hw.y;
-    const float h_im = xy.y * Hf - 0.5f;
-    const float w_im = xy.x * Wf - 0.5f;
-    const bool valid = act && h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const float lh = h_im - hf, lw = w_im - wf;
-    const int dy = (int)(c >> 1), dx = (int)(c & 1);
-    const int y = (int)hf + dy, x = (int)wf + dx;
-    const float wy = dy ? lh : 1.f - lh;
-    const float wx = dx ? lw : 1.f - lw;
-    k.inb = valid && y >= 0 && y < hw.x && x >= 0 && x < hw.y;
-    k.wb = k.inb ? wy * wx : 0.f;
-    k.w = k.wb * a;
-    k.offb = k.inb ? ((unsigned)(st + y * hw.y + x) * M + m) * (D * 4u) : 0u;
-    if (kNeedGrad) {
-        k.cx = k.inb ? (dx ? wy : -wy) : 0.f;
-        k.cy = k.inb ? (dy ? wx : -wx) : 0.f;
-        k.a = valid ? a : 0.f;
-        k.Wf = Wf; k.Hf = Hf;
-        k.lvl = l;
-        k.pix = (unsigned)(y * hw.y + x);
-        k.hw = (unsigned)(hw.x * hw.y);
-    }
-    return k;
-}
-
-__device__ __forceinline__ float4 load_row16(const float *__restrict__ base, unsigned byte_off)
-{
-    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
-}
+}  // namespace
+#include "msda_fwd_lean.h"
+namespace {
 
 template <int CQR>
 __global__ __launch_bounds__(kBlock, 8) void msda_fwd_lean(
@@ -389,50 +295,9 @@ __global__ __launch_bounds__(kBlock, 8) void msda_fwd_lean(
     const float *__restrict__ attn, unsigned S, FastDiv Mdiv, unsigned LP, FastDiv Qdiv,
     float invP, unsigned nitems, unsigned per_xcd, float *__restrict__ out)
 {
-    constexpr unsigned D = 16 * CQR;
-    constexpr unsigned SLOTS = 16 / CQR;  // value rows per gather instruction
-    constexpr unsigned NI = 64 / SLOTS;   // gather instructions per 64-entry chunk
-    const unsigned M = Mdiv.d;
     const ItemId id = lean_item(nitems, per_xcd, Qdiv, Mdiv);
     if (!id.ok) return;  // wave-uniform
-    const unsigned lane = threadIdx.x & 63;
-    const float *vb = value + (size_t)id.b * S * M * D;  // uniform
-    const float *loc_i = loc + (size_t)id.item * LP * 2;
-    const float *att_i = attn + (size_t)id.item * LP;
-
-    const unsigned R = lane >> 4;
-    const unsigned slot = (lane & 15) / CQR;
-    const unsigned cq = R * CQR + (lane & (CQR - 1));
-    const int bp = (int)(slot * 4);  // ds_bpermute byte address of source lane `slot`
-    const unsigned lane_off = cq * 16;
-
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (unsigned s0 = 0; s0 < LP; s0 += 16) {
-        const Entry k = entry_setup<false>(shapes, start, loc_i, att_i, s0 + (lane >> 2),
-                                           lane & 3, LP, invP, M, D, id.m);
-        const int offb_i = (int)k.offb, w_i = __float_as_int(k.w);
-#pragma unroll
-        for (unsigned j = 0; j < NI; ++j) {
-            const int a = bp + (int)(j * SLOTS * 4);
-            const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(a, offb_i);
-            const float wj = __int_as_float(__builtin_amdgcn_ds_bpermute(a, w_i));
-            const float4 v = load_row16(vb, oj + lane_off);
-            acc.x = fmaf(wj, v.x, acc.x);
-            acc.y = fmaf(wj, v.y, acc.y);
-            acc.z = fmaf(wj, v.z, acc.z);
-            acc.w = fmaf(wj, v.w, acc.w);
-        }
-    }
-    // reduce over the SLOTS lanes (same DPP row) that hold the same channel quad
-    if (CQR <= 1) { acc.x = dpp_add<0x121>(acc.x); acc.y = dpp_add<0x121>(acc.y);
-                    acc.z = dpp_add<0x121>(acc.z); acc.w = dpp_add<0x121>(acc.w); }
-    if (CQR <= 2) { acc.x = dpp_add<0x122>(acc.x); acc.y = dpp_add<0x122>(acc.y);
-                    acc.z = dpp_add<0x122>(acc.z); acc.w = dpp_add<0x122>(acc.w); }
-    acc.x = dpp_add<0x124>(acc.x); acc.y = dpp_add<0x124>(acc.y);
-    acc.z = dpp_add<0x124>(acc.z); acc.w = dpp_add<0x124>(acc.w);
-    acc.x = dpp_add<0x128>(acc.x); acc.y = dpp_add<0x128>(acc.y);
-    acc.z = dpp_add<0x128>(acc.z); acc.w = dpp_add<0x128>(acc.w);
-    if (slot == 0) *reinterpret_cast<float4 *>(out + (size_t)id.item * D + cq * 4) = acc;
+    fwd_lean_item<CQR>(value, shapes, start, loc, attn, S, Mdiv.d, LP, invP, id, out);
 }
 
 // Backward, lean path, grad_value by fp32 atomics (used when no workspace is supplied).
@@ -1491,16 +1356,6 @@ inline bool lean_ok(int B, int S, int M, int D, int L, int Q, int P)
 
 // mul, shift with (n * mul) >> shift == n / d for every n < 2^31:
 // s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1 (< 2^32), shift = 31 + s.
-inline FastDiv make_fast_div(unsigned d)
-{
-    FastDiv f;
-    f.d = d;
-    unsigned s = 0;
-    while ((1ull << s) < d) ++s;
-    f.shift = 31 + s;
-    f.mul = (unsigned)(((1ull << (31 + s)) / d) + 1);
-    return f;
-}
 
 inline int generic_grid(long n)
 {
@@ -1680,6 +1535,36 @@ int fwd_generic(const T *value, const int64_t *shapes, const int64_t *start, con
     return (int)hipGetLastError();
 }
 
+// Zero-fill on the caller's stream by a KERNEL: hipMemsetAsync becomes a memset node when the stream is being captured,
+// and ROCm 7.2 replays such a node out of order with the kernels around it (found in round 4, scripts/repro_memset_graph.py).
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *__restrict__ p, size_t n16, unsigned char *__restrict__ tail, unsigned ntail)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+inline hipError_t zero_fill_async(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return hipSuccess;
+    unsigned char *b = reinterpret_cast<unsigned char *>(ptr);
+    const size_t head = ((uintptr_t)b & 15) ? 16 - ((uintptr_t)b & 15) : 0;
+    if (head >= bytes || bytes < 64) {   // tiny: bytes by one block
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(256), 0, st, (uint4 *)nullptr, (size_t)0, b, (unsigned)(bytes < 256 ? bytes : 0));
+        if (bytes >= 256) return hipErrorInvalidValue;   // (unreachable: < 64 here)
+        return hipGetLastError();
+    }
+    if (head) {   // unaligned start (never the case for torch / hipMalloc storage): the first bytes on their own
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(256), 0, st, (uint4 *)nullptr, (size_t)0, b, (unsigned)head);
+        b += head;
+        bytes -= head;
+    }
+    const size_t n16 = bytes / 16;
+    const unsigned ntail = (unsigned)(bytes - n16 * 16);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4 *>(b), n16, b + n16 * 16, ntail);
+    return hipGetLastError();
+}
+
 template <typename T>
 int bwd_generic(const T *grad_out, const T *value, const int64_t *shapes, const int64_t *start,
                 const T *loc, const T *attn, int B, int S, int M, int D, int L, int Q, int P,
@@ -1687,11 +1572,11 @@ int bwd_generic(const T *grad_out, const T *value, const int64_t *shapes, const 
 {
     const long n = (long)B * Q * M * D;
     const size_t nsamp = (size_t)B * Q * M * L * P;
-    hipError_t e = hipMemsetAsync(gv, 0, sizeof(T) * (size_t)B * S * M * D, st);
+    hipError_t e = zero_fill_async(gv, sizeof(T) * (size_t)B * S * M * D, st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(gl, 0, sizeof(T) * nsamp * 2, st);
+    e = zero_fill_async(gl, sizeof(T) * nsamp * 2, st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(ga, 0, sizeof(T) * nsamp, st);
+    e = zero_fill_async(ga, sizeof(T) * nsamp, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(msda_bwd_generic<T>, dim3(generic_grid(n)), dim3(kBlock), 0, st, grad_out,
                        value, shapes, start, loc, attn, S, M, D, L, Q, P, n, gv, gl, ga);
@@ -1739,7 +1624,7 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
     if (lpr == 0)
         return bwd_generic<float>(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P,
                                   gv, gl, ga, st);
-    hipError_t e = hipMemsetAsync(gv, 0, sizeof(float) * (size_t)B * S * M * D, st);
+    hipError_t e = zero_fill_async(gv, sizeof(float) * (size_t)B * S * M * D, st);
     if (e != hipSuccess) return (int)e;
     if (lean_ok(B, S, M, D, L, Q, P)) {
         if (D == 16) return launch_bwd_lean_atomic<1>(grad_out, value, shapes, start, loc, attn, B, S, M, L, Q, P, gv, gl, ga, st);
@@ -1844,6 +1729,14 @@ int zira_msda_fwd_plan_f32(const float *value, const int64_t *shapes, const int6
                            const float *attn, int B, int S, int M, int D, int L, int Q, int P, float *out, void *plan,
                            size_t plan_bytes, void *stream)
 {
+    if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !out || !plan) return ZIRA_MSDA_EINVAL;
+    const size_t need = zira_msda_plan_bytes(B, S, M, D, L, Q, P);
+    if (!need || plan_bytes < need || ((uintptr_t)plan & 15)) return ZIRA_MSDA_EINVAL;
+    if (lean_ok(B, S, M, D, L, Q, P)) {   // one launch: the plan's blocks beside the gather's
+        const int rc = zira::tiles_fwd_plan_f32(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out, plan, plan_bytes,
+                                                (hipStream_t)stream);
+        if (rc != -1) return rc;
+    }
     const int rc = zira_msda_fwd_f32(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out, stream);
     if (rc != 0) return rc;
     return zira_msda_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, plan, plan_bytes, stream);

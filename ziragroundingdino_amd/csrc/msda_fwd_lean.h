@@ -1,0 +1,177 @@
+// msda_fwd_lean.h -- building blocks of the "lean" forward of multi-scale deformable attention (D = 16 / 32 / 64) for
+// gfx950, shared by csrc/msda.hip (the forward kernel, the atomic backward) and csrc/msda_tiles.hip (the forward fused
+// with the sparse backward's plan).  Arithmetic to match: reference ms_deform_im2col_cuda.cuh:237-299 + :33-84.
+// Layout notes are in csrc/msda.hip ("lean" path).  Everything here is internal linkage (one copy per TU).
+#ifndef ZIRA_MSDA_FWD_LEAN_H_
+#define ZIRA_MSDA_FWD_LEAN_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr unsigned kLeanWavesPerBlock = 4;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x)
+{
+    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+
+struct ItemId {
+    unsigned item;  // flat (b, q, m)
+    unsigned b, m;
+    bool ok;
+};
+
+// n / d for n < 2^31 with a host-prepared multiplier (no hardware integer divide on the GPU:
+// a plain `/` costs ~30 scalar instructions per wave, and the scalar unit is shared by the CU)
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv f)
+{
+    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
+}
+
+// head-major placement (see head_major_item), wave-uniform / scalar, 32-bit
+__device__ __forceinline__ ItemId lean_item(unsigned nitems, unsigned per, FastDiv Q, FastDiv M,
+                                            unsigned bid = blockIdx.x, unsigned waves_per_block = kLeanWavesPerBlock, unsigned wave_offset = 0)
+{
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + wave_offset;
+    const unsigned xcd = bid & 7, idx = bid >> 3;
+    const unsigned t0 = xcd * per;
+    const unsigned t = t0 + idx * waves_per_block + wave;
+    const unsigned t1 = (t0 + per < nitems) ? t0 + per : nitems;
+    ItemId r;
+    r.ok = t < t1;
+    const unsigned g = fast_div(t, Q), q = t - g * Q.d;
+    r.b = fast_div(g, M);
+    r.m = g - r.b * M.d;
+    r.item = (r.b * Q.d + q) * M.d + r.m;
+    return r;
+}
+
+struct Entry {
+    float w;        // bilinear weight x attention weight, 0 for a corner that contributes nothing
+    unsigned offb;  // BYTE offset of the corner's value row inside the batch element (0 if unused)
+    // backward only
+    float wb, cx, cy, a, Wf, Hf;
+    unsigned lvl, pix, hw;  // level, pixel index inside the level, pixels in the level
+    bool inb;
+};
+
+template <bool kNeedGrad>
+__device__ __forceinline__ Entry entry_setup(const int64_t *__restrict__ shapes,
+                                             const int64_t *__restrict__ start,
+                                             const float *__restrict__ loc_i,
+                                             const float *__restrict__ att_i, unsigned s,
+                                             unsigned c, unsigned LP, float invP, unsigned M,
+                                             unsigned D, unsigned m)
+{
+#pragma clang fp contract(off)
+    Entry k;
+    const bool act = s < LP;
+    const unsigned sc = act ? s : 0u;
+    const unsigned l = (unsigned)(((float)sc + 0.5f) * invP);  // == sc / P
+    // low dwords of the int64 level table (sizes are < 2^31)
+    const int2 hw = make_int2(reinterpret_cast<const int *>(shapes)[4 * l],
+                              reinterpret_cast<const int *>(shapes)[4 * l + 2]);
+    const int st = reinterpret_cast<const int *>(start)[2 * l];
+    const float2 xy = *reinterpret_cast<const float2 *>(loc_i + 2 * sc);
+    const float a = att_i[sc];
+    const float Hf = (float)hw.x, Wf = (float)hw.y;
+    const float h_im = xy.y * Hf - 0.5f;
+    const float w_im = xy.x * Wf - 0.5f;
+    const bool valid = act && h_im > -1.f && w_im > -1.f && h_im < Hf && w_im < Wf;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const float lh = h_im - hf, lw = w_im - wf;
+    const int dy = (int)(c >> 1), dx = (int)(c & 1);
+    const int y = (int)hf + dy, x = (int)wf + dx;
+    const float wy = dy ? lh : 1.f - lh;
+    const float wx = dx ? lw : 1.f - lw;
+    k.inb = valid && y >= 0 && y < hw.x && x >= 0 && x < hw.y;
+    k.wb = k.inb ? wy * wx : 0.f;
+    k.w = k.wb * a;
+    k.offb = k.inb ? ((unsigned)(st + y * hw.y + x) * M + m) * (D * 4u) : 0u;
+    if (kNeedGrad) {
+        k.cx = k.inb ? (dx ? wy : -wy) : 0.f;
+        k.cy = k.inb ? (dy ? wx : -wx) : 0.f;
+        k.a = valid ? a : 0.f;
+        k.Wf = Wf; k.Hf = Hf;
+        k.lvl = l;
+        k.pix = (unsigned)(y * hw.y + x);
+        k.hw = (unsigned)(hw.x * hw.y);
+    }
+    return k;
+}
+
+__device__ __forceinline__ float4 load_row16(const float *__restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+inline FastDiv make_fast_div(unsigned d)
+{
+    FastDiv f;
+    f.d = d;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = 31 + s;
+    f.mul = (unsigned)(((1ull << (31 + s)) / d) + 1);
+    return f;
+}
+
+// The forward of one (b, q, m) item by one wave (see the layout notes above); `id.ok` is wave-uniform.
+template <int CQR>
+__device__ __forceinline__ void fwd_lean_item(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                                              const int64_t *__restrict__ start, const float *__restrict__ loc,
+                                              const float *__restrict__ attn, unsigned S, unsigned M, unsigned LP,
+                                              float invP, const ItemId id, float *__restrict__ out)
+{
+    constexpr unsigned D = 16 * CQR;
+    constexpr unsigned SLOTS = 16 / CQR;  // value rows per gather instruction
+    constexpr unsigned NI = 64 / SLOTS;   // gather instructions per 64-entry chunk
+    const unsigned lane = threadIdx.x & 63;
+    const float *vb = value + (size_t)id.b * S * M * D;  // uniform
+    const float *loc_i = loc + (size_t)id.item * LP * 2;
+    const float *att_i = attn + (size_t)id.item * LP;
+
+    const unsigned R = lane >> 4;
+    const unsigned slot = (lane & 15) / CQR;
+    const unsigned cq = R * CQR + (lane & (CQR - 1));
+    const int bp = (int)(slot * 4);  // ds_bpermute byte address of source lane `slot`
+    const unsigned lane_off = cq * 16;
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned s0 = 0; s0 < LP; s0 += 16) {
+        const Entry k = entry_setup<false>(shapes, start, loc_i, att_i, s0 + (lane >> 2),
+                                           lane & 3, LP, invP, M, D, id.m);
+        const int offb_i = (int)k.offb, w_i = __float_as_int(k.w);
+#pragma unroll
+        for (unsigned j = 0; j < NI; ++j) {
+            const int a = bp + (int)(j * SLOTS * 4);
+            const unsigned oj = (unsigned)__builtin_amdgcn_ds_bpermute(a, offb_i);
+            const float wj = __int_as_float(__builtin_amdgcn_ds_bpermute(a, w_i));
+            const float4 v = load_row16(vb, oj + lane_off);
+            acc.x = fmaf(wj, v.x, acc.x);
+            acc.y = fmaf(wj, v.y, acc.y);
+            acc.z = fmaf(wj, v.z, acc.z);
+            acc.w = fmaf(wj, v.w, acc.w);
+        }
+    }
+    // reduce over the SLOTS lanes (same DPP row) that hold the same channel quad
+    if (CQR <= 1) { acc.x = dpp_add<0x121>(acc.x); acc.y = dpp_add<0x121>(acc.y);
+                    acc.z = dpp_add<0x121>(acc.z); acc.w = dpp_add<0x121>(acc.w); }
+    if (CQR <= 2) { acc.x = dpp_add<0x122>(acc.x); acc.y = dpp_add<0x122>(acc.y);
+                    acc.z = dpp_add<0x122>(acc.z); acc.w = dpp_add<0x122>(acc.w); }
+    acc.x = dpp_add<0x124>(acc.x); acc.y = dpp_add<0x124>(acc.y);
+    acc.z = dpp_add<0x124>(acc.z); acc.w = dpp_add<0x124>(acc.w);
+    acc.x = dpp_add<0x128>(acc.x); acc.y = dpp_add<0x128>(acc.y);
+    acc.z = dpp_add<0x128>(acc.z); acc.w = dpp_add<0x128>(acc.w);
+    if (slot == 0) *reinterpret_cast<float4 *>(out + (size_t)id.item * D + cq * 4) = acc;
+}
+
+}  // namespace
+
+#endif

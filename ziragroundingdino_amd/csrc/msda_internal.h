@@ -26,6 +26,10 @@ size_t tiles_plan_bytes(int B, int S, int M, int D, int L, int Q, int P);
 int tiles_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc, int B, int S, int M, int D, int L, int Q,
                    int P, void *plan, size_t plan_bytes, hipStream_t st);
 
+// forward + plan in one launch (D = 32); -1: not applicable
+int tiles_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t *start, const float *loc, const float *attn,
+                       int B, int S, int M, int D, int L, int Q, int P, float *out, void *plan, size_t plan_bytes, hipStream_t st);
+
 int tiles_backward_planned_f32(const float *grad_out, const float *value, const float *attn, int B, int S, int M, int D,
                                int L, int Q, int P, float *grad_value, float *grad_loc, float *grad_attn, const void *plan,
                                size_t plan_bytes, hipStream_t st);

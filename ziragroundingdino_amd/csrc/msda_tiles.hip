@@ -19,19 +19,20 @@
 //          2 x 2 corner block touches (LDS histogram; the rank inside the tile comes back from the atomic).  A block
 //          scan turns the histogram into record offsets.  Per tile a 32-byte WORK ITEM {first record, records, tile
 //          origin, level size, value row of the level's pixel 0, query 0 of the head, ...}; a tile with more than
-//          `cap` records is SPLIT into K = ceil(n / cap) items whose sums meet through fp32 atomics (its pixels are
-//          zeroed by a small launch in front of the accumulate kernel).  Pass 2 writes one 32-byte RECORD per
+//          `cap` records is SPLIT into K = ceil(n / cap) items whose sums meet in a small fold launch behind the
+//          accumulate kernel.  Pass 2 writes one 32-byte RECORD per
 //          (sample, touched tile) with everything the accumulate kernel needs already resolved: byte offset of the
 //          query's grad_out row, index of the sample in grad_attn, byte offset of its top-left value row, the LDS
 //          byte offsets of its four corner rows (a trash row for corners outside this tile), flags, lw, lh.  A sample
 //          outside (-1, H) x (-1, W) gets one record without corners whose only effect is zero gradients.
-//          The items are dealt to the accumulate blocks by the plan blocks themselves: three size classes (heavy /
-//          medium / light by record count), per group of heads (= one XCD's share) one ring cursor per class in
-//          global memory; a plan block takes a range of each ring with ONE returning atomic per class (issued before
-//          pass 2, needed after it) and writes its items straight into the per-(block, class) lists.  Every class is
-//          thus spread evenly over the group's blocks -- longest-processing-time-first in three steps -- without a
-//          fence or a second pass (a sort by the group's last block was measured: 6 us for the device-scope release /
-//          acquire + 3 us for the sort); the accumulate kernel needs no level table, no prefix sums and no division.
+//          The items of a unit are stored by size class (six classes by record count, i.e. by 32-record block steps) and the unit's three
+//          counts published; nothing else crosses between plan blocks -- no atomics on global memory, no fence, nothing
+//          to initialise.  The deal is made by the accumulate blocks themselves: a prefix over the class counts of
+//          the units of a group of heads (= one XCD's share) lays all items of the group on one virtual ring, heavy
+//          ones first, and block k takes ring positions k, k + nbg, ...: longest-processing-time-first in three steps,
+//          the same for every run.  (Measured on the way: a sort by the group's last plan block costs 6 us for the
+//          device-scope release / acquire + 3 us for the sort; ring cursors in global memory need a clearing launch --
+//          hipMemsetAsync is replayed out of order inside a hipGraph on ROCm 7.2 -- that rocprofv3 shows at 4.6 us.)
 //   accum  (msda_bwd_tile_accum)  persistent blocks (256 threads, 4 per CU).  Per item: 32 records per block step, 8
 //          lanes x 4 channels per record: the grad_out row (one 128-byte gather), the corner terms w * (attn * g) added
 //          to the tile's accumulators in LDS (`ds_add_f64`), and -- in the tile that owns the sample -- the four value
@@ -40,7 +41,7 @@
 //          in-order vmcnt waits stay exact; the next item's first records are requested before the current item's steps,
 //          its first loads before the current tile is flushed.  Flush: every pixel of an unsplit tile once with 16-byte
 //          stores (no zero-fill of grad_value anywhere), each thread clearing the accumulator words it read; empty
-//          tiles are written as zeros without touching LDS; shares of split tiles add their non-zero pixels atomically.
+//          tiles are written as zeros without touching LDS; shares of split tiles store their sums to partial tiles that a small second launch (msda_bwd_fold) adds up.
 //
 // The sums are formed in double from exact products of fp32 factors (w and attn * g rounded to fp32 as in
 // the reference, cuh:117-147) and rounded to fp32 once: at least as close to the reference as an fp32
@@ -53,6 +54,7 @@
 #include <type_traits>
 
 #include "dev/stamps.h"
+#include "msda_fwd_lean.h"
 #include "msda_internal.h"
 
 #ifndef ZIRA_TILE_CAP
@@ -80,10 +82,14 @@ constexpr unsigned kTrash = kNPix * kRowBytes;   // LDS byte offset of the trash
 static_assert(kTrash < 65536, "a corner's LDS offset is 16 bits of a record");
 constexpr unsigned kAccThreads = ZIRA_TILE_THREADS;
 constexpr unsigned kPlanThreads = 1024;
-constexpr unsigned kClasses = 3;        // size classes of the deal: records >= kHeavy (and every share of a split tile), >= kMedium, the rest
-constexpr unsigned kHeavy = 256, kMedium = 64;
+constexpr unsigned kClasses = 6;        // size classes of the deal, by block steps (32 records): > 8, 5-8, 3-4, 2, 1, none (empty tiles)
+__host__ __device__ constexpr unsigned size_class(unsigned n)
+{
+    return n > 256 ? 0u : (n > 128 ? 1u : (n > 64 ? 2u : (n > 32 ? 3u : (n > 0 ? 4u : 5u))));
+}
+constexpr unsigned kUcnt = 8;           // words a unit publishes: kClasses counts, its first item slot, spare
 constexpr unsigned kNoCell = 0xFFFFFFFFu, kOutside = 0xFFFFFFFEu, kNoRank = 0xFFFFFFFFu;
-constexpr unsigned kItemAtomic = 1u << 16;   // item flag: a share of a split tile (atomic write-out)
+constexpr unsigned kItemShare = 1u << 16;    // item flag: a share of a split tile (its sums go to a partial tile of the workspace)
 // record flags
 constexpr unsigned kFlHome = 1u, kFlXStep = 2u, kFlYStep = 4u, kFl00 = 8u, kFl01 = 16u, kFl10 = 32u, kFl11 = 64u, kFlLive = 128u;
 
@@ -114,16 +120,17 @@ struct PlanGeom {
     unsigned iph;       // item slots per head: ntmax + L * ecap
     unsigned ng, hp;    // groups of heads (8: one per XCD, or 1), heads per group
     unsigned nbg;       // accumulate blocks per group
-    unsigned maxslots;  // item slots per accumulate block and size class
+    unsigned ccap;      // item slots per size class: heads * iph
     FastDivT Mdiv, NBGdiv;
 };
 
 // The plan buffer (device memory, caller-owned):
 struct PlanPtrs {
-    unsigned *ring;     // [8][4] items of a group per size class so far (zeroed by a memset in front of the plan)
+    unsigned *ucnt;     // [units][kUcnt] items of a unit per size class, and the unit's first item slot
     unsigned *scount;   // [units] split tiles of a unit
-    uint4 *usplit;      // [units * ecap]       {origin, H | W << 16, value row of pixel 0, 0} of every split tile
-    uint4 *bitems;      // [ng * nbg][kClasses][maxslots][2]  block (g, k)'s items of a class are contiguous
+    uint4 *usplit;      // [units * ecap]       {origin, H | W << 16, value row of pixel 0, first partial tile | shares << 24} of every split tile
+    float *partial;     // [units * ecap][kNPix * 32]  sums of the shares of split tiles (written by the accumulate kernel)
+    uint4 *citems;      // [kClasses][ccap][2]  items by size class, a unit's at its own slots
     uint4 *recs;        // [units * rcap][2]    records, sorted by tile inside a unit
 };
 
@@ -298,8 +305,8 @@ __device__ __forceinline__ void store_item(uint4 *dst, unsigned off, unsigned n,
 // One query per thread and pass (kOnePass: Q <= kPlanThreads, P <= 4): the cells and the ranks inside their tiles stay
 // in registers between the count and the copy-out, so the sampling locations are read once.
 template <bool kOnePass>
-__global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                                                          const float *__restrict__ loc, PlanGeom G, PlanPtrs W)
+__device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                          const float *__restrict__ loc, const PlanGeom &G, const PlanPtrs &W, const unsigned unit)
 {
     constexpr unsigned D = 32;
     extern __shared__ unsigned lds_plan[];
@@ -310,15 +317,18 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
 
     TSTAMP_DECL;
     const unsigned tid = threadIdx.x;
-    const unsigned unit = blockIdx.x;
     const unsigned h = unit / G.L, l = unit - h * G.L;
     const unsigned b = fdiv(h, G.Mdiv), m = h - b * G.M;
     const unsigned NT = tile_levels(shapes, start, G.L, lv, misc);
-    if (NT > G.ntmax) return;   // (a level table that does not tile [0, S): the group's item count stays 0, nothing is accumulated)
+    if (NT > G.ntmax) {   // (a level table that does not tile [0, S): no items, nothing is accumulated)
+        if (tid < kUcnt) W.ucnt[unit * kUcnt + tid] = 0;
+        if (tid == 0) W.scount[unit] = 0;
+        return;
+    }
     const TLevel Lv = lv[l];
     const unsigned ntl = Lv.nty * Lv.ntx;
     for (unsigned i = tid; i < ntl; i += kPlanThreads) hist[i] = 0;
-    if (tid < 8) misc[tid] = 0;
+    if (tid < 16) misc[tid] = 0;
     __syncthreads();
     TSTAMP(0);
 
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
     __syncthreads();
     TSTAMP(1);
 
-    // per tile: its work item(s) -- kept in registers until the group's ring cursors have answered
+    // per tile: its work item(s), by size class
     ItemCtx IC;
     IC.HW = (unsigned)Lv.H | ((unsigned)Lv.W << 16);
     IC.vrow = (b * G.S + Lv.st) * G.M + m;
@@ -400,29 +410,26 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
     for (unsigned r = 0; r < 4; ++r) mine[r] = tid + r * kPlanThreads < ntl ? hist[tid + r * kPlanThreads] : 0u;
     __syncthreads();
     block_scan_inplace(hist, ntl, scr);
-    unsigned ioff[4], ipos[4];   // first record; position inside the unit's share of its class ring | class << 28 | K << 20
+    unsigned ioff[4], ipos[4], islot[4];   // first record; position inside the unit's items of its class | class << 28 | K << 20; first partial tile
 #pragma unroll
     for (unsigned r = 0; r < 4; ++r) {
         const unsigned t = tid + r * kPlanThreads;
-        ioff[r] = ipos[r] = 0;
+        ioff[r] = ipos[r] = islot[r] = 0;
         if (t >= ntl) continue;
         const unsigned n = mine[r];
         unsigned K = (n + G.cap - 1) / G.cap;
         K = K < 1 ? 1u : (K > kKmax ? kKmax : K);
-        const unsigned cls = (K > 1 || n >= kHeavy) ? 0u : (n >= kMedium ? 1u : 2u);
+        const unsigned cls = size_class((n + K - 1) / K);   // (a share's size for split tiles)
         ioff[r] = rbase + hist[t];
         ipos[r] = atomicAdd(&misc[5 + cls], K) | (cls << 28) | (K << 20);
-        if (K > 1) {
+        if (K > 1) {   // split: the shares' sums go to K partial tiles of the workspace, msda_bwd_fold adds them up
             const unsigned tyy = t / Lv.ntx, txx = t - tyy * Lv.ntx;
-            const unsigned sp = atomicAdd(&misc[3], 1u);
-            if (sp < G.ecap) us[sp] = make_uint4((tyy * kTH) | ((txx * kTW) << 16), IC.HW, IC.vrow, 0u);
+            const unsigned sp = atomicAdd(&misc[3], 1u), sl = atomicAdd(&misc[4], K);
+            islot[r] = unit * G.ecap + sl;
+            if (sp < G.ecap) us[sp] = make_uint4((tyy * kTH) | ((txx * kTW) << 16), IC.HW, IC.vrow, islot[r] | (K << 24));
         }
     }
     __syncthreads();
-    // this unit's range of each class ring of its group: one returning atomic per class, answered during pass 2
-    const unsigned g = G.ng > 1 ? h / G.hp : 0u;
-    unsigned ring_base = 0;
-    if (tid < kClasses) ring_base = atomicAdd(&W.ring[g * 4 + tid], misc[5 + tid]);
     TSTAMP(2);
 
     // pass 2: the records, tile by tile
@@ -478,12 +485,11 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
     }
     TSTAMP(3);
     if (tid == 0) W.scount[unit] = misc[3] < G.ecap ? misc[3] : G.ecap;
-    if (tid < kClasses) misc[8 + tid] = ring_base;
-    __syncthreads();
+    const unsigned ubase = h * G.iph + Lv.tbase + l * G.ecap;   // this unit's item slots (in each class array)
+    if (tid < kClasses) W.ucnt[unit * kUcnt + tid] = misc[5 + tid];
+    if (tid == kClasses) W.ucnt[unit * kUcnt + kClasses] = ubase;
     TSTAMP(4);
-    // the items, straight into the lists of the accumulate blocks: ring position r of class c -> block r mod nbg
-    // (classes run in alternating directions, so that the blocks that got one item more of a class get one less of
-    // the next), slot r / nbg
+    // the items, by class, in the unit's own slots
 #pragma unroll
     for (unsigned r = 0; r < 4; ++r) {
         const unsigned t = tid + r * kPlanThreads;
@@ -492,13 +498,12 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
         const unsigned tyy = t / Lv.ntx, txx = t - tyy * Lv.ntx;
         const unsigned org = (tyy * kTH) | ((txx * kTW) << 16);
         for (unsigned k = 0; k < K; ++k) {
-            const unsigned rr = misc[8 + cls] + (ipos[r] & 0xFFFFFu) + k;
-            const unsigned slot = fdiv(rr, G.NBGdiv), pos = rr - slot * G.nbg;
-            const unsigned blk = (cls & 1u) ? G.nbg - 1 - pos : pos;
-            if (slot >= G.maxslots) continue;   // (cannot happen: maxslots bounds a group's items per block)
-            uint4 *dst = W.bitems + ((((size_t)g * G.nbg + blk) * kClasses + cls) * G.maxslots + slot) * 2;
+            const unsigned rr = ubase + (ipos[r] & 0xFFFFFu) + k;
+            if (rr >= G.ccap) continue;   // (cannot happen: a unit has ntl + ecap slots)
+            uint4 *dst = W.citems + ((size_t)cls * G.ccap + rr) * 2;
             const unsigned e0 = (unsigned)(((unsigned long long)n * k) / K), e1 = (unsigned)(((unsigned long long)n * (k + 1)) / K);
-            store_item(dst, ioff[r] + e0, e1 - e0, org, IC, K > 1 ? kItemAtomic : 0u);
+            IC.unit = K > 1 ? islot[r] + k : 0u;   // (word b.w of a share: its partial tile)
+            store_item(dst, ioff[r] + e0, e1 - e0, org, IC, K > 1 ? kItemShare : 0u);
         }
     }
     TSTAMP(5);
@@ -506,29 +511,73 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
     PSTAMP_FLUSH;
 }
 
-// The ring cursors and split-tile counts start at zero.  (A kernel, not hipMemsetAsync: inside a captured hipGraph the
-// memset node of ROCm 7.2 was found to run out of order with the kernels around it -- the replayed plan then counted
-// from stale cursors.)
-__global__ __launch_bounds__(256) void msda_plan_clear(unsigned *__restrict__ ctl, unsigned words)
+template <bool kOnePass>
+__global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                                          const float *__restrict__ loc, PlanGeom G, PlanPtrs W)
 {
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) ctl[i] = 0u;
+    plan_unit<kOnePass>(shapes, start, loc, G, W, blockIdx.x);
 }
 
-// The pixels of split tiles start at zero: their shares meet through fp32 atomics.  Two blocks per unit.
-__global__ __launch_bounds__(256) void msda_bwd_zero_split(PlanGeom G, const unsigned *__restrict__ scount,
-                                                           const uint4 *__restrict__ usplit, float *__restrict__ grad_value)
+// Forward gather + plan in ONE launch (zira_msda_fwd_plan_f32): the first `units8` blocks plan a (head, level) unit each
+// (they are the long pole and start first), the others run the forward of 16 (b, q, m) items each, one per wave, exactly
+// as msda_fwd_lean does (csrc/msda_fwd_lean.h).  Two kernels on two streams do not overlap here -- neither eagerly (the
+// forward's waves fill every register file before a 1024-thread plan block fits) nor as branches of a replayed hipGraph
+// (measured: 36.5 us = the sum) -- while one grid does: the plan runs on 64 CUs beside the gather.  Keeping the kernel within
+// the forward's 64 registers (two-pass plan, 84 bytes of scratch per lane) was measured at 24.4 us for the call; with the
+// plan's 100 registers and one forward block per CU 19.0 us.
+#ifndef ZIRA_FUSED_WAVES
+#define ZIRA_FUSED_WAVES 4   // (no register cap below the one-pass plan's 100: spilling it costs 5 us)
+#endif
+#ifndef ZIRA_FUSED_ONEPASS
+#define ZIRA_FUSED_ONEPASS 1
+#endif
+__global__ __launch_bounds__(kPlanThreads, ZIRA_FUSED_WAVES) void msda_fwd_plan(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+    const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, FastDiv Mdiv, unsigned LP, FastDiv Qdiv,
+    float invP, unsigned nitems, unsigned per_xcd, float *__restrict__ out, PlanGeom G, PlanPtrs W, unsigned units,
+    unsigned units8, unsigned onepass)
+{
+    if (blockIdx.x < units8) {
+        if (blockIdx.x < units) {
+            if (onepass) plan_unit<true>(shapes, start, loc, G, W, blockIdx.x);
+            else plan_unit<false>(shapes, start, loc, G, W, blockIdx.x);
+        }
+        return;
+    }
+    // (the plan's registers -- 100 against the forward's 64 -- leave room for ONE such block per CU; two items per wave with
+    // interleaved gathers were measured and lost: 20.6 against 19.0 us for the call)
+    const ItemId id = lean_item(nitems, per_xcd, Qdiv, Mdiv, blockIdx.x - units8, kPlanThreads / 64);
+    if (!id.ok) return;  // wave-uniform
+    fwd_lean_item<2>(value, shapes, start, loc, attn, S, Mdiv.d, LP, invP, id, out);
+}
+
+// The shares of a split tile leave their sums in partial tiles of the workspace (plain stores); this adds them up in
+// a fixed order and writes the tile's pixels -- no atomics, no zero-fill, the same result in every run.  (Round 3 and
+// the first round-4 version let the shares meet through fp32 atomics on pre-zeroed pixels: a share's 4096 atomics sit
+// in the same in-order memory queue as the next item's loads -- with 160-record shares the kernel took 46 instead of 28 us.)
+// kFoldParts blocks per unit.
+constexpr unsigned kFoldParts = 16;
+__global__ __launch_bounds__(256) void msda_bwd_fold(PlanGeom G, const unsigned *__restrict__ scount, const uint4 *__restrict__ usplit,
+                                                     const float *__restrict__ partial, float *__restrict__ grad_value)
 {
     constexpr unsigned D = 32;
-    const unsigned unit = blockIdx.x >> 1, part = blockIdx.x & 1u;
+    const unsigned unit = blockIdx.x / kFoldParts, part = blockIdx.x % kFoldParts;
     const unsigned ns = scount[unit] < G.ecap ? scount[unit] : G.ecap;
-    for (unsigned s = part; s < ns; s += 2) {
+    for (unsigned s = part; s < ns; s += kFoldParts) {
         const uint4 e = usplit[(size_t)unit * G.ecap + s];
         const unsigned ty0 = e.x & 0xFFFFu, tx0 = e.x >> 16, H = e.y & 0xFFFFu, Wd = e.y >> 16;
+        const unsigned slot = e.w & 0xFFFFFFu, K = e.w >> 24;
+        const float4 *src = reinterpret_cast<const float4 *>(partial + (size_t)slot * kNPix * D);
         for (unsigned i = threadIdx.x; i < kNPix * (D / 4); i += 256) {
+            float4 a = src[i];
+            for (unsigned k = 1; k < K; ++k) {
+                const float4 b = src[(size_t)k * kNPix * (D / 4) + i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
             const unsigned c4 = i % (D / 4), pix = i / (D / 4);
             const unsigned y = ty0 + pix / kTW, x = tx0 + pix % kTW;
             if (y < H && x < Wd)
-                *reinterpret_cast<float4 *>(grad_value + ((size_t)e.z + (size_t)(y * Wd + x) * G.M) * D + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(grad_value + ((size_t)e.z + (size_t)(y * Wd + x) * G.M) * D + c4 * 4) = a;
         }
     }
 }
@@ -575,7 +624,7 @@ struct Ld {
 // a work item: a tile or a share of a split tile; everything block-uniform (scalar registers)
 struct Item {
     unsigned n, ty0, tx0, the, twe, H, W;
-    unsigned atomic;      // a share of a split tile: atomic write-out
+    unsigned share, slot; // a share of a split tile: its sums go to partial tile `slot` of the workspace
     unsigned hq;          // item index of query 0 of the head: b * Q * M + m
     size_t voff;          // float offset of the level's pixel 0, this head, in value / grad_value
     size_t roff;          // first record
@@ -591,8 +640,9 @@ __device__ __forceinline__ T ldg(const void *base, unsigned byte_off)   // scala
 
 __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd_tile_accum(
     const float *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ attn, PlanGeom G,
-    const unsigned *__restrict__ ring, const uint4 *__restrict__ bitems, const uint4 *__restrict__ recs,
-    float *__restrict__ dump, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+    const unsigned *__restrict__ ucnt, const uint4 *__restrict__ citems, const uint4 *__restrict__ recs,
+    float *__restrict__ dump, float *__restrict__ partial, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attn)
 {
     constexpr unsigned D = 32, LPS = 8, NTHR = kAccThreads, NW = NTHR / 64, NG = 8;
     constexpr unsigned SPB = NW * NG;     // records per block step
@@ -602,32 +652,71 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
     TSTAMP_DECL;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned grp = lane / LPS, j = lane % LPS;
-    const unsigned odd = grp & 1;
     // this block's list of items (group g = the heads whose value slices this XCD keeps in its L2; placement is for speed only)
     const unsigned g = G.ng > 1 ? blockIdx.x & 7u : 0u, k = G.ng > 1 ? blockIdx.x >> 3 : blockIdx.x;
-    unsigned cn[kClasses], cnt = 0;   // this block's items per size class
-#pragma unroll
-    for (unsigned c = 0; c < kClasses; ++c) {
-        const unsigned N = uni(ring[g * 4 + c]);
-        const unsigned full = fdiv(N, G.NBGdiv), rem = N - full * G.nbg;
-        cn[c] = full + ((((c & 1u) ? G.nbg - 1 - k : k) < rem) ? 1u : 0u);
-        cn[c] = cn[c] < G.maxslots ? cn[c] : G.maxslots;
-        cnt += cn[c];
+    // This block's items.  The units of the group (nug of them) publish three class counts each; laid end to end --
+    // class-major, so heavy items first -- they form one ring, and block k takes positions k, k + nbg, ...
+    unsigned *tab = reinterpret_cast<unsigned *>(acc + (kNPix + 1) * D);   // [3 nug] prefix, then [nug] first item slot of the unit
+    const unsigned h0 = g * G.hp;
+    const unsigned nug = (G.heads - h0 < G.hp ? G.heads - h0 : G.hp) * G.L, ne = kClasses * nug;
+    if (G.ng > 1 && h0 >= G.heads) return;
+    for (unsigned e = tid; e < ne; e += NTHR) {
+        const unsigned c = e / nug, u = e - c * nug;
+        tab[e] = ucnt[(h0 * G.L + u) * kUcnt + c];
     }
+    for (unsigned u = tid; u < nug; u += NTHR) tab[ne + u] = ucnt[(h0 * G.L + u) * kUcnt + kClasses];
+    __syncthreads();
+    if (wave == 0) {   // exclusive prefix over the ne counts, 64 at a time
+        unsigned run = 0;
+        for (unsigned e0 = 0; e0 < ne; e0 += 64) {
+            const unsigned v = e0 + lane < ne ? tab[e0 + lane] : 0u;
+            unsigned incl = v;
+#pragma unroll
+            for (unsigned d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (e0 + lane < ne) tab[e0 + lane] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) tab[ne + nug] = run;
+    }
+    __syncthreads();
+    const unsigned total = uni(tab[ne + nug]);
+    const unsigned cnt = total > k ? fdiv(total - k - 1, G.NBGdiv) + 1 : 0u;
     if (cnt == 0) return;
-    const uint4 *my = bitems + (size_t)(g * G.nbg + k) * kClasses * G.maxslots * 2;
+    const unsigned pre_l = lane < ne ? tab[lane] : 0xFFFFFFFFu;   // (the common case: ne <= 64, the whole prefix in one wave's lanes)
+    __syncthreads();   // (tab is read; below it is only touched again through load_hdr's reads)
     for (unsigned x = tid; x < (kNPix + 1) * D / 2; x += NTHR) reinterpret_cast<uint4 *>(acc)[x] = make_uint4(0u, 0u, 0u, 0u);
 
     const unsigned rs = G.M * D;                  // floats between pixels
     const unsigned gsel = wave * NG + grp;        // this group's record inside a block step
-    // accumulator word kk * 8 + j holds channel 4 j + kk; the odd group of a 16-lane row swaps kk 0 <-> 1 and 2 <-> 3 so
-    // that its eight 8-byte words fall into the other half of the banks
-    const unsigned lb0 = (j + (odd ? 8u : 0u)) * 8u, lb1 = (j + (odd ? 0u : 8u)) * 8u;
+    // Channel 4 j + kk of an accumulator row lives in word kk * 8 + j: a group's 8 lanes add to 8 consecutive words, the
+    // fast pattern for ds_add_f64 (measured against it, whole kernel: word (kk >> 1) * 16 + 2 j + (kk & 1), a lane's
+    // channel pairs adjacent, 37.4 against 33.7 us; word 4 j + kk, a lane's four channels contiguous, 59 us).  The
+    // write-out gathers a lane's four channels with four 8-byte reads 64 bytes apart.
+    const unsigned odd = grp & 1u;
+    constexpr unsigned kAccWord[4] = {0u, 8u, 16u, 24u}, kSwap = 1;   // odd groups: kk 0 <-> 1, 2 <-> 3 (the other 64 bytes)
+    const unsigned lb = j * 8u;
+    unsigned lbk[4];   // byte offset inside a row of the word this lane's add number kk goes to
+#pragma unroll
+    for (unsigned kk = 0; kk < 4; ++kk) lbk[kk] = lb + (odd ? kAccWord[kk ^ kSwap] : kAccWord[kk]) * 8u;
 
-    auto load_hdr = [&](unsigned i) {   // item i of this block: heavy ones first
-        const unsigned c = i < cn[0] ? 0u : (i < cn[0] + cn[1] ? 1u : 2u);
-        const unsigned sl = i - (c > 0 ? cn[0] : 0u) - (c > 1 ? cn[1] : 0u);
-        const uint4 *p = my + ((size_t)c * G.maxslots + sl) * 2;
+    auto load_hdr = [&](unsigned i) {   // item i of this block: ring position k + i nbg -> (class, unit, position in the unit's class items)
+        const unsigned r = k + i * G.nbg;
+        unsigned e;
+        if (ne <= 64) {
+            e = (unsigned)__popcll(__ballot(pre_l <= r)) - 1u;
+        } else {
+            e = 0;
+            for (unsigned e0 = 0; e0 < ne; e0 += 64)
+                e += (unsigned)__popcll(__ballot(e0 + lane < ne && tab[e0 + lane] <= r));
+            e -= 1u;
+        }
+        e = uni(e);
+        const unsigned c = e / nug, u = e - c * nug;
+        const unsigned idx = uni(tab[ne + u]) + (r - uni(tab[e]));
+        const uint4 *p = citems + ((size_t)c * G.ccap + idx) * 2;
         Hdr h;
         h.a = p[0];
         h.b = p[1];
@@ -638,7 +727,8 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
         const unsigned off = uni(hd.a.x), org = uni(hd.a.z), hw = uni(hd.a.w), vrow = uni(hd.b.x);
         it.n = uni(hd.a.y);
         it.hq = uni(hd.b.y);
-        it.atomic = uni(hd.b.z) & kItemAtomic;
+        it.share = uni(hd.b.z) & kItemShare;
+        it.slot = uni(hd.b.w);
         it.ty0 = org & 0xFFFFu;
         it.tx0 = org >> 16;
         it.H = hw & 0xFFFFu;
@@ -715,19 +805,20 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
                 make_float2(__fmul_rn(__fmul_rn((float)it.W, a), gx), __fmul_rn(__fmul_rn((float)it.H, a), gy));
         }
         // corner rows: term = w * (a * g), both factors rounded to fp32 as the reference forms them, the product
-        // and the sum in double
-        const float gs0 = odd ? g4.y : g4.x, gs1 = odd ? g4.x : g4.y, gs2 = odd ? g4.w : g4.z, gs3 = odd ? g4.z : g4.w;
-        const double tt[4] = {(double)__fmul_rn(gs0, a), (double)__fmul_rn(gs1, a), (double)__fmul_rn(gs2, a),
-                              (double)__fmul_rn(gs3, a)};
+        // and the sum in double.  Layout of an accumulator row (32 words of 8 bytes): see kAccLayout.
+        // The two groups of a 16-lane LDS row issue their four adds in different orders (kk ^ swap), so that one
+        // instruction finds them in different halves of the banks (steps alone 33.4 -> 28.4 us).
+        const float gs[4] = {odd ? g4.y : g4.x, odd ? g4.x : g4.y, odd ? g4.w : g4.z, odd ? g4.z : g4.w};
+        const double tt[4] = {(double)__fmul_rn(gs[0], a), (double)__fmul_rn(gs[1], a), (double)__fmul_rn(gs[2], a),
+                              (double)__fmul_rn(gs[3], a)};
         const double wc[4] = {(double)w00, (double)w01, (double)w10, (double)w11};
         const unsigned oc[4] = {d.o01 & 0xFFFFu, d.o01 >> 16, d.o23 & 0xFFFFu, d.o23 >> 16};
 #pragma unroll
         for (unsigned cc = 0; cc < 4; ++cc) {
             char *ap = reinterpret_cast<char *>(acc) + oc[cc];
-            atomicAdd(reinterpret_cast<double *>(ap + lb0), wc[cc] * tt[0]);
-            atomicAdd(reinterpret_cast<double *>(ap + lb1), wc[cc] * tt[1]);
-            atomicAdd(reinterpret_cast<double *>(ap + lb0 + 128), wc[cc] * tt[2]);
-            atomicAdd(reinterpret_cast<double *>(ap + lb1 + 128), wc[cc] * tt[3]);
+#pragma unroll
+            for (unsigned kk = 0; kk < 4; ++kk)   // (tt[kk] belongs to channel 4 j + (kk ^ swap) in the odd groups)
+                atomicAdd(reinterpret_cast<double *>(ap + lbk[kk]), wc[cc] * tt[kk]);
         }
     };
 
@@ -771,45 +862,40 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
         TSTAMP(2);
 
         // ---- write-out (each thread clears the accumulator words it reads) -------------------------------
-        // The tile is read linearly, 16 bytes per lane and instruction (no bank conflicts: a wave reads four whole
-        // rows): thread t gets words 2 (t & 15), + 1 of row 16 i + (t >> 4) in round i, i.e. channels c0 and c0 + 4 of
-        // that pixel (word kk * 8 + j holds channel 4 j + kk); a wave's two 4-byte stores complete its four 128-byte rows.
+        // Thread t gets channels 4 (t & 7) .. + 3 of pixel 32 i + (t >> 3) in round i and stores them with one 16-byte
+        // store -- a wave writes eight whole 128-byte rows (4-byte stores of a bank-conflict-free linear read of the tile
+        // were measured first: the write-out alone 20.8 against 12.1 us).
         {
-            constexpr unsigned RPR = NTHR / 16, NR = kNPix / RPR;        // tile rows (pixels) per round, rounds
-            static_assert(RPR % kTW == 0 || kTW % RPR == 0, "a round covers whole pixel rows or a part of one");
-            const unsigned w0 = 2u * (tid & 15u), c0 = 4u * (w0 & 7u) + (w0 >> 3);
-            const unsigned p0 = tid >> 4;                                 // pixel of round 0 (then + RPR per round)
+            constexpr unsigned PPR = NTHR / 8, NR = kNPix / PPR;          // pixels per round, rounds
+            static_assert(PPR % kTW == 0, "a round covers whole pixel rows");
+            const unsigned c4 = tid & 7u, p0 = tid >> 3;                  // channel quad, pixel of round 0 (then + PPR per round)
             const unsigned pc = p0 % kTW, pr0 = p0 / kTW;
             const bool colin = pc < it.twe;
-            float *gbase = grad_value + it.voff + ((size_t)(it.ty0 + pr0) * it.W + (it.tx0 + pc)) * rs + c0;
-            const size_t rstep = (size_t)(RPR / kTW) * it.W * rs;
-            static_assert(RPR >= kTW, "rounds advance by whole pixel rows");
-            double2 *lp = reinterpret_cast<double2 *>(acc) + tid;
-            if (!it.atomic) {   // every pixel of the tile once, plain stores (grad_value is never zero-filled)
+            float *gbase = grad_value + it.voff + ((size_t)(it.ty0 + pr0) * it.W + (it.tx0 + pc)) * rs + c4 * 4;
+            const size_t rstep = (size_t)(PPR / kTW) * it.W * rs;
+            // (thread t: pixel row (t >> 3) of the round, channel quad t & 7)
+            char *lp = reinterpret_cast<char *>(acc) + (tid >> 3) * kRowBytes + (tid & 7u) * 8u;
+            constexpr unsigned kRound = PPR * kRowBytes;
+            auto take4 = [&](unsigned i) {   // read this thread's four channels of round i and clear them
+                char *q = lp + i * kRound;
+                float4 o;
+                double *w = reinterpret_cast<double *>(q);
+                o = make_float4((float)w[0], (float)w[8], (float)w[16], (float)w[24]);
+                w[0] = 0.0; w[8] = 0.0; w[16] = 0.0; w[24] = 0.0;
+                return o;
+            };
+            if (!it.share) {   // every pixel of the tile once, plain stores (grad_value is never zero-filled)
 #pragma unroll
                 for (unsigned i = 0; i < NR; ++i) {
-                    float o0 = 0.f, o1 = 0.f;
-                    if (it.n) {
-                        const double2 v = lp[i * NTHR];
-                        lp[i * NTHR] = make_double2(0.0, 0.0);
-                        o0 = (float)v.x;
-                        o1 = (float)v.y;
-                    }
-                    float *dst = (colin && (RPR / kTW) * i + pr0 < it.the) ? gbase + i * rstep : dump + 192 + 4 * lane;   // (pixels of an edge tile outside the map)
-                    dst[0] = o0;
-                    dst[4] = o1;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (it.n) o = take4(i);
+                    float *dst = (colin && (PPR / kTW) * i + pr0 < it.the) ? gbase + i * rstep : dump + 192 + 4 * lane;   // (pixels of an edge tile outside the map)
+                    *reinterpret_cast<float4 *>(dst) = o;
                 }
-            } else {            // a share of a split tile: its non-zero values are added to rows msda_bwd_zero_split zeroed
+            } else {            // a share of a split tile: the whole tile, as it is, to its partial tile (msda_bwd_fold adds the shares up)
+                float *pb = partial + (size_t)it.slot * kNPix * D + (size_t)p0 * D + c4 * 4;
 #pragma unroll
-                for (unsigned i = 0; i < NR; ++i) {
-                    const double2 v = lp[i * NTHR];
-                    lp[i * NTHR] = make_double2(0.0, 0.0);
-                    const float o0 = (float)v.x, o1 = (float)v.y;
-                    if (colin && (RPR / kTW) * i + pr0 < it.the) {
-                        if (o0 != 0.f) unsafeAtomicAdd(gbase + i * rstep, o0);
-                        if (o1 != 0.f) unsafeAtomicAdd(gbase + i * rstep + 4, o1);
-                    }
-                }
+                for (unsigned i = 0; i < NR; ++i) *reinterpret_cast<float4 *>(pb + (size_t)i * PPR * D) = take4(i);
             }
         }
         if (it.n) __syncthreads();   // the tile is clear again before the next item adds to it
@@ -826,7 +912,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TilesLayout {
     PlanGeom G;
-    size_t ctl_bytes, off_usplit, off_bitems, off_dump, off_recs, total;
+    size_t ctl_bytes, off_usplit, off_citems, off_dump, off_recs, off_partial, total;
     bool one_pass;
     size_t lds_plan, lds_acc;
     unsigned units, grid;
@@ -874,20 +960,24 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     if (G.ng > 1) T.grid &= ~7u;
     if (T.grid < G.ng) return false;
     G.nbg = T.grid / G.ng;
-    G.maxslots = (unsigned)(((unsigned long long)G.hp * G.iph + G.nbg - 1) / G.nbg) + 1;
+    if (heads * G.iph >= (1ull << 28)) return false;
+    G.ccap = (unsigned)(heads * G.iph);
+    if ((unsigned long long)G.hp * L * (kClasses + 1) + 1 > 1024) return false;   // (the deal's prefix table lives in LDS beside the tile)
     G.Mdiv = make_fdiv((unsigned)M);
     G.NBGdiv = make_fdiv(G.nbg);
     T.lds_plan = (kTLevelWords * kTMaxLevels + 16 + kPlanThreads / 64 + 1 + G.ntmax) * 4;
     if (T.lds_plan > 64 * 1024) return false;
-    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8;
+    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + ((size_t)G.hp * L * (kClasses + 1) + 1) * 4;
     T.one_pass = (unsigned)Q <= kPlanThreads && P <= 4;
     size_t o = 0;
-    T.ctl_bytes = align256(128 + (size_t)T.units * 4);   // ring[8][4], scount[units]
+    T.ctl_bytes = align256((size_t)T.units * (kUcnt + 1) * 4);   // ucnt[units][kUcnt], scount[units]
     o += T.ctl_bytes;
     T.off_usplit = o; o += align256((size_t)T.units * G.ecap * 16);
-    T.off_bitems = o; o += align256((size_t)T.grid * kClasses * G.maxslots * 32);
+    T.off_citems = o; o += align256((size_t)kClasses * G.ccap * 32);
     T.off_dump = o;   o += 2048;                                            // where redirected stores go (never read)
     T.off_recs = o;   o += align256((size_t)T.units * G.rcap * 32) + 256;   // (+ pad: record 0 of an empty tail item)
+    if ((unsigned long long)T.units * G.ecap >= (1ull << 24)) return false;   // 24-bit partial-tile index
+    T.off_partial = o; o += align256((size_t)T.units * G.ecap * kNPix * 32 * 4);   // (worst case; what is touched is one 16 KB tile per share)
     T.total = o;
     return true;
 }
@@ -896,10 +986,11 @@ inline PlanPtrs plan_ptrs(const TilesLayout &T, void *plan)
 {
     char *w = reinterpret_cast<char *>(plan);
     PlanPtrs W;
-    W.ring = reinterpret_cast<unsigned *>(w);
-    W.scount = W.ring + 32;
+    W.ucnt = reinterpret_cast<unsigned *>(w);
+    W.scount = W.ucnt + (size_t)T.units * kUcnt;
     W.usplit = reinterpret_cast<uint4 *>(w + T.off_usplit);
-    W.bitems = reinterpret_cast<uint4 *>(w + T.off_bitems);
+    W.partial = reinterpret_cast<float *>(w + T.off_partial);
+    W.citems = reinterpret_cast<uint4 *>(w + T.off_citems);
     W.recs = reinterpret_cast<uint4 *>(w + T.off_recs);
     return W;
 }
@@ -919,13 +1010,26 @@ int tiles_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc
     TilesLayout T;
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
     const PlanPtrs W = plan_ptrs(T, plan);
-    hipLaunchKernelGGL(msda_plan_clear, dim3(1), dim3(256), 0, st, reinterpret_cast<unsigned *>(plan), (unsigned)(T.ctl_bytes / 4));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
     if (T.one_pass)
         hipLaunchKernelGGL(msda_plan<true>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, T.G, W);
     else
         hipLaunchKernelGGL(msda_plan<false>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, T.G, W);
+    return (int)hipGetLastError();
+}
+
+int tiles_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t *start, const float *loc, const float *attn,
+                       int B, int S, int M, int D, int L, int Q, int P, float *out, void *plan, size_t plan_bytes, hipStream_t st)
+{
+    TilesLayout T;
+    if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
+    if ((unsigned long long)B * Q * M >= (1ull << 31) || L * P > 64) return -1;
+    const PlanPtrs W = plan_ptrs(T, plan);
+    const unsigned nitems = (unsigned)B * Q * M, per = (nitems + 7) >> 3, wpb = kPlanThreads / 64;
+    const unsigned units8 = (T.units + 7) & ~7u;
+    const unsigned grid = units8 + 8 * ((per + wpb - 1) / wpb);
+    hipLaunchKernelGGL(msda_fwd_plan, dim3(grid), dim3(kPlanThreads), T.lds_plan, st, value, shapes, start, loc, attn, (unsigned)S,
+                       make_fast_div((unsigned)M), (unsigned)(L * P), make_fast_div((unsigned)Q), 1.0f / (float)P, nitems, per,
+                       out, T.G, W, T.units, units8, (T.one_pass && ZIRA_FUSED_ONEPASS) ? 1u : 0u);
     return (int)hipGetLastError();
 }
 
@@ -936,12 +1040,12 @@ int tiles_backward_planned_f32(const float *grad_out, const float *value, const 
     TilesLayout T;
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
     const PlanPtrs W = plan_ptrs(T, const_cast<void *>(plan));
-    hipLaunchKernelGGL(msda_bwd_zero_split, dim3(T.units * 2), dim3(256), 0, st, T.G, W.scount, W.usplit, gv);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<void *>(plan)) + T.off_dump);
     hipLaunchKernelGGL(msda_bwd_tile_accum, dim3(T.grid), dim3(kAccThreads), T.lds_acc, st, grad_out, value, attn, T.G,
-                       W.ring, W.bitems, W.recs, dump, gv, gl, ga);
+                       W.ucnt, W.citems, W.recs, dump, W.partial, gv, gl, ga);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(msda_bwd_fold, dim3(T.units * kFoldParts), dim3(256), 0, st, T.G, W.scount, W.usplit, W.partial, gv);
     return (int)hipGetLastError();
 }
 

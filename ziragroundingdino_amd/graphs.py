@@ -209,13 +209,48 @@ class GraphedTransformer:
         self.transformer = transformer
         self.max_signatures = max_signatures
         self._cache = {}
+        self._eager_keys = set()     # signatures whose capture was refused: they run eagerly from then on
+        self._versions = None
+
+    def _refresh_derived_weights(self):
+        """A replay re-runs no Python, so buffers DERIVED from parameters (the MSDA modules' concatenated query
+        projection) must follow in-place changes of those parameters (``copy_``, ``load_state_dict`` into a live model)
+        here: cheap version check per call, refresh in place when anything moved."""
+        params = getattr(self, "_params", None)
+        if params is None:
+            params = self._params = list(self.transformer.parameters())
+        ver = sum(p._version for p in params)
+        if ver != self._versions:
+            if self._versions is not None:
+                for m in self.transformer.modules():
+                    if hasattr(m, "refresh_fused_projection"):
+                        m.refresh_fused_projection()
+            self._versions = ver
+
+    def _capture(self, piece, args, shared, key):
+        """``_graph`` with a way out: a refused capture (out of memory for the private pools, an op that cannot be
+        captured, another thread touching the GPU during a global-mode capture) must not end a task -- the signature
+        is marked eager, logged once, and the piece runs uncaptured in this same process."""
+        if key in self._eager_keys:
+            return piece
+        try:
+            return _graph(piece, args, shared)
+        except Exception as exc:   # noqa: BLE001 -- whatever the capture raised
+            if torch.cuda.is_current_stream_capturing():
+                raise              # (still inside a capture: nothing sane can run on this stream)
+            torch.cuda.synchronize()
+            self._eager_keys.add(key)
+            print("[GraphedTransformer] hipGraph capture refused (%s: %s); this input signature runs eagerly"
+                  % (type(exc).__name__, str(exc).splitlines()[0] if str(exc) else ""), flush=True)
+            return piece
 
     def __call__(self, srcs, masks, poss, text_dict, no_padding=False):
         t = self.transformer
         key = (tuple((tuple(x.shape), x.requires_grad) for x in srcs),
                tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad, bool(no_padding),
                torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))   # a capture bakes the dtype path in
-        if key not in self._cache and len(self._cache) >= self.max_signatures:
+        self._refresh_derived_weights()
+        if key in self._eager_keys or (key not in self._cache and len(self._cache) >= self.max_signatures):
             hs, refs, hs_enc, ref_enc, init_box, _ = t(srcs, masks, None, poss, None, None, text_dict,
                                                        no_padding=no_padding)
             return hs, refs, hs_enc, ref_enc, init_box
@@ -243,7 +278,7 @@ class GraphedTransformer:
             if enc.fusion_layers and self.graph_fusion:   # one graph pair per block (developer switch)
                 fargs = (output, memory_text, mask_flat, text_attention_mask)
                 if len(entry["fusion"]) <= i:
-                    entry["fusion"].append(_graph(_FusionPiece(enc.fusion_layers[i], no_padding), fargs))
+                    entry["fusion"].append(self._capture(_FusionPiece(enc.fusion_layers[i], no_padding), fargs, (), key))
                 output, memory_text = entry["fusion"][i](*fargs)
             elif enc.fusion_layers:  # eager: graphs with several BiAttention blocks fault on replay (see class doc)
                 output, memory_text = enc.fusion_layers[i](v=output, l=memory_text,
@@ -253,7 +288,7 @@ class GraphedTransformer:
                     pos_text, tsm)
             if len(entry["layers"]) <= i:
                 piece = _EncoderLayerPiece(enc, i, spatial_shapes, level_start_index, no_padding)
-                entry["layers"].append(_graph(piece, args, shared) if self.graph_encoder else piece)
+                entry["layers"].append(self._capture(piece, args, shared, key) if self.graph_encoder else piece)
             output, memory_text = entry["layers"][i](*args)
         text_dict["encoded_text"] = memory_text
 
@@ -263,14 +298,14 @@ class GraphedTransformer:
                     text_dict["text_token_mask"])
             if entry["decode"] is None:
                 piece = _DecoderPiece(t, spatial_shapes, level_start_index, no_padding)
-                entry["decode"] = (_graph(piece, args, shared) if self.graph_decoder else piece, piece)
+                entry["decode"] = (self._capture(piece, args, shared, key) if self.graph_decoder else piece, piece)
             graphed, piece = entry["decode"]
             out = graphed(*args)
             return list(out[:piece.n_hs]), list(out[piece.n_hs:]), hs_enc, ref_enc, init_box
         args = (output, memory_text, mask_flat, lvl_pos, valid_ratios, text_dict["text_token_mask"])
         if entry["decode"] is None:
             piece = _SelectDecodePiece(t, shapes, spatial_shapes, level_start_index, no_padding)
-            entry["decode"] = (_graph(piece, args, shared) if self.graph_decoder else piece, piece)
+            entry["decode"] = (self._capture(piece, args, shared, key) if self.graph_decoder else piece, piece)
         graphed, piece = entry["decode"]
         out = graphed(*args)
         nh, nr = piece.n_hs, piece.n_refs

@@ -37,12 +37,16 @@ class MultiScaleDeformableAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
-        output = _C.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                           sampling_locations, attention_weights, im2col_step)
-        # how the backward is cut into tiles depends on the sampling locations only: planned here, off the backward's
-        # critical path (None for CPU tensors, dense calls or when nothing needs a gradient)
-        ctx.plan = _C.ms_deform_attn_plan(value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                                          im2col_step) if any(ctx.needs_input_grad) else None
+        # How the backward is cut into tiles depends on the sampling locations only: for sparse GPU calls (decoder
+        # cross-attention) that plan is made here, in the forward's own launch, off the backward's critical path.
+        ctx.plan = None
+        if any(ctx.needs_input_grad) and _C.plan_applies(value, value_spatial_shapes, value_level_start_index,
+                                                        sampling_locations, im2col_step):
+            output, ctx.plan = _C.ms_deform_attn_forward_plan(value, value_spatial_shapes, value_level_start_index,
+                                                             sampling_locations, attention_weights, im2col_step)
+        else:
+            output = _C.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                               sampling_locations, attention_weights, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output
@@ -235,6 +239,7 @@ class MultiScaleDeformableAttention(nn.Module):
         self.value_proj = nn.Linear(embed_dim, embed_dim)
         self.output_proj = nn.Linear(embed_dim, embed_dim)
         self.init_weights()
+        self.register_load_state_dict_post_hook(MultiScaleDeformableAttention.refresh_fused_projection)
 
     def _reset_parameters(self):
         return self.init_weights()
@@ -267,6 +272,13 @@ class MultiScaleDeformableAttention(nn.Module):
         self.attention_weights.weight.requires_grad = False
         self.attention_weights.bias.requires_grad = False
 
+    def refresh_fused_projection(self, *unused):
+        """Bring the concatenated copy of the two query projections up to date (in place).  Runs after every
+        ``load_state_dict`` (post-hook registered in ``__init__``); ``GraphedTransformer`` also calls it when a parameter
+        version changed, because a graph replay skips the Python code that would notice."""
+        if getattr(self, "_fused_qp", None) is not None:
+            self._fused_query_projection()
+
     fuse_query_projections = True   # class-level switch (tests compare both ways)
     fuse_sampling_plan = True       # ... softmax + sampling locations in one native launch each way (needs the fused projection)
 
@@ -283,8 +295,19 @@ class MultiScaleDeformableAttention(nn.Module):
         cached = getattr(self, "_fused_qp", None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                w = torch.cat([so.weight, aw.weight], 0).contiguous()
-                b = torch.cat([so.bias, aw.bias], 0).contiguous()
+                n1 = so.weight.shape[0]
+                if (cached is not None and cached[1].device == so.weight.device and cached[1].dtype == so.weight.dtype
+                        and cached[1].shape[0] == n1 + aw.weight.shape[0] and cached[1].shape[1] == so.weight.shape[1]):
+                    # refreshed IN PLACE: captured hipGraphs (GraphedTransformer) keep reading these two buffers, and
+                    # a replay never re-runs this Python code
+                    w, b = cached[1], cached[2]
+                    w[:n1].copy_(so.weight)
+                    w[n1:].copy_(aw.weight)
+                    b[:n1].copy_(so.bias)
+                    b[n1:].copy_(aw.bias)
+                else:
+                    w = torch.cat([so.weight, aw.weight], 0).contiguous()
+                    b = torch.cat([so.bias, aw.bias], 0).contiguous()
             cached = self._fused_qp = (key, w, b)
         return cached[1], cached[2]
 

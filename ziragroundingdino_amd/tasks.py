@@ -106,15 +106,30 @@ def _resume(spec: TaskSpec, model, trainer: ZiraTrainer) -> int:
     return int(checkpoint["trainer"]["iteration"]) + 1
 
 
-def _check_matching(model):
+def _check_matching(model, process_group=None):
     """The device-side matcher records what the reference stops on at once (scipy's ValueError for an
     infeasible -- inf / NaN -- cost matrix, ``generalized_box_iou``'s xyxy assertion:
     matcher/matcher.py:147, util/box_ops.py:51-52) as device flags and goes on with dummy assignments.
-    Read them back here so that a diverged run ends before a checkpoint is written or merged."""
+    Read them back here so that a diverged run ends before a checkpoint is written or merged.  With several ranks the
+    verdict is all-reduced (MAX) first: every rank raises together instead of one raising and the others hanging in
+    their next collective until the RCCL timeout."""
     criterion = getattr(model, "criterion", None)
     matcher = getattr(criterion, "matcher", None)
+    err = None
     if matcher is not None and hasattr(matcher, "check"):
-        matcher.check()
+        try:
+            matcher.check()
+        except (AssertionError, ValueError) as exc:
+            err = exc
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dev = next(model.parameters()).device
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32,
+                            device=dev if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=process_group)
+        if err is None and int(flag.item()):
+            err = RuntimeError("device-side matching failed on another rank (infeasible cost matrix or boxes not in xyxy order)")
+    if err is not None:
+        raise err
 
 
 def run_task(spec: TaskSpec, build_model, init_checkpoint: Optional[str], device="cpu", process_group=None,
@@ -141,10 +156,10 @@ def run_task(spec: TaskSpec, build_model, init_checkpoint: Optional[str], device
         if on_step is not None:
             on_step(spec, it, loss_dict)
         if (it + 1) % period == 0:
-            _check_matching(model)        # before anything is written: one host sync per checkpoint period
+            _check_matching(model, process_group)        # before anything is written: one host sync per checkpoint period
             if _is_main(process_group):
                 save_checkpoint(spec.output_dir, "model_%07d" % it, model, trainer, it)
-    _check_matching(model)                # ... and before the side branches are merged into the weights
+    _check_matching(model, process_group)                # ... and before the side branches are merged into the weights
     trainer.after_train(list(spec.categories_names))
     if _is_main(process_group):
         save_checkpoint(spec.output_dir, "model_final", model, trainer, spec.max_iter)

@@ -48,6 +48,10 @@ class ZiraTrainer:
             self.grad_scaler = torch.amp.GradScaler(next(model.parameters()).device.type)
         assert int(batch_size_scale) >= 1
         self.batch_size_scale = int(batch_size_scale)
+        # the reference unscales + clips every iteration but steps every k-th (train_multidatasets.py:185-199): with a
+        # GradScaler that is "unscale_() has already been called" on the second iteration -- a latent bug there; refused here
+        assert not (amp_dtype is torch.float16 and self.batch_size_scale > 1), \
+            "fp16 (GradScaler) cannot be combined with batch_size_scale > 1: use bf16 or fp32 for accumulated steps"
         if tuned_gemms and next(model.parameters()).is_cuda:
             from . import tuned_gemm
 
