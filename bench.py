@@ -97,6 +97,82 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def msda_call_pair(_C, v, sh, st, loc, attn, go):
+    """The forward and backward of one MSDA call as the autograd Function issues them: for sparse calls (decoder) the
+    forward makes the backward's plan in its own launch and the backward starts from that plan; dense calls (encoder)
+    have no plan.  Returns (fwd, bwd) closures; bwd uses the plan of the most recent fwd."""
+    state = {}
+    if _C.plan_applies(v, sh, st, loc, 64):
+        def fwd():
+            out, state["plan"] = _C.ms_deform_attn_forward_plan(v, sh, st, loc, attn, 64)
+            return out
+        fwd()
+        bwd = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64, plan=state["plan"])
+    else:
+        fwd = lambda: _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
+        bwd = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+    return fwd, bwd
+
+
+_FLUSH = {}
+
+
+def timeit_cold(fn, iters, dev):
+    """Average microseconds of ONE graph-replayed call behind a 512 MB write (twice the 256 MB Infinity Cache): HIP events
+    bracket the replay of a one-call hipGraph, so the figure also holds the launch of that graph (~10 us) -- an upper bound,
+    reported beside `timeit_cold_cycle`."""
+    buf = _FLUSH.get(dev)
+    if buf is None:
+        buf = _FLUSH[dev] = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev)
+    g = graphed(fn, 1)
+    for _ in range(3):
+        g()
+    tot = 0.0
+    for i in range(iters):
+        buf.fill_(float(i))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g()
+        e1.record()
+        e1.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / iters * 1e3
+
+
+def msda_cold_cycle(_C, v, sh, st, loc, attn, go, sets=8, reps=10):
+    """Forward and backward of one MSDA call with COLD operands and no launch artefacts: `sets` independent copies of every
+    operand (value alone is 45 MB; eight sets of inputs + outputs + plans are > 1 GB, four times the Infinity Cache), the
+    calls of all sets captured back to back into one hipGraph per direction with every output kept alive (so that the
+    allocator cannot hand a warm buffer to the next call); a call finds its operands where a training step leaves them --
+    in HBM -- and the replayed graph has no host gaps.  Returns (fwd_us, bwd_us) per call."""
+    copies = [tuple(t.clone() for t in (v, loc, attn, go)) for _ in range(sets)]
+    planned = _C.plan_applies(v, sh, st, loc, 64)
+    keep = []
+
+    def fwd_all():
+        keep.clear()
+        for cv, cl, ca, _ in copies:
+            if planned:
+                keep.append(_C.ms_deform_attn_forward_plan(cv, sh, st, cl, ca, 64))
+            else:
+                keep.append((_C.ms_deform_attn_forward(cv, sh, st, cl, ca, 64), None))
+    fwd_all()
+    plans = [p for _, p in keep]
+    outs = []
+
+    def bwd_all():
+        outs.clear()
+        for (cv, cl, ca, cg), p in zip(copies, plans):
+            kw = {} if p is None else {"plan": p}
+            outs.append(_C.ms_deform_attn_backward(cv, sh, st, cl, ca, cg, 64, **kw))
+    gb = graphed(bwd_all, 1)      # (uses the plans of the eager forward above; they stay alive in `plans`)
+    tb = timeit(gb, reps) / sets
+    outs.clear()
+    gf = graphed(fwd_all, 1)
+    tf = timeit(gf, reps) / sets
+    return tf, tb
+
+
 def encoder_loc(B, M, shapes, P, seed, dev):
     """Pixel-grid reference points of every level (reference transformer_for_adapter.py:482-497)
     + N(0, 2 px) offsets in each level's own pixels."""
@@ -136,8 +212,7 @@ def msda_micro(dev):
     out = {}
     for name, (v, sh, st, loc, attn, go), Q, iters in cases:
         fb, bb = msda_algorithmic_bytes(B, S, M, D, L, Q, P)
-        fwd = lambda: _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
-        bwd = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+        fwd, bwd = msda_call_pair(_C, v, sh, st, loc, attn, go)
         pair = lambda: (fwd(), bwd())
         per = 10
         res = {"Q": Q, "warmup": 20, "iters": iters}
@@ -159,11 +234,11 @@ def inmodel_replay(trainer, data, dev):
     got = {}
     orig_f, orig_b = _C.ms_deform_attn_forward, _C.ms_deform_attn_backward
 
-    def hook(value, sh, st, loc, attn, go, step):
+    def hook(value, sh, st, loc, attn, go, step, **kw):
         key = "enc" if loc.shape[1] == value.shape[1] else "dec"
         if key not in got:
             got[key] = [t.detach().clone() for t in (value, sh, st, loc, attn, go)]
-        return orig_b(value, sh, st, loc, attn, go, step)
+        return orig_b(value, sh, st, loc, attn, go, step, **kw)
 
     use_graph = trainer.model.use_transformer_graph
     trainer.model.use_transformer_graph = False
@@ -179,16 +254,24 @@ def inmodel_replay(trainer, data, dev):
         B, S, M, D = v.shape
         Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
         fb, bb = msda_algorithmic_bytes(B, S, M, D, L, Q, P)
-        fwd = lambda: orig_f(v, sh, st, loc, attn, 64)
-        bwd = lambda: orig_b(v, sh, st, loc, attn, go, 64)
+        fwd, bwd = msda_call_pair(_C, v, sh, st, loc, attn, go)
         per, iters = 10, (200 if key == "dec" else 50)
-        res = {"dims_BSMDLQP": [B, S, M, D, L, Q, P], "warmup": 20, "iters": iters}
+        res = {"dims_BSMDLQP": [B, S, M, D, L, Q, P], "warmup": 20, "iters": iters,
+               "planned": bool(_C.plan_applies(v, sh, st, loc, 64))}
         for name, fn, nbytes in (("fwd", fwd, fb), ("bwd", bwd, bb), ("pair", lambda: (fwd(), bwd()), fb + bb)):
             g = graphed(fn, per)
             timeit(g, 2)
             us = timeit(g, max(1, iters // per)) / per
             res[name + "_us"] = us
             res[name + "_frac"] = nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        # the same two calls with cold operands: cycling through 8 independent operand sets inside one hipGraph per direction
+        # (what a call costs inside the step), and one at a time behind a 512 MB write (includes the graph launch: upper bound)
+        cyc_f, cyc_b = msda_cold_cycle(_C, v, sh, st, loc, attn, go, sets=8 if key == "dec" else 3)
+        res.update({"cold_fwd_us": cyc_f, "cold_bwd_us": cyc_b, "cold_pair_us": cyc_f + cyc_b,
+                    "cold_pair_frac": (fb + bb) / ((cyc_f + cyc_b) * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        if key == "dec":
+            one_f, one_b = timeit_cold(fwd, 30, dev), timeit_cold(bwd, 30, dev)
+            res.update({"cold_single_fwd_us": one_f, "cold_single_bwd_us": one_b, "cold_single_pair_us": one_f + one_b})
         out[key] = res
     return out
 
@@ -392,6 +475,9 @@ def main():
                     help="categories in the synthetic caption: 2 + 2 n text tokens (15 -> T = 32, the ODinW-like length of SURVEY.md 8d)")
     ap.add_argument("--minibatches", type=int, default=4,
                     help="distinct synthetic minibatches the steps rotate through (graph static buffers and the prefetch path see new data every step)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="with WORLD_SIZE=1 under torch.distributed.run: still create the nccl group and issue every barrier / "
+                         "all-reduce of the N > 1 path (a hardware check of that path on a 1-GPU box)")
     ap.add_argument("--no-second-mode", action="store_true",
                     help="skip the second timed region in the other launch mode (eager <-> hipGraph replay)")
     args = ap.parse_args()
@@ -405,7 +491,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or (args.force_collectives and "WORLD_SIZE" in os.environ)
+    if dist_on:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ziragroundingdino_amd import _C, _lib
@@ -417,7 +504,9 @@ def main():
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
     model.use_transformer_graph = args.transformer_graph
-    trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
+    trainer = ZiraTrainer(model, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
+                          process_group=dist.group.WORLD if dist_on else None)
+    trainer.always_reduce = dist_on and world == 1   # (--force-collectives: the bucket all-reduce on a one-rank group too)
     # own shard: `--minibatches` distinct minibatches per rank, visited in turn
     batches = [synthetic_batch(args.batch, args.height, args.width, n_categories=args.categories,
                                seed=rank * 1009 + i, device=dev) for i in range(max(1, args.minibatches))]
@@ -433,13 +522,13 @@ def main():
 
     def timed(n):
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(n)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -492,7 +581,7 @@ def main():
     replay = None
     if rank == 0 and not args.no_micro:
         replay = inmodel_replay(trainer, data, dev)
-    if world > 1:
+    if dist_on:
         keys = sorted(modes)
         t = torch.tensor([elapsed] + [modes[k] for k in keys], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -505,7 +594,7 @@ def main():
         kernels = {}
         for key, (calls, avg_s, dims) in sorted(groups.items()):
             fb, bb = msda_algorithmic_bytes(*dims)
-            nbytes = fb if key.startswith("fwd") else bb
+            nbytes = fb if key.startswith("fwd") else (bb if key.startswith("bwd") else 0)
             kernels[key] = {"calls_per_step": calls / timed_steps, "avg_us": avg_s * 1e6,
                             "algorithmic_bytes": nbytes, "achieved": nbytes / avg_s / 1e9,
                             "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
@@ -522,7 +611,7 @@ def main():
             roofline.update(pmc)
         if "fwd_dec" in kernels and "bwd_dec" in kernels:
             f, b = kernels["fwd_dec"], kernels["bwd_dec"]
-            t_pair = (f["avg_us"] + b["avg_us"]) * 1e-6
+            t_pair = (f["avg_us"] + b["avg_us"] + (kernels["plan_dec"]["avg_us"] if "plan_dec" in kernels else 0.0)) * 1e-6
             nbytes = f["algorithmic_bytes"] + b["algorithmic_bytes"]
             roofline.update({"kernel": "ms_deform_attn fwd+bwd, decoder cross-attention shape "
                                        "B=%d,S=%d,M=%d,D=%d,L=%d,Q=%d,P=%d" % tuple(f["dims_BSMDLQP"]),
@@ -533,15 +622,24 @@ def main():
         if replay:
             roofline["inmodel_replay"] = replay
             if "dec" in replay:
-                # The headline figure: the model's own decoder inputs re-issued back to back from a hipGraph -- the
-                # execution mode of the timed region.  The eager event brackets (launch gaps included) stay beside it.
+                # The headline figure: the model's own decoder call, forward (+ plan) and backward, replayed from hipGraphs
+                # that cycle through eight independent operand sets (> 1 GB: every call finds its operands in HBM, as in
+                # the step).  The warm back-to-back replay of round 3's headline and the eager event brackets of the real
+                # step (host launch gaps included) stay beside it.
                 r = replay["dec"]
                 fb, bb = msda_algorithmic_bytes(*r["dims_BSMDLQP"])
                 roofline["eager_events"] = {k: roofline.get(k) for k in ("achieved", "frac", "avg_us")}
-                roofline.update({"achieved": (fb + bb) / (r["pair_us"] * 1e-6) / 1e9, "frac": r["pair_frac"],
-                                 "avg_us": r["pair_us"], "algorithmic_bytes": fb + bb,
-                                 "frac_source": "inmodel_replay.dec.pair_us (graph-replayed launches of the decoder "
-                                                "MSDA call captured from a training step); eager_events = " + timing_source})
+                roofline["warm_replay"] = {"achieved": (fb + bb) / (r["pair_us"] * 1e-6) / 1e9, "frac": r["pair_frac"],
+                                           "avg_us": r["pair_us"]}
+                roofline.update({"achieved": (fb + bb) / (r["cold_pair_us"] * 1e-6) / 1e9, "frac": r["cold_pair_frac"],
+                                 "avg_us": r["cold_pair_us"], "algorithmic_bytes": fb + bb,
+                                 "frac_source": "inmodel_replay.dec.cold_pair_us: the decoder MSDA call captured from a "
+                                                "training step, forward (with the backward's plan) and backward replayed "
+                                                "from hipGraphs cycling through 8 independent operand sets (cold operands, "
+                                                "no host gaps); cold_single_* = one call behind a 512 MB write, graph launch "
+                                                "included; "
+                                                "warm_replay = the same calls back to back (round 3's headline); "
+                                                "eager_events = " + timing_source})
         images = args.steps * args.batch * world
         flagship = args.backbone == "swin_T_224_1k" and args.dtype == "f32"
         size = "T" if args.backbone.startswith("swin_T") else "B"
@@ -569,7 +667,7 @@ def main():
                 "images_per_gpu": args.batch,
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world, "transformer_graph": bool(args.transformer_graph),
-                "frontend_prefetch": bool(args.prefetch),
+                "frontend_prefetch": bool(args.prefetch), "collectives_forced": bool(dist_on and world == 1),
                 "text_tokens": 2 + 2 * args.categories, "distinct_minibatches": len(batches),
                 "launch_modes": {k: {"images_per_s": images / v, "ms_per_step": v / args.steps * 1e3}
                                  for k, v in sorted(modes.items())},
@@ -583,7 +681,7 @@ def main():
             line["cpu_baseline"] = {"value": n_img / el, "unit": "images/s", "cores": cores,
                                     "cores_on_host": os.cpu_count(), "kind": "port", "sample": desc, "msda": cpu_baseline_msda(cores)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -306,6 +306,13 @@ int zira_cat_logits_bwd_f32(const float *grad_out, const int32_t *argmax, const 
 int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *bias_t, int B, int H, int W, int heads,
                          int head_dim, int window, int shift, float scale, float *out, void *stream);
 
+/* The same for bfloat16 qkv / out (qkv_bias and bias_t stay float32), 12 x 12 windows only: the 384-pixel Swin-B / L
+ * variants of BASELINE configs[3], whose qkv projection runs under bf16 autocast (swin_transformer.py:775-788).  A
+ * padding token's q / k / v are the bias rounded to bfloat16, as the projection would leave them; scores, softmax and
+ * the weighted sum are formed in float32 on the matrix cores (v_mfma_f32_32x32x2_f32), one block per (window, head). */
+int zira_window_attn_bf16(const void *qkv, const float *qkv_bias, const float *bias_t, int B, int H, int W, int heads,
+                          int head_dim, int window, int shift, float scale, void *out, void *stream);
+
 
 /* ---- MSDA module: attention softmax + sampling locations, forward and backward ---------------------
  * zira_msda_sampling_{fwd,bwd}_f32 replace what MultiScaleDeformableAttention.forward does between its query projections

@@ -17,10 +17,10 @@ trainer = ZiraTrainer(model)
 data = synthetic_batch(2, 800, 1333, device=dev)
 captured = {}
 orig_b = _C.ms_deform_attn_backward
-def hook(value, sh, st, loc, attn, go, step):
+def hook(value, sh, st, loc, attn, go, step, **kw):
     key = "enc" if loc.shape[1] == value.shape[1] else "dec"
     captured.setdefault(key, []).append([t.detach().clone() for t in (value, sh, st, loc, attn, go)])
-    return orig_b(value, sh, st, loc, attn, go, step)
+    return orig_b(value, sh, st, loc, attn, go, step, **kw)
 cap_step = int(os.environ.get("ZIRA_CAPTURE_STEP", "2"))
 for i in range(cap_step + 1):
     if i == cap_step:

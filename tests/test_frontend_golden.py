@@ -66,3 +66,48 @@ def test_bert_matches_huggingface(golden, dev):
     tol = 1e-4 if dev == "cpu" else 1e-3
     # (the rows of padded tokens attend to nothing real in either implementation: compare the real tokens)
     close(hidden.cpu()[valid], g["last_hidden_state"][valid], tol, "last_hidden_state")
+
+
+@pytest.fixture(scope="module")
+def golden_b():
+    return torch.load(os.path.join(HERE, "golden", "frontend_swinb.pt"), weights_only=False)
+
+
+def _swin_b(g, dev):
+    swin = zb.SwinTransformer(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in zb.SWIN_VARIANTS["swin_B_384_22k"].items()},
+                              out_indices=(1, 2, 3))
+    assert [n for n, _ in swin.named_parameters()] == g["swin_param_names"]
+    fill_by_name_(swin, g["swin_salt"], 0.04, {"norm": 0.1, "relative_position_bias_table": 0.5})
+    layernorm_weights_plus_one_(swin)
+    return swin.to(dev).eval()
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_swin_b_matches_reference(golden_b, dev):
+    """GroundingDINO-B's backbone (BASELINE configs[3]: swin_B_384_22k, 12 x 12 windows, reference
+    backbone/swin_transformer.py:775-780) against the reference's own SwinTransformer: fp32 1e-4 (CPU) / 1e-3 (GPU: the
+    144-token window kernel, hipBLASLt GEMMs, the row LayerNorm kernel)."""
+    g = golden_b
+    swin = _swin_b(g, dev)
+    with torch.no_grad():
+        outs = swin(NestedTensor(g["image"].to(dev), g["image_mask"].to(dev)))
+    tol = 1e-4 if dev == "cpu" else 1e-3
+    for i, k in enumerate(sorted(outs)):
+        close(outs[k].tensors, g["feats"][i], tol, "Swin-B feature map %d" % i)
+        assert torch.equal(outs[k].mask.cpu(), g["feat_masks"][i])
+
+
+@pytest.mark.gpu
+def test_swin_b_bf16_autocast_against_the_reference(golden_b):
+    """configs[3] runs its GEMMs under bf16 autocast: the same backbone against the REFERENCE's fp32 feature maps (not
+    against this package's own fp32 run).  24 blocks of bf16 GEMMs with fp32 residuals / norms: 3e-2 of the map's scale
+    at most, 6e-3 in the root mean square."""
+    g = golden_b
+    swin = _swin_b(g, "cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        outs = swin(NestedTensor(g["image"].cuda(), g["image_mask"].cuda()))
+    for i, k in enumerate(sorted(outs)):
+        got, want = outs[k].tensors.float().cpu(), g["feats"][i]
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) / scale <= 3e-2, (i, float((got - want).abs().max()) / scale)
+        assert float((got - want).pow(2).mean().sqrt()) / scale <= 6e-3, (i, float((got - want).pow(2).mean().sqrt()) / scale)

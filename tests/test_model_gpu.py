@@ -307,6 +307,8 @@ if world > 1:
 model = small_model().train()
 model.use_transformer_graph = True            # hipGraph replay of the transformer, as bench.py runs it
 trainer = ZiraTrainer(model, process_group=group)
+bucket = []
+trainer.on_reduced_grad = lambda g: bucket.append(g.detach().cpu().clone()) if not bucket else None   # step 1, after the all-reduce
 full = [synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, seed=s, device="cuda") for s in range(2)]
 batches = [b[rank:rank + 1] for b in full] if world > 1 else full   # one image per rank / both images
 losses = []
@@ -316,8 +318,8 @@ for it in range(4):                           # rotating minibatches, the next o
 torch.cuda.synchronize()
 assert trainer._prefetched is not None and all(l == l for l in losses)
 if rank == 0:
-    torch.save({"params": {n: p.detach().cpu() for n, p in zip(trainer.names, trainer.params)}, "losses": losses},
-               os.environ["ZIRA_OUT"])
+    torch.save({"params": {n: p.detach().cpu() for n, p in zip(trainer.names, trainer.params)}, "losses": losses,
+                "bucket": bucket[0]}, os.environ["ZIRA_OUT"])
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 print("TWO-RANKS-ONE-GPU-OK rank %d" % rank)
@@ -354,6 +356,11 @@ def test_two_ranks_on_one_gpu_match_one_process(tmp_path):
     # rank 0 reports the loss terms of ITS image (with the all-reduced normalisers); the weights must agree: sums over
     # images divided by the mean number of boxes, gradients averaged over the ranks.  (Tolerance as in _RCCL_ONE_RANK.)
     assert set(w1["params"]) == set(w2["params"])
+    # the flat gradient bucket of step 1 after the all-reduce (mean over the two ranks) against the one-process gradient of
+    # both images: the same sum in another order -- 1e-5 of the bucket's scale (measured: a few 1e-7)
+    b2, b1 = w2["bucket"], w1["bucket"]
+    assert b1.shape == b2.shape and torch.isfinite(b2).all()
+    assert float((b2 - b1).abs().max()) <= 1e-5 * float(b1.abs().max()), (float((b2 - b1).abs().max()), float(b1.abs().max()))
     for n, q in w1["params"].items():
         p = w2["params"][n]
         assert torch.isfinite(p).all(), n
@@ -510,3 +517,99 @@ def test_add_layer_norm_equals_add_then_norm():
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
     small = torch.randn(4, 7, 256, generator=g).cuda()        # (below the row kernel's size: the plain path)
     assert torch.equal(LayerNorm(256).cuda().add_norm(small, small), LayerNorm(256).cuda()(small + small))
+
+
+def test_state_dict_loaded_after_capture_reaches_the_graphs():
+    """A replayed hipGraph re-runs no Python: buffers derived from parameters (the MSDA modules' concatenated query
+    projection) must follow a ``load_state_dict`` into a live model whose graphs exist already.  Two models, A stepped
+    (graphs captured), then B's weights loaded into A: A's next loss must be the one B computes eagerly."""
+    a, b = small_model().train(), small_model().train()
+    with torch.no_grad():
+        for p in b.transformer.parameters():     # B: every transformer weight moved (incl. sampling_offsets / attention_weights)
+            p.add_(0.05 * torch.randn_like(p))
+    data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+    a.use_transformer_graph, b.use_transformer_graph = True, False
+    ta, tb = ZiraTrainer(a, lr=0.0), ZiraTrainer(b, lr=0.0)    # (lr 0: the steps leave the weights alone)
+    before = float(sum(ta.run_step(data).values()))
+    ta.run_step(data)
+    a.load_state_dict(b.state_dict())
+    got = float(sum(ta.run_step(data).values()))
+    want = float(sum(tb.run_step(data).values()))
+    assert abs(want - before) > 1e-2 * abs(want), "the two weight sets must give different losses for this test to bite"
+    assert abs(got - want) <= 2e-3 * max(1.0, abs(want)), (got, want, before)
+
+
+def test_product_graphs_never_capture_the_known_faulting_patterns(monkeypatch):
+    """graphs.GraphedTransformer stays clear of what faulted on replay on ROCm 7.2 / torch 2.10 (scripts/repro_*.py):
+    no ``torch.topk`` while a stream is capturing (query selection runs eagerly), no image <-> text fusion block inside a
+    captured piece, and no memset node (``hipMemsetAsync`` is replayed out of order: the native library zero-fills with
+    kernels).  One training step with graphs on; the guards fire inside the capture if the product ever regresses."""
+    import ctypes
+
+    from ziragroundingdino_amd import graphs as zg
+    from ziragroundingdino_amd import transformer as zt
+
+    seen = {"topk": 0, "fusion_in_capture": 0}
+    real_topk = torch.topk
+
+    def topk(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            seen["topk"] += 1
+        return real_topk(*a, **k)
+
+    real_fwd = zt.BiAttentionBlock.forward
+
+    def fusion_forward(self, *a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            seen["fusion_in_capture"] += 1
+        return real_fwd(self, *a, **k)
+
+    monkeypatch.setattr(torch, "topk", topk)
+    monkeypatch.setattr(zt.BiAttentionBlock, "forward", fusion_forward)
+    assert zg.GraphedTransformer.graph_selection is False and zg.GraphedTransformer.graph_fusion is False
+    model = small_model().train()
+    model.use_transformer_graph = True
+    trainer = ZiraTrainer(model)
+    data = synthetic_batch(2, 224, 320, n_categories=4, boxes_per_image=3, device="cuda")
+    for _ in range(3):
+        out = trainer.run_step(data)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v) for v in out.values())
+    assert seen == {"topk": 0, "fusion_in_capture": 0}, seen
+    # the native library itself: no hipMemsetAsync left in its import table
+    import subprocess
+
+    from ziragroundingdino_amd import _lib
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "hipMemsetAsync" not in syms and "hipMemset" not in syms, [l for l in syms.splitlines() if "Memset" in l]
+
+
+_BENCH_UNDER_TORCHRUN = r"""
+import json, os, subprocess, sys
+root = os.environ["ZIRA_ROOT"]
+cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+       "--master-port", os.environ["ZIRA_PORT"], os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+       "--no-cpu-baseline", "--no-micro", "--no-second-mode", "--kernel-timing-steps", "1", "--height", "320", "--width", "448",
+       "--force-collectives"]
+p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+line = json.loads(lines[0])
+assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1" and line["config"]["collectives_forced"]
+print("BENCH-UNDER-TORCHRUN-OK %.2f images/s" % line["value"])
+"""
+
+
+def test_bench_under_torchrun_with_the_nccl_backend(tmp_path):
+    """`bench.py` launched exactly as the driver launches the N > 1 runs (`python -m torch.distributed.run ... bench.py
+    --gpus N`), with N = 1 -- the only N this box allows -- and `--force-collectives`: the nccl process group with
+    `device_id=`, the barriers around the timed region, the MAX all-reduce of the timings, the flat-bucket all-reduce of
+    every step and rank 0's one JSON line all execute on hardware (a small image keeps it short)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZIRA_ROOT=root, ZIRA_PORT=str(29700 + os.getpid() % 90))
+    p = subprocess.run([sys.executable, "-c", _BENCH_UNDER_TORCHRUN], env=env, capture_output=True, text=True, timeout=1700)
+    assert p.returncode == 0 and "BENCH-UNDER-TORCHRUN-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

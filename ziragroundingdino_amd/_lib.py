@@ -20,7 +20,7 @@ SYMBOLS = (
     "zira_bisoftmax_workspace_floats", "zira_bisoftmax_fwd_f32", "zira_bisoftmax_bwd_f32",
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32", "zira_add_layernorm_fwd_f32",
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
-    "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32",
+    "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32", "zira_window_attn_bf16",
     "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32", "zira_gemm_drelu_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
@@ -108,6 +108,8 @@ def load():
     lib.zira_cat_logits_bwd_f32.restype = i
     lib.zira_window_attn_f32.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, f32, vp, vp]
     lib.zira_window_attn_f32.restype = i
+    lib.zira_window_attn_bf16.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, f32, vp, vp]
+    lib.zira_window_attn_bf16.restype = i
     lib.zira_msda_sampling_fwd_f32.argtypes = [vp, i, vp, i, vp, ll, i, i, i, vp, vp, vp]
     lib.zira_msda_sampling_fwd_f32.restype = i
     lib.zira_msda_sampling_bwd_f32.argtypes = [vp, vp, vp, vp, i, vp, ll, i, i, i, vp, i, vp]

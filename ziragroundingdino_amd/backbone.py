@@ -89,15 +89,21 @@ class WindowAttention(nn.Module):
 
         lib = _lib.load()
         B, L, C = xn.shape
-        qkv = self.qkv(xn).contiguous()                    # [B, H, W, 3, heads, 32]
-        out = torch.empty((B, L, C), dtype=torch.float32, device=xn.device)
+        qkv = self.qkv(xn).contiguous()                    # [B, H, W, 3, heads, 32]; bfloat16 under bf16 autocast
         hd = C // self.num_heads
+        if qkv.dtype == torch.bfloat16:                    # (12 x 12 windows only: SwinTransformerBlock.forward checks)
+            fn, name = lib.zira_window_attn_bf16, "zira_window_attn_bf16"
+        elif qkv.dtype == torch.float32:
+            fn, name = lib.zira_window_attn_f32, "zira_window_attn_f32"
+        else:
+            raise RuntimeError("window attention: qkv must be float32 or bfloat16, got %s" % qkv.dtype)
+        out = torch.empty((B, L, C), dtype=qkv.dtype, device=xn.device)
         with torch.cuda.device(xn.device):
-            rc = lib.zira_window_attn_f32(qkv.data_ptr(), self.qkv.bias.data_ptr(), self._bias_transposed().data_ptr(),
-                                          B, H, W, self.num_heads, hd, self.ws, shift, float(hd) ** -0.5, out.data_ptr(),
-                                          torch.cuda.current_stream().cuda_stream)
+            rc = fn(qkv.data_ptr(), self.qkv.bias.data_ptr(), self._bias_transposed().data_ptr(),
+                    B, H, W, self.num_heads, hd, self.ws, shift, float(hd) ** -0.5, out.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
         if rc != 0:
-            raise RuntimeError("zira_window_attn_f32 failed with code %d" % rc)
+            raise RuntimeError("%s failed with code %d" % (name, rc))
         return self.proj(out)
 
     def forward(self, x, mask=None):
@@ -114,9 +120,19 @@ class WindowAttention(nn.Module):
 
 class SwinTransformerBlock(nn.Module):
     native_max_tokens = 64
-    native_attention = True   # no-grad fp32 GPU forwards with windows of <= 64 tokens (7x7: one query row per lane):
-                              # window attention through the C ABI (csrc/winattn.hip).  12x12 windows (the 384-pixel
-                              # Swin-B / L variants) stay on SDPA: three rows per lane and one wave per block lose to it
+    native_attention = True   # no-grad GPU forwards: window attention through the C ABI (csrc/winattn.hip) -- fp32 with
+                              # windows of <= 64 tokens (7x7: one query row per lane) and, fp32 or under bf16 autocast,
+                              # the 12x12 windows of the 384-pixel Swin-B / L variants (144 tokens: the MFMA kernel)
+
+    def _native_ok(self, x, C):
+        ws = self.window_size
+        if not (self.native_attention and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and C // self.attn.num_heads == 32 and self.attn.qkv.bias is not None
+                and self.attn.qkv.weight.dtype == torch.float32 and self.attn.qkv.bias.dtype == torch.float32):
+            return False
+        if torch.is_autocast_enabled():
+            return ws == 12 and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        return ws * ws <= self.native_max_tokens or ws == 12
 
     def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, drop_path):
         super().__init__()
@@ -139,9 +155,7 @@ class SwinTransformerBlock(nn.Module):
         ws = self.window_size
         shortcut = x
         dp0, dp1 = (dp[0], dp[1]) if dp is not None else (None, None)
-        if (self.native_attention and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-                and not torch.is_autocast_enabled() and C // self.attn.num_heads == 32 and ws * ws <= self.native_max_tokens
-                and self.attn.qkv.bias is not None and self.attn.qkv.weight.dtype == torch.float32):
+        if self._native_ok(x, C):
             x = self._residual(shortcut, self.attn.forward_native(self.norm1(x), H, W, self.shift_size), dp0)
             return self._residual(x, self.mlp(self.norm2(x)), dp1)
         x = self.norm1(x).view(B, H, W, C)

@@ -160,6 +160,202 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 12 x 12 windows (the 384-pixel Swin-B / L variants: 144 tokens per window) on the matrix cores
+// ------------------------------------------------------------------------------------------
+// One block per (image, window, head), one wave per tile of 32 queries (five for 144 tokens).  The block stages the
+// window's K and V rows (padding tokens: the projection's bias) and the tokens' shift-mask regions in LDS once; every
+// wave then walks the five key tiles in the MFMA form of csrc/attn.hip: S^T = K Q^T on `v_mfma_f32_32x32x2_f32` (exact
+// fp32 products) with a query's scores in ONE lane's accumulator registers -- bias, mask, running maximum and sum are
+// per-lane scalars -- and O^T += V^T P^T takes those registers directly as its operand.  Input / output either fp32 or
+// bf16 (configs[3] runs the qkv projection under bf16 autocast; the arithmetic here is fp32 either way).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned rowmap32(unsigned reg, unsigned hh) { return (reg & 3u) + 8u * (reg >> 2) + 4u * hh; }
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short x) { return __uint_as_float((unsigned)x << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float x)   // round to nearest even (torch's conversion)
+{
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+// 16 consecutive elements as floats
+__device__ __forceinline__ void load16(const float *p, float (&x)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = reinterpret_cast<const float4 *>(p)[i];
+        x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void load16(const unsigned short *p, float (&x)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[8 * i + 2 * k] = __uint_as_float(w[k] << 16);
+            x[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u);
+        }
+    }
+}
+// the projection's bias as a padding token's q / k / v: rounded to the tensor's precision, as the projection would
+template <typename T>
+__device__ __forceinline__ void load16_bias(const float *p, float (&x)[16])
+{
+    load16(p, x);
+    if (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = bf16_to_f32(f32_to_bf16(x[i]));
+    }
+}
+
+template <int WS, typename T>
+__global__ __launch_bounds__(64 * ((WS * WS + 31) / 32)) void window_attn_mfma(
+    const T *__restrict__ qkv, const float *__restrict__ qkv_bias, const float *__restrict__ bias_t, int B, int H, int W,
+    int heads, int shift, float scale, T *__restrict__ out)
+{
+    constexpr int N = WS * WS, NT = (N + 31) / 32, NTHR = 64 * NT, KP = 36;   // KP: LDS row stride in floats
+    __shared__ float ks[N][KP], vs[N][KP];
+    __shared__ int toks[NT * 32], rids[NT * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned r = lane & 31, hh = lane >> 5;
+    const int C = heads * kHD;
+    const int nwx = (W + WS - 1) / WS, nwy = (H + WS - 1) / WS, Hp = nwy * WS, Wp = nwx * WS;
+    const int item = blockIdx.x, h = item % heads, win = item / heads;
+    const int wx = win % nwx, wy = (win / nwx) % nwy, b = win / (nwx * nwy);
+
+    // stage: source token (or -1: padding) and region of every token of the window, its K and V rows
+    for (int t = tid; t < NT * 32; t += NTHR) {
+        const int tc = t < N ? t : N - 1;
+        const int hp = wy * WS + tc / WS, wp = wx * WS + tc % WS;     // rolled, padded coordinates
+        int ho = hp + shift, wo = wp + shift;                         // x_rolled[hp] = x[(hp + shift) mod Hp]
+        if (ho >= Hp) ho -= Hp;
+        if (wo >= Wp) wo -= Wp;
+        toks[t] = (ho < H && wo < W) ? (b * H + ho) * W + wo : -1;
+        rids[t] = shift ? region(hp, Hp, WS, shift) * 3 + region(wp, Wp, WS, shift) : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * 4; i += NTHR) {       // a token's K or V row half: 16 floats
+        const int t = i >> 2, part = i & 3, which = part >> 1, half = part & 1;   // which: 0 K, 1 V
+        const int tok = toks[t];
+        float x[16];
+        const size_t off = (size_t)(1 + which) * C + h * kHD + 16 * half;
+        if (tok >= 0) load16(qkv + (size_t)tok * 3 * C + off, x);
+        else load16_bias<T>(qkv_bias + off, x);
+        float *dst = (which ? vs[t] : ks[t]) + 16 * half;
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) *reinterpret_cast<float4 *>(dst + c) = make_float4(x[c], x[c + 1], x[c + 2], x[c + 3]);
+    }
+    // this wave's 32 queries
+    const int tq = wave * 32 + (int)r, tqc = tq < N ? tq : N - 1;
+    const int tokq = toks[tqc], ridq = rids[tqc];
+    float bq[16];
+    {
+        const size_t off = (size_t)h * kHD + 16 * hh;
+        if (tokq >= 0) load16(qkv + (size_t)tokq * 3 * C + off, bq);
+        else load16_bias<T>(qkv_bias + off, bq);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bq[t] *= scale;
+    }
+    __syncthreads();
+
+    const float *bt = bias_t + (size_t)h * N * N;   // [key j][query i]
+    float m = -INFINITY, lsum = 0.f;
+    f32x16 acc_o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_o[i] = 0.f;
+    for (int kt = 0; kt < NT; ++kt) {
+        const int k0 = kt * 32;
+        float ka[16], va[16];
+        {
+            const int kr = k0 + (int)r < N ? k0 + (int)r : N - 1;
+#pragma unroll
+            for (int c = 0; c < 16; c += 4) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(&ks[kr][16 * hh + c]);
+                ka[c] = v4.x; ka[c + 1] = v4.y; ka[c + 2] = v4.z; ka[c + 3] = v4.w;
+            }
+#pragma unroll
+            for (unsigned t = 0; t < 16; ++t) {
+                const int vr = k0 + (int)rowmap32(t, hh);
+                va[t] = vs[vr < N ? vr : N - 1][r];
+            }
+        }
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], bq[t], s, 0, 0, 0);
+        // s[reg] = S^T[key k0 + rowmap(reg, hh)][query tq]
+        float mt = -INFINITY;
+#pragma unroll
+        for (unsigned reg = 0; reg < 16; ++reg) {
+            const int kidx = k0 + (int)rowmap32(reg, hh);
+            float x = s[reg];
+            if (kidx >= N) {
+                x = -INFINITY;
+            } else {
+                x += bt[(size_t)kidx * N + tqc];
+                if (shift && rids[kidx] != ridq) x -= 100.0f;
+            }
+            s[reg] = x;
+            mt = fmaxf(mt, x);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __expf(m - m_new);   // (m = -inf: 0; every tile holds real keys, so m_new is finite)
+        float ps = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const float p = __expf(s[reg] - m_new);
+            s[reg] = p;
+            ps += p;
+        }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[i] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t], s[t], acc_o, 0, 0, 0);
+        // acc_o[reg] = O^T[feature rowmap(reg, hh)][query tq]
+        m = m_new;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    if (tq < N && tokq >= 0) {     // (the reference crops the padding away again)
+        const float inv = 1.0f / lsum;
+        T *o = out + (size_t)tokq * C + h * kHD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v4 = make_float4(acc_o[4 * g] * inv, acc_o[4 * g + 1] * inv, acc_o[4 * g + 2] * inv, acc_o[4 * g + 3] * inv);
+            if (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + 8 * g + 4 * hh) = v4;
+            } else {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(v4.x) | ((unsigned)f32_to_bf16(v4.y) << 16);
+                pk.y = (unsigned)f32_to_bf16(v4.z) | ((unsigned)f32_to_bf16(v4.w) << 16);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(o) + 8 * g + 4 * hh) = pk;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_window_attn(const T *qkv, const float *qkv_bias, const float *bias_t, int B, int H, int W, int heads, int window,
+                       int shift, float scale, T *out, hipStream_t st)
+{
+    const int nwx = (W + window - 1) / window, nwy = (H + window - 1) / window;
+    const long long nitems = (long long)B * nwx * nwy * heads;
+    if (nitems >= (1ll << 31) || (long long)B * H * W * 3 * heads * kHD >= (1ll << 40)) return ZIRA_MSDA_EINVAL;
+    if (window != 12) return ZIRA_MSDA_EINVAL;
+    hipLaunchKernelGGL((window_attn_mfma<12, T>), dim3((unsigned)nitems), dim3(64 * 5), 0, st, qkv, qkv_bias, bias_t, B, H, W, heads,
+                       shift, scale, out);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -171,6 +367,8 @@ int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *b
         shift >= window)
         return ZIRA_MSDA_EINVAL;
     if (!qkv || !qkv_bias || !bias_t || !out) return ZIRA_MSDA_EINVAL;
+    if (window == 12)   // 144-token windows: the MFMA kernel
+        return launch_window_attn<float>(qkv, qkv_bias, bias_t, B, H, W, heads, window, shift, scale, out, (hipStream_t)stream);
     const int N = window * window;
     const int nwx = (W + window - 1) / window, nwy = (H + window - 1) / window;
     const long long nitems = (long long)B * nwx * nwy * heads;
@@ -189,6 +387,16 @@ int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *b
                            (hipStream_t)stream, qkv, qkv_bias, bias_t, B, H, W, heads, window, shift, scale, (int)nitems,
                            lds_per_wave, out);
     return (int)hipGetLastError();
+}
+
+int zira_window_attn_bf16(const void *qkv, const float *qkv_bias, const float *bias_t, int B, int H, int W, int heads,
+                          int head_dim, int window, int shift, float scale, void *out, void *stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || head_dim != kHD || window != 12 || shift < 0 || shift >= window)
+        return ZIRA_MSDA_EINVAL;
+    if (!qkv || !qkv_bias || !bias_t || !out) return ZIRA_MSDA_EINVAL;
+    return launch_window_attn<unsigned short>(reinterpret_cast<const unsigned short *>(qkv), qkv_bias, bias_t, B, H, W, heads,
+                                              window, shift, scale, reinterpret_cast<unsigned short *>(out), (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -62,6 +62,7 @@ class ZiraTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.iter = 0
         self.always_reduce = False  # tests: issue the collective on a one-rank group too
+        self.on_reduced_grad = None  # tests: callable(flat_grad) right after the all-reduce, before clip and step
         self._prefetched = None     # front end of the next minibatch, queued by run_step(..., next_data=)
         if hasattr(model, "criterion") and hasattr(model.criterion, "process_group"):
             model.criterion.process_group = process_group  # num_boxes is averaged over the same ranks
@@ -136,6 +137,8 @@ class ZiraTrainer:
             # identical on every rank, so sum / world leaves them as they are -- what DDP's reducer does too)
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)
+        if self.on_reduced_grad is not None:
+            self.on_reduced_grad(self.flat_grad)
         if self.clip_max_norm is not None:
             if scaler is not None:
                 scaler.unscale_(self.optimizer)   # (:187-189; without a clip, scaler.step() unscales)
