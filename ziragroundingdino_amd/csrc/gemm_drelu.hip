@@ -25,9 +25,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef ZIRA_GD_BK
 #define ZIRA_GD_BK 16
 #endif
-#ifndef ZIRA_GD_ABL
-#define ZIRA_GD_ABL 0   // developer timing builds (wrong results): 1 no H loads, 2 no C stores, 4 no MFMAs
-#endif
 #ifndef ZIRA_GD_OCC
 #define ZIRA_GD_OCC 2
 #endif
@@ -103,7 +100,6 @@ __global__ __launch_bounds__(kThreads, ZIRA_GD_OCC) void gemm_nn_drelu(const flo
         for (int kp = 0; kp < kBK; kp += 2) {
             const float a0 = As[buf][kp * 128 + oa0[kp >> 2]], a1 = As[buf][kp * 128 + oa1[kp >> 2]];
             const float b0 = Bs[buf][kp * 128 + ob0[kp >> 2]], b1 = Bs[buf][kp * 128 + ob1[kp >> 2]];
-            if (ZIRA_GD_ABL & 4) { acc[0][0][0] += a0 * b0; acc[1][1][0] += a1 * b1; continue; }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);

@@ -99,36 +99,11 @@
 #ifndef ZIRA_ACC_THREADS
 #define ZIRA_ACC_THREADS 512
 #endif
-#ifndef ZIRA_BIN_ABL
-#define ZIRA_BIN_ABL 0   // developer timing builds (wrong results): 1 no record stores, 2 no grad_out maximum
-#endif
 #ifndef ZIRA_ACC_MINW
 #define ZIRA_ACC_MINW 4    // accumulate: waves per SIMD the register allocation must allow
 #endif
 #ifndef ZIRA_ACC_DR
 #define ZIRA_ACC_DR 3      // accumulate: grad_out rows requested this many records ahead (DR + 1 divides 8)
-#endif
-#ifndef ZIRA_ACC_ABL
-#define ZIRA_ACC_ABL 0   // developer timing builds (wrong results): 1 no accumulator adds, 2 no home dots, 4 all grad_out rows = row 0
-#endif
-
-#ifndef ZIRA_ABL
-#define ZIRA_ABL 0   // developer timing builds (wrong results): 1 all grad_out rows = row 0, 2 all records = record 0,
-                     // 4 no home visits, 8 no value column loads
-#endif
-#ifndef ZIRA_CELL_STAMPS
-#define ZIRA_CELL_STAMPS 0   // 1: developer build, per-phase wall-clock stamps (scripts/cell_stamps.py); 0 in shipped builds
-#endif
-#if ZIRA_CELL_STAMPS
-__device__ unsigned long long zira_cell_stamps[16 * 16384];
-#define WSTAMP(id, i, v)                                                                              \
-    do {                                                                                              \
-        if (threadIdx.x == 0 && (id) < 16384) zira_cell_stamps[(size_t)(id) * 16 + (i)] = (v);        \
-    } while (0)
-#define WCLOCK(id, i) WSTAMP(id, i, wall_clock64())
-#else
-#define WSTAMP(id, i, v)
-#define WCLOCK(id, i)
 #endif
 
 namespace {
@@ -351,7 +326,7 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
     constexpr unsigned kGoLoads = 4;   // (rows of the block = QB * D / 4 float4 pieces; 256 threads take up to 4 each up front,
     uint4 gob[kGoLoads];               //  so that their latency runs behind the sample pass)
     const unsigned d4 = G.D / 4, ngo = G.QB * d4;
-    if (amax_blk && !(ZIRA_BIN_ABL & 2)) {
+    if (amax_blk) {
 #pragma unroll
         for (unsigned r = 0; r < kGoLoads; ++r) {
             const unsigned i = threadIdx.x + r * kBinThreads;
@@ -388,7 +363,7 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
         ranks[idx * 2 + 1] = r10 | (r11 << 16);
     }
     if (amax_blk) {
-        if (!(ZIRA_BIN_ABL & 2)) {
+        {
 #pragma unroll
             for (unsigned r = 0; r < kGoLoads; ++r) {
                 const unsigned m01 = max(gob[r].x & 0x7fffffffu, gob[r].y & 0x7fffffffu);
@@ -455,7 +430,7 @@ __global__ __launch_bounds__(kBinThreads) void msda_bwd_bin(
         const unsigned l = fast_div(s, G.Pdiv);
         const Level L = lv[l];
         const SampleGeo geo = sample_geo(xy.x, xy.y, attn[si], L.H, L.W);
-        if (!geo.valid || (ZIRA_BIN_ABL & 1)) continue;
+        if (!geo.valid) continue;
         const TileSet t = tiles_of_cell(geo.u, geo.v, L.W, L.nty, G.thp, G.thpdiv, L.twl);
         const unsigned r0 = ranks[idx * 2], r1 = ranks[idx * 2 + 1];
         const unsigned t00 = L.tbase + t.ty0 * L.ntx, t10 = L.tbase + t.ty1 * L.ntx;
@@ -591,9 +566,6 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
 
     const unsigned lane = threadIdx.x;
     const unsigned grp = lane / LPG, j = lane % LPG;
-#if ZIRA_CELL_STAMPS
-    const unsigned long long t_block = wall_clock64();
-#endif
     load_levels(shapes, G, lv, misc);
     const unsigned NT = misc[0], NW = misc[1];
     if (NT > G.ntmax) return;
@@ -610,8 +582,6 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
         tix = __builtin_amdgcn_readfirstlane(tix);
         const unsigned vt = xcd * per + tix;
         if (tix >= per || vt >= nvirt) break;
-        WSTAMP(vt, 0, t_block);
-        WCLOCK(vt, 1);
         const unsigned head = vt / NW;
         // last items first: the coarse levels hold the heaviest items (most records per pixel)
         const Item it = decode_item(lv, G.L, NW - 1 - (vt - head * NW));
@@ -651,8 +621,6 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
         }
         if (lane == 0) runpre[nruns] = n;
         ZIRA_WAVE_SYNC();
-        WCLOCK(vt, 2);
-        WSTAMP(vt, 8, ((unsigned long long)n << 32) | (it.l << 16) | (Lv.K << 8) | Lv.twl);
         // This work item's share of the tile's records: every K-th one, and when they do not fit one pass,
         // every (K * NP)-th one per pass.  Interleaved on purpose: consecutive records come from consecutive
         // queries, i.e. from one spatial band, and would all land in one or two walkers of the tile.
@@ -768,7 +736,6 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                 vis[(s_lo + rk) * NG + ul] = pos | (home ? kFlagBit : 0u);
             }
             ZIRA_WAVE_SYNC();
-            if (!rmw) { WCLOCK(vt, 3); WSTAMP(vt, 9, ((unsigned long long)Ltot << 32) | nb); }
 
             // ---- walk ----------------------------------------------------------------------------
             float4 aBp[NV], aBc[NV], aTp[NV], aTc[NV];   // pixels (y, c-1), (y, c), (y-1, c-1), (y-1, c)
@@ -826,7 +793,7 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                     vtl[k] = vtr[k]; vtr[k] = vtn[k];
                     vbl[k] = vbr[k]; vbr[k] = vbn[k];
                 }
-                if (c < tw && !(ZIRA_ABL & 8)) load_col(x0 + (int)c + 1, vtn, vbn);
+                if (c < tw) load_col(x0 + (int)c + 1, vtn, vbn);
             };
             load_col(x0 - 1, vtr, vbr);
             load_col(x0, vtn, vbn);
@@ -846,10 +813,10 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                 const bool ok = k < Ltot;
                 const unsigned w = vis[(ok ? k : 0u) * NG + grp];
                 e.wd = ok ? w : kIdleWord;
-                e.rc = reg_h[(e.wd != kIdleWord && !(ZIRA_ABL & 2)) ? (e.wd & ((1u << kRefBits) - 1)) : 0u];
+                e.rc = reg_h[e.wd != kIdleWord ? (e.wd & ((1u << kRefBits) - 1)) : 0u];
             };
             auto issue_row = [&](Elem &e) {
-                const unsigned q = (e.wd != kIdleWord && !(ZIRA_ABL & 1)) ? (e.rc.x & ((1u << kQBits) - 1)) : 0u;
+                const unsigned q = e.wd != kIdleWord ? (e.rc.x & ((1u << kQBits) - 1)) : 0u;
                 const unsigned o = q * rs + j * 4;
 #pragma unroll
                 for (unsigned k = 0; k < NV; ++k)
@@ -868,7 +835,7 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                     axpy4(aBp[k], wBl, e.row[k]);
                     axpy4(aBc[k], wBr, e.row[k]);
                 }
-                if ((e.wd & kFlagBit) && !(ZIRA_ABL & 4)) {
+                if (e.wd & kFlagBit) {
                     // dots with the value rows of the four corners: top-left, top-right, bottom-left, bottom-right
                     float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
 #pragma unroll
@@ -891,7 +858,7 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                     if (j == 0) {
                         const unsigned q = e.rc.x & ((1u << kQBits) - 1);
                         const unsigned pp = (e.rc.x >> kQBits) & ((1u << kPBits) - 1);
-                        const unsigned oi = (ZIRA_ABL & 16) ? lane : q * mlp + pp;  // (16: timing build, all stores to one line)
+                        const unsigned oi = q * mlp + pp;
                         ga_h[oi] = ga;
                         *reinterpret_cast<float2 *>(gl_h + 2 * oi) =
                             make_float2(__fmul_rn(__fmul_rn((float)W, a), gx), __fmul_rn(__fmul_rn((float)H, a), gy));
@@ -911,7 +878,6 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                 visit(e);
             };
 
-            if (!rmw) { WCLOCK(vt, 4); WSTAMP(vt, 10, Ltot); }
 #pragma unroll
             for (unsigned r = 0; r < DF; ++r) fetch(ring[r], r);
 #pragma unroll
@@ -925,10 +891,8 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
                     process(ring[r], k0 + r);
                 }
             }
-            if (!rmw) WCLOCK(vt, 5);
             // the steps that are left (they are empty or done), then the last pixel
             for (unsigned c = cur + 1; c <= tw + 1; ++c) transition(c);
-            if (!rmw) WCLOCK(vt, 6);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a later chunk re-reads what this one stored
             ZIRA_WAVE_SYNC();
             rmw = true;
@@ -936,7 +900,6 @@ __global__ __launch_bounds__(64, ZIRA_WALK_MINWAVES) void msda_bwd_walk(
             if (nb == 0) break;
           }
         }
-        WCLOCK(vt, 7);
     }
 }
 
@@ -1231,10 +1194,10 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
 #pragma unroll
             for (unsigned c = 0; c < 4; ++c) {
                 const unsigned pr = ul - 1 + (c >> 1), pc = vl - 1 + (c & 1);   // (unsigned: -1 wraps and fails the test)
-                ad[c] = (okr && pr < THP && pc < tw && !(ZIRA_ACC_ABL & 1)) ? (pr * twm + pc) * D : trash;
+                ad[c] = (okr && pr < THP && pc < tw) ? (pr * twm + pc) * D : trash;
             }
             const int u = y0 + (int)ul, v = x0 + (int)vl;
-            const bool home = okr && (vl < tw || v == W) && (ul < THP || u == H) && !(ZIRA_ACC_ABL & 2);
+            const bool home = okr && (vl < tw || v == W) && (ul < THP || u == H);
             P.lw = rec.y;
             P.lh = rec.z;
             P.a = okr ? rec.w : 0u;
@@ -1242,7 +1205,7 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
             P.a23 = ad[2] | (ad[3] << 16);
             P.vh = (home ? ((ul * VC + vl) * D) : 0u) | (home ? 0x10000u : 0u);
             P.oi = q * mlp + pp;
-            P.qo = (okr && !(ZIRA_ACC_ABL & 4)) ? q * rs : 0u;
+            P.qo = okr ? q * rs : 0u;
             return P;
         };
         float4 ring[NR];
@@ -1396,10 +1359,6 @@ inline bool make_geom(int B, int S, int M, int D, int L, int Q, int P, CellGeom 
     G.twl_min = dense ? 2 : 1;
     G.vstar = dense ? ZIRA_WALK_VSTAR_DENSE : ZIRA_WALK_VSTAR_SPARSE;
     if (use_accum(B, M, D, Q)) {  // one tile shape for all levels; busy levels only get more work items per tile
-#ifdef ZIRA_ACC_NG
-        G.ng = ZIRA_ACC_NG;
-        G.thp = G.ng - 1;
-#endif
         G.twl_max = G.twl_min = ZIRA_ACC_TWL;
         G.vstar = ZIRA_ACC_VSTAR;
     }
@@ -1520,16 +1479,5 @@ int cells_backward_f32(const float *grad_out, const float *value, const int64_t 
     return launch_walk<64, 8>(G, grad_out, value, shapes, start, desc, region, partial, tickets, gv, gl, ga, st);
 }
 
-#if ZIRA_CELL_STAMPS
-extern "C" int zira_dev_read_cell_stamps(unsigned long long *host, int n)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(zira_cell_stamps), sizeof(unsigned long long) * n);
-}
-extern "C" int zira_dev_clear_cell_stamps(void)
-{
-    static unsigned long long zeros[16 * 16384];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(zira_cell_stamps), zeros, sizeof(zeros));
-}
-#endif
 
 }  // namespace zira
