@@ -73,8 +73,8 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
  * see the planned entry points below): without a plan from the forward pass this call plans first, the workspace being
  * the plan buffer.  Other sparse calls keep the round-2 entry sort (per-block counting sort of corner contributions,
  * per-tile row sums).
- * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (34 MB at
- * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, about a third is touched; 496 MB at Q=S), or 0 when
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (87 MB at
+ * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, about a fifth is touched; 496 MB at Q=S), or 0 when
  * no workspace path applies (the plain entry point is then the only one).  The workspace is caller-owned DEVICE
  * memory, 16-byte aligned, needs no initialisation and may be reused by later calls on the same stream; with
  * workspace == NULL or too small the call degrades to zira_msda_bwd_f32.  Every element of grad_value,
@@ -98,17 +98,17 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
  *
  *   zira_msda_plan_bytes      size of the plan buffer for these dimensions on the current device (0: no planned path;
  *                             use zira_msda_bwd_f32_ws)
- *   zira_msda_plan_f32        enqueue the planning kernel on `stream`: writes the plan (records sorted by tile, work
- *                             items, a balanced schedule) into the caller's DEVICE buffer; reads no value / attention
- *                             data, so a binding can run it on a second stream beside zira_msda_fwd_f32 (~13 us on 64
- *                             CUs at the north-star shape) and keep the buffer with the tensors saved for backward
- *   zira_msda_fwd_plan_f32    convenience: forward, then the plan, on one stream
- *   zira_msda_bwd_planned_f32 the backward from a plan: a small launch that zeroes the split tiles + the accumulate
- *                             kernel.  `plan` must come from zira_msda_plan_* for the same dimensions, level tables and
- *                             sampling_loc (those three arguments are not read again); it is only read and may serve
- *                             several backward calls.  Same outputs / contract as zira_msda_bwd_f32_ws.
- * The plan buffer needs no initialisation, 16-byte alignment, and must not be written by anyone else between the
- * plan and the last backward that uses it. */
+ *   zira_msda_fwd_plan_f32    the forward AND the plan in ONE launch: the first 64 workgroups plan a (head, level) unit
+ *                             each, the others run the gather (17 us for both at the north-star shape against 10.6 +
+ *                             12.5 us apart: two kernels on two streams do not overlap on this stack, one grid does)
+ *   zira_msda_plan_f32        the plan alone: reads no value / attention data
+ *   zira_msda_bwd_planned_f32 the backward from a plan: the accumulate kernel + a small launch that adds up the partial
+ *                             tiles of split tiles.  `plan` must come from zira_msda_*plan_f32 for the same dimensions,
+ *                             level tables and sampling_loc (those three arguments are not read again).  Same outputs /
+ *                             contract as zira_msda_bwd_f32_ws; deterministic apart from the order of the LDS sums in
+ *                             double (no fp32 atomics anywhere).
+ * The plan buffer needs no initialisation and 16-byte alignment; the backward uses a region of it as scratch (the partial
+ * tiles), so a plan may serve several backward calls one after the other on a stream, not concurrently. */
 size_t zira_msda_plan_bytes(int B, int S, int M, int D, int L, int Q, int P);
 
 int zira_msda_plan_f32(const int64_t *spatial_shapes, const int64_t *level_start_index, const float *sampling_loc,

@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import NORTH_STAR_SHAPES, make_msda_inputs  # noqa: E402
+from bench import NORTH_STAR_SHAPES, make_msda_inputs, msda_call_pair  # noqa: E402
 from ziragroundingdino_amd import _C  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
@@ -26,9 +26,10 @@ elif shape == "clustered":
     loc = (centre + 0.05 * torch.randn(B, Q, M, 4, P, 2, generator=g)).to(dev)
 if os.environ.get("ZIRA_INPUTS"):  # captured from a model step (scripts/inmodel_msda.py): shape = dec | enc
     v, sh, st, loc, attn, go = [t.to(dev) for t in torch.load(os.environ["ZIRA_INPUTS"])[shape]]
+fwd, bwd = msda_call_pair(_C, v, sh, st, loc, attn, go)   # (as the autograd Function issues them: sparse calls plan in the forward)
 for _ in range(iters):
     if which in ("fwd", "both"):
-        _C.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
+        fwd()
     if which in ("bwd", "both"):
-        _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+        bwd()
 torch.cuda.synchronize()

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(kThreads, ZIRA_GD_OCC) void gemm_nn_drelu(const flo
         }
         // (measured and not kept: all operand reads of the step ahead of its MFMAs, 525 against 497 us; the hand-over
         // below in the middle of the MFMA sequence, 523-528 against 511-515 on the same box; three blocks per CU, 536; the
-        // tiles of the last, partial round of blocks as 128 x 64 halves in a second launch, 458 + 69 against 500 us)
+        // tiles of the last, partial round of blocks as 128 x 64 halves in a second launch, 458 + 69 against 500 us;
+        // round 4: persistent blocks walking the tiles with the next tile's first operand loads issued before the epilogue --
+        // 561 us with two blocks per CU (154 registers), 558 us with four (128 registers, 112 bytes of scratch) against
+        // 460 us for this form on the same box: the prefetched operands live through the epilogue and cost the fourth block)
         if (kt + 1 < nk) {
             stage(buf ^ 1);      // (the other buffer: last read a step ago, behind the barrier at its end)
             __syncthreads();

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kPlanThreads, ZIRA_FUSED_WAVES) void msda_fwd_plan(
 // the first round-4 version let the shares meet through fp32 atomics on pre-zeroed pixels: a share's 4096 atomics sit
 // in the same in-order memory queue as the next item's loads -- with 160-record shares the kernel took 46 instead of 28 us.)
 // kFoldParts blocks per unit.
-constexpr unsigned kFoldParts = 16;
+constexpr unsigned kFoldParts = 4;
 __global__ __launch_bounds__(256) void msda_bwd_fold(PlanGeom G, const unsigned *__restrict__ scount, const uint4 *__restrict__ usplit,
                                                      const float *__restrict__ partial, float *__restrict__ grad_value)
 {
