@@ -226,13 +226,12 @@ def msda_micro(dev):
     return out
 
 
-def inmodel_replay(trainer, data, dev):
-    """The MSDA calls of one real step (last decoder layer and last encoder layer: sampling locations and attention
-    weights as the model produces them), re-issued back to back from a hipGraph: kernel time on the model's inputs
-    without the launch gaps that HIP events around eager launches include."""
+def capture_inmodel(trainer, data):
+    """One real (eager) step with a hook on the native backward: the MSDA inputs of the last decoder layer and the last
+    encoder layer as the model produces them.  The step holds the data-parallel collectives: EVERY rank must call this."""
     from ziragroundingdino_amd import _C
     got = {}
-    orig_f, orig_b = _C.ms_deform_attn_forward, _C.ms_deform_attn_backward
+    orig_b = _C.ms_deform_attn_backward
 
     def hook(value, sh, st, loc, attn, go, step, **kw):
         key = "enc" if loc.shape[1] == value.shape[1] else "dec"
@@ -248,6 +247,15 @@ def inmodel_replay(trainer, data, dev):
     finally:
         _C.ms_deform_attn_backward = orig_b
         trainer.model.use_transformer_graph = use_graph
+    torch.cuda.synchronize()
+    return got
+
+
+def inmodel_replay(got, dev):
+    """The MSDA calls of one real step (`capture_inmodel`), re-issued from hipGraphs: kernel time on the model's inputs
+    without the launch gaps that HIP events around eager launches include -- back to back on one operand set (warm), and
+    cycling through independent operand sets (cold).  No collectives: rank 0 alone runs this."""
+    from ziragroundingdino_amd import _C
     torch.cuda.synchronize()
     out = {}
     for key, (v, sh, st, loc, attn, go) in got.items():
@@ -579,8 +587,11 @@ def main():
                          "region (its steps replay the transformer from hipGraphs, which hides the launches)"
                          % args.kernel_timing_steps)
     replay = None
-    if rank == 0 and not args.no_micro:
-        replay = inmodel_replay(trainer, data, dev)
+    if not args.no_micro:
+        got = capture_inmodel(trainer, data)     # (a training step: every rank, the collectives inside need them all)
+        if rank == 0:
+            replay = inmodel_replay(got, dev)
+        del got
     if dist_on:
         keys = sorted(modes)
         t = torch.tensor([elapsed] + [modes[k] for k in keys], device=dev, dtype=torch.float64)

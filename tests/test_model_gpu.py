@@ -589,13 +589,14 @@ import json, os, subprocess, sys
 root = os.environ["ZIRA_ROOT"]
 cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
        "--master-port", os.environ["ZIRA_PORT"], os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-       "--no-cpu-baseline", "--no-micro", "--no-second-mode", "--kernel-timing-steps", "1", "--height", "320", "--width", "448",
+       "--no-cpu-baseline", "--no-second-mode", "--kernel-timing-steps", "1", "--height", "320", "--width", "448",
        "--force-collectives"]
 p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
 lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
 assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
 line = json.loads(lines[0])
 assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "dp1" and line["config"]["collectives_forced"]
+assert line["roofline"]["inmodel_replay"]["dec"]["cold_pair_us"] > 0 and "micro" in line["roofline"]   # (the capture step is collective: all ranks)
 print("BENCH-UNDER-TORCHRUN-OK %.2f images/s" % line["value"])
 """
 
