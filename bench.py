@@ -497,11 +497,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (test hooks: ZIRA_BENCH_DEVICE pins every rank to one GPU and ZIRA_BENCH_BACKEND=gloo carries the collectives through
+    # the host, so that the N > 1 control flow of this file can run on a 1-GPU box -- RCCL refuses two ranks on one device)
+    dev_index = int(os.environ.get("ZIRA_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("ZIRA_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist_on = world > 1 or (args.force_collectives and "WORLD_SIZE" in os.environ)
     if dist_on:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ziragroundingdino_amd import _C, _lib
     from ziragroundingdino_amd.config import zira_swint_config

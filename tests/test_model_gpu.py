@@ -614,3 +614,36 @@ def test_bench_under_torchrun_with_the_nccl_backend(tmp_path):
     env = dict(os.environ, ZIRA_ROOT=root, ZIRA_PORT=str(29700 + os.getpid() % 90))
     p = subprocess.run([sys.executable, "-c", _BENCH_UNDER_TORCHRUN], env=env, capture_output=True, text=True, timeout=1700)
     assert p.returncode == 0 and "BENCH-UNDER-TORCHRUN-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+_BENCH_TWO_RANKS = r"""
+import json, os, subprocess, sys
+root = os.environ["ZIRA_ROOT"]
+cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+       "--master-port", os.environ["ZIRA_PORT"], os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+       "--no-second-mode", "--kernel-timing-steps", "1", "--height", "256", "--width", "320"]
+env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZIRA_BENCH_DEVICE="0", ZIRA_BENCH_BACKEND="gloo")
+p = subprocess.run(cmd, capture_output=True, text=True, timeout=1700, env=env)
+lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+line = json.loads(lines[0])
+assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
+assert line["scaling"] == "weak" and "cpu_baseline" not in line and line["roofline"]["inmodel_replay"]["dec"]["cold_pair_us"] > 0
+print("BENCH-TWO-RANKS-OK %.2f images/s" % line["value"])
+"""
+
+
+def test_bench_control_flow_with_two_ranks_on_one_gpu():
+    """The whole default `bench.py` path at N = 2 -- two ranks under `torch.distributed.run`, both pinned to the box's one
+    GPU, collectives over gloo (RCCL refuses two ranks on a device): warm-up, the timed region between its barriers, the
+    eager MSDA timing steps, the in-model capture step (collective: every rank), rank 0's micro-benchmarks while rank 1
+    waits in the MAX all-reduce of the timings, one JSON line with the aggregate.  Round 4 found rank 0 running the capture
+    step alone, which would have hung every N > 1 run in its first all-reduce."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZIRA_ROOT=root, ZIRA_PORT=str(29500 + os.getpid() % 90))
+    p = subprocess.run([sys.executable, "-c", _BENCH_TWO_RANKS], env=env, capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0 and "BENCH-TWO-RANKS-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
