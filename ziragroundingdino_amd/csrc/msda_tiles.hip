@@ -10,11 +10,11 @@
 // IN LDS IN DOUBLE, in any order, and a pile-up of the decoder's queries on a few pixels costs nothing extra.  What
 // has to be organised is which samples go to which tile and how the tiles are dealt to the CUs -- and all of that
 // depends on the sampling locations only, which are known in the FORWARD pass.  Round 3 planned inside the backward
-// call (15 us on 64 CUs in front of the accumulate kernel); since round 4 the plan is a call of its own
-// (zira_msda_plan_f32) that a binding runs beside the forward gather on a second stream, and the backward
-// (zira_msda_bwd_planned_f32) starts with everything resolved:
+// call (15 us on 64 CUs in front of the accumulate kernel); since round 4 the plan is made in the forward pass -- by
+// the first 64 blocks of the forward's own grid (msda_fwd_plan / zira_msda_fwd_plan_f32; msda_plan is the same code as a
+// kernel of its own) -- and the backward (zira_msda_bwd_planned_f32) starts with everything resolved:
 //
-//   plan   (msda_plan)  one 1024-thread block per (head, level) unit; touches only the sampling locations.  Pass 1: a
+//   plan   (plan_unit)  one 1024-thread block per (head, level) unit; touches only the sampling locations.  Pass 1: a
 //          thread per query computes the pixel cells of its samples and counts each sample into every tile its
 //          2 x 2 corner block touches (LDS histogram; the rank inside the tile comes back from the atomic).  A block
 //          scan turns the histogram into record offsets.  Per tile a 32-byte WORK ITEM {first record, records, tile
