@@ -629,3 +629,35 @@ def test_forward_plan_eager_side_stream_and_in_a_graph(oracle):
             g_ = g_.detach().cpu().numpy() if torch.is_tensor(g_) else g_
             errs.append((what, nm, float(np.abs(g_ - w).max()) / max(1.0, float(np.abs(w).max()))))
     assert all(e[2] <= 2e-5 for e in errs), errs
+
+
+FUSED_SHAPES = [
+    # (id, B, Q, M, shapes, P, kwargs): the branches of the fused forward + plan kernel and of the deal
+    ("two_pass_p5_heads12", 3, 57, 4, [(12, 9), (6, 5), (3, 3), (2, 2), (1, 1)], 5, {}),
+    ("one_group_heads4", 2, 200, 2, [(17, 23)], 1, {}),
+    ("two_pass_q1500", 1, 1500, 8, [(30, 41), (15, 21), (8, 11)], 4, dict(clustered=True)),
+    ("oob_p3_heads6", 2, 333, 3, [(20, 31), (10, 16), (5, 8), (3, 4)], 3, dict(lo=-0.5, hi=1.5)),
+    ("pinpoint_small_map", 2, 900, 8, [(9, 13), (5, 7)], 4, dict(hot=2)),
+]
+
+
+@pytest.mark.parametrize("name,B,Q,M,shapes,P,kw", FUSED_SHAPES, ids=[c[0] for c in FUSED_SHAPES])
+def test_fused_forward_plan_and_planned_backward_other_shapes(oracle, name, B, Q, M, shapes, P, kw):
+    """`MultiScaleDeformableAttnFunction` on sparse D = 32 calls away from the north-star shape: the fused forward + plan launch
+    with the two-pass plan (P > 4 or Q > 1024), fewer than eight heads (one group, every accumulate block deals from all units),
+    out-of-window samples (records without corners), everything on a few pixels of a small map (tiles split into many shares)."""
+    D = 32
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=41, **kw)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, lo, at = t(value).requires_grad_(), t(loc).requires_grad_(), t(attn).requires_grad_()
+    assert _C.plan_applies(v, t(sh), t(start), lo, 64)
+    out = MultiScaleDeformableAttnFunction.apply(v, t(sh), t(start), lo, at, 64)
+    assert out.grad_fn.plan is not None
+    out.backward(t(go))
+    torch.cuda.synchronize()
+    _close(out, oracle.msda_forward(value, sh, start, loc, attn), 2e-5, "output")
+    want = oracle.msda_backward(go, value, sh, start, loc, attn)
+    ok = _away_from_pixel_borders(loc, sh)
+    _close(v.grad, want[0], 2e-5, "grad_value")
+    _close(lo.grad.cpu().numpy() * ok[..., None], want[1] * ok[..., None], 2e-5, "grad_loc")
+    _close(at.grad, want[2], 2e-5, "grad_attn")
