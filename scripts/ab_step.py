@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Dev: same-box A/B of class-level switches on the replayed training step.  `python scripts/ab_step.py NAME=0|1 ...` with
+NAME in {shared_source, batch_value}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
+prints ms per step.  Run the variants alternately in ONE gpurun call."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ziragroundingdino_amd import transformer as zt  # noqa: E402
+from ziragroundingdino_amd.config import zira_swint_config  # noqa: E402
+from ziragroundingdino_amd.groundingdino import build_model  # noqa: E402
+from ziragroundingdino_amd.ms_deform_attn import MultiScaleDeformableAttention as M  # noqa: E402
+from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch  # noqa: E402
+
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    if k == "shared_source":
+        M.fuse_shared_source = bool(int(v))
+    elif k == "batch_value":
+        zt.TransformerDecoder.batch_value_projections = bool(int(v))
+    else:
+        raise SystemExit("unknown switch " + k)
+dev = torch.device("cuda")
+torch.manual_seed(0)
+model = build_model(zira_swint_config(device="cuda")).to(dev).train()
+trainer = ZiraTrainer(model)
+batches = [synthetic_batch(2, 800, 1333, n_categories=15, seed=i, device=dev) for i in range(4)]
+for i in range(8):
+    trainer.run_step(batches[i % 4], next_data=batches[(i + 1) % 4])
+torch.cuda.synchronize()
+ts = []
+for rep in range(2):
+    t0 = time.perf_counter()
+    for i in range(20):
+        trainer.run_step(batches[i % 4], next_data=batches[(i + 1) % 4])
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) / 20 * 1e3)
+print("%s: %.3f / %.3f ms per step" % (" ".join(sys.argv[1:]) or "defaults", ts[0], ts[1]), flush=True)

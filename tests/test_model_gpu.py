@@ -647,3 +647,67 @@ def test_bench_control_flow_with_two_ranks_on_one_gpu():
     env = dict(os.environ, ZIRA_ROOT=root, ZIRA_PORT=str(29500 + os.getpid() % 90))
     p = subprocess.run([sys.executable, "-c", _BENCH_TWO_RANKS], env=env, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0 and "BENCH-TWO-RANKS-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_shared_source_and_multi_value_projections_change_nothing():
+    """Round 4: the encoder's self-attention hands (src, pos) to its deformable-attention module as ONE source, so that
+    value_proj(src) and the query projection of src + pos are one autograd node whose input gradients accumulate inside the
+    second GEMM; the decoder projects the encoder output for all its layers' cross-attention in one node likewise
+    (`multi_value_projections`).  Same outputs and gradients as the separate projections (summation order only)."""
+    from ziragroundingdino_amd import transformer as zt
+    from ziragroundingdino_amd.ms_deform_attn import MultiScaleDeformableAttention as M
+    from ziragroundingdino_amd.ms_deform_attn import multi_value_projections
+
+    torch.manual_seed(0)
+    shapes = torch.tensor([[16, 20], [8, 10], [4, 5]], device="cuda")
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    mods = [M(embed_dim=256, num_heads=8, num_levels=3, num_points=4, batch_first=True).cuda() for _ in range(3)]
+    for mod in mods:
+        with torch.no_grad():
+            mod.sampling_offsets.weight.normal_(0, 0.02)
+            mod.attention_weights.weight.normal_(0, 0.1)
+            mod.value_proj.bias.normal_(0, 0.1)
+        for p in mod.parameters():
+            p.requires_grad_(False)
+    src = torch.randn(2, S, 256, device="cuda", requires_grad=True)
+    pos = torch.randn(2, S, 256, device="cuda")
+    ref = torch.rand(2, S, 3, 2, device="cuda")
+    mask = torch.zeros(2, S, dtype=torch.bool, device="cuda")
+    mask[1, -37:] = True
+    g = torch.randn(2, S, 256, device="cuda")
+
+    def encoder_style(kpm):
+        out = mods[0](query=src, query_pos=pos, value=src, reference_points=ref, spatial_shapes=shapes,
+                      level_start_index=start, key_padding_mask=kpm)
+        return (out,) + torch.autograd.grad(out, [src], g)
+
+    for kpm in (None, mask):
+        try:
+            M.fuse_shared_source = False
+            want = encoder_style(kpm)
+        finally:
+            M.fuse_shared_source = True
+        got = encoder_style(kpm)
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+
+    # decoder style: three modules read one memory, 40 queries each
+    q = torch.randn(2, 40, 256, device="cuda", requires_grad=True)
+    refq = torch.rand(2, 40, 3, 2, device="cuda")
+    gq = torch.randn(2, 40, 256, device="cuda")
+
+    def decoder_style(batched, kpm):
+        vals = multi_value_projections(mods, src, kpm) if batched else None
+        assert (vals is not None) == batched
+        tot = 0
+        for i, mod in enumerate(mods):
+            tot = tot + mod(query=q, value=src, reference_points=refq, spatial_shapes=shapes, level_start_index=start,
+                            key_padding_mask=kpm, value_projected=None if vals is None else vals[i])
+        return (tot,) + torch.autograd.grad(tot, [q, src], gq)
+
+    for kpm in (None, mask):
+        want, got = decoder_style(False, kpm), decoder_style(True, kpm)
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+    assert zt.TransformerDecoder.batch_value_projections is True

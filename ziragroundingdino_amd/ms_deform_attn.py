@@ -108,6 +108,86 @@ class _SamplingPlan(Function):
         return grad_proj, None, None, None, None, None
 
 
+class _SharedSourceProjections(Function):
+    """value_proj(src) and the fused query projection of (src + pos) as ONE autograd node (frozen weights): the encoder's
+    self-attention reads its image tokens three times -- as values, as queries and through the residual connection -- and
+    autograd would form the two projections' input gradients separately and add them with a pass over the 45 MB tensor.
+    Here the second product accumulates into the first (``addmm_``, beta = 1): one add less per layer and direction.
+    Reference: ms_deform_attn.py:286-295 (value_proj, sampling_offsets / attention_weights on the same source)."""
+
+    @staticmethod
+    def forward(ctx, src, pos, wv, bv, wq, bq):
+        c = src.shape[-1]
+        s2 = src.reshape(-1, c)
+        q2 = s2 if pos is None else (src + pos).reshape(-1, c)
+        value = torch.addmm(bv, s2, wv.t()).view(*src.shape[:-1], wv.shape[0])
+        proj = torch.addmm(bq, q2, wq.t()).view(*src.shape[:-1], wq.shape[0])
+        ctx.save_for_backward(wv, wq)
+        ctx.pos_grad = pos is not None and pos.requires_grad
+        ctx.src_shape = src.shape
+        return value, proj
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_value, g_proj):
+        wv, wq = ctx.saved_tensors
+        gx = None
+        if g_value is not None:
+            gx = g_value.reshape(-1, g_value.shape[-1]) @ wv
+        g_pos = None
+        if g_proj is not None:
+            gp2 = g_proj.reshape(-1, g_proj.shape[-1])
+            if ctx.pos_grad:
+                g_pos = (gp2 @ wq).view(ctx.src_shape)
+            gx = gp2 @ wq if gx is None else gx.addmm_(gp2, wq)
+        return (None if gx is None else gx.view(ctx.src_shape)), g_pos, None, None, None, None
+
+
+class _MultiValueProjections(Function):
+    """The value projections of SEVERAL deformable-attention modules on one source (the six decoder layers all read the
+    encoder's output, reference transformer_for_adapter.py:1059 inside the loop :700-806) as one autograd node, frozen
+    weights: the input gradient is one buffer that the n products accumulate into, instead of n tensors of 45 MB and n - 1
+    adds.  ``wb`` = n weights, then n biases."""
+
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        ws, bs = wb[:n], wb[n:]
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(*ws)
+        ctx.x_shape = x.shape
+        return tuple(torch.addmm(b, x2, w.t()).view(*x.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        ws = ctx.saved_tensors
+        gx = None
+        for g, w in zip(gs, ws):
+            if g is None:
+                continue
+            g2 = g.reshape(-1, g.shape[-1])
+            gx = g2 @ w if gx is None else gx.addmm_(g2, w)
+        return (None if gx is None else gx.view(ctx.x_shape), None) + (None,) * (2 * len(ws))
+
+
+def _frozen_fp32_linear(lin, x):
+    return (x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32 and lin.bias is not None
+            and not lin.weight.requires_grad and not lin.bias.requires_grad and not torch.is_autocast_enabled())
+
+
+def multi_value_projections(modules, source, key_padding_mask=None):
+    """``[m.value_proj(source) for m in modules]`` (padded positions zeroed, as ``MultiScaleDeformableAttention.forward``
+    does), through one autograd node when every projection is frozen fp32 on the GPU; None otherwise (the modules then
+    project for themselves).  Hand the i-th result to ``modules[i](..., value_projected=...)``."""
+    if not modules or not all(_frozen_fp32_linear(m.value_proj, source) for m in modules) or not source.requires_grad:
+        return None
+    outs = _MultiValueProjections.apply(source, len(modules), *[m.value_proj.weight for m in modules],
+                                        *[m.value_proj.bias for m in modules])
+    if key_padding_mask is not None:
+        outs = tuple(o.masked_fill(key_padding_mask[..., None], float(0)) for o in outs)
+    return list(outs)
+
+
 def _sampling_plan_ok(proj, reference_points, spatial_shapes, L, P):
     LP = L * P
     return (proj.is_cuda and proj.dtype == torch.float32 and reference_points.dtype == torch.float32
@@ -311,19 +391,35 @@ class MultiScaleDeformableAttention(nn.Module):
             cached = self._fused_qp = (key, w, b)
         return cached[1], cached[2]
 
-    def project(self, query, value, key_padding_mask, reference_points, spatial_shapes):
+    fuse_shared_source = True       # value == query source (encoder self-attention): both projections one autograd node
+
+    def project(self, query, value, key_padding_mask, reference_points, spatial_shapes, shared_source=None,
+                value_projected=None):
         """Everything of ``forward`` up to the native call (reference :286-325), batch-first.
-        Returns (value[B,S,M,D], sampling_locations[B,Q,M,L,P,2], attention_weights[B,Q,M,L,P])."""
-        bs, num_query, _ = query.shape
-        num_value = value.shape[1]
+        Returns (value[B,S,M,D], sampling_locations[B,Q,M,L,P,2], attention_weights[B,Q,M,L,P]).
+        ``shared_source`` = (src, pos) when ``value is src`` and ``query = src + pos`` (``query`` may then be None);
+        ``value_projected``: ``value_proj(value)`` with the padding zeroed, made elsewhere (``multi_value_projections``)."""
         M, L, P = self.num_heads, self.num_levels, self.num_points
-        value = self.value_proj(value)
-        if key_padding_mask is not None:
+        fused = self._fused_query_projection()
+        oa = None
+        if (shared_source is not None and fused is not None and self.fuse_shared_source and value_projected is None
+                and _frozen_fp32_linear(self.value_proj, shared_source[0])):
+            src, pos = shared_source
+            value, oa = _SharedSourceProjections.apply(src, pos, self.value_proj.weight, self.value_proj.bias, fused[0], fused[1])
+            bs, num_query = src.shape[0], src.shape[1]
+            num_value = num_query
+        else:
+            if query is None:
+                query = shared_source[0] if shared_source[1] is None else shared_source[0] + shared_source[1]
+            bs, num_query, _ = query.shape
+            num_value = value.shape[1]
+            value = self.value_proj(value) if value_projected is None else value_projected
+        if key_padding_mask is not None and value_projected is None:
             value = value.masked_fill(key_padding_mask[..., None], float(0))
         value = value.view(bs, num_value, M, -1)
-        fused = self._fused_query_projection()
         if fused is not None:   # one GEMM for the two projections of the query (both frozen: one dgrad GEMM, no add)
-            oa = F.linear(query, fused[0], fused[1])
+            if oa is None:
+                oa = F.linear(query, fused[0], fused[1])
             if self.fuse_sampling_plan and _sampling_plan_ok(oa, reference_points, spatial_shapes, L, P):
                 loc, attn = _SamplingPlan.apply(oa, reference_points, spatial_shapes, M, L, P)
                 return value, loc, attn
@@ -342,18 +438,26 @@ class MultiScaleDeformableAttention(nn.Module):
                 key_padding_mask: Optional[torch.Tensor] = None,
                 reference_points: Optional[torch.Tensor] = None,
                 spatial_shapes: Optional[torch.Tensor] = None,
-                level_start_index: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
+                level_start_index: Optional[torch.Tensor] = None,
+                value_projected: Optional[torch.Tensor] = None, **kwargs) -> torch.Tensor:
         if value is None:
             value = query
-        if query_pos is not None:
+        # value and query from ONE tensor (the encoder's self-attention: query = src + pos, value = src): both projections
+        # become one autograd node (see _SharedSourceProjections)
+        shared = (query, query_pos) if (value is query and self.batch_first and value_projected is None) else None
+        if shared is not None:
+            query = None
+        elif query_pos is not None:
             query = query + query_pos
         if not self.batch_first:
             query = query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
+            if value_projected is not None and value_projected.shape[0] != value.shape[0]:
+                value_projected = value_projected.permute(1, 0, 2)
         _check_levels_cover_value(spatial_shapes, value.shape[1], level_start_index)
 
         value, loc, attn = self.project(query, value, key_padding_mask, reference_points,
-                                        spatial_shapes)
+                                        spatial_shapes, shared_source=shared, value_projected=value_projected)
         half = value.dtype in (torch.float16, torch.bfloat16)
         out_dtype = value.dtype
         if half:  # the native op is fp32/fp64 (reference :326-344 upcasts fp16 the same way)

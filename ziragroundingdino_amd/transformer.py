@@ -23,6 +23,7 @@ from torch import Tensor, nn
 
 from .dense import LayerNorm, bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul
 from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
+from .ms_deform_attn import multi_value_projections
 from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
                     gen_sineembed_for_position, get_sine_pos_embed, inverse_sigmoid)
 
@@ -555,7 +556,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
                 key_padding_mask=None):
-        src2 = self.self_attn(query=self.with_pos_embed(src, pos), reference_points=reference_points,
+        # (query = src + pos, value = src: handed over as ONE tensor + pos so that the module can treat them as one node)
+        src2 = self.self_attn(query=src, query_pos=pos, reference_points=reference_points,
                               value=src, spatial_shapes=spatial_shapes,
                               level_start_index=level_start_index, key_padding_mask=key_padding_mask)
         src = self.norm1.add_norm(src, self.dropout1(src2))
@@ -626,7 +628,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 tgt_reference_points=None, memory_text=None, text_attention_mask=None, memory=None,
                 memory_key_padding_mask=None, memory_level_start_index=None,
                 memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
-                cross_attn_mask=None, memory_text_lb=None):
+                cross_attn_mask=None, memory_text_lb=None, memory_value=None):
         assert cross_attn_mask is None
         if self.self_attn is not None:
             q = k = self.with_pos_embed(tgt, tgt_query_pos)
@@ -643,6 +645,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
             reference_points=tgt_reference_points.transpose(0, 1).contiguous(),
             value=memory.transpose(0, 1), spatial_shapes=memory_spatial_shapes,
             level_start_index=memory_level_start_index, key_padding_mask=memory_key_padding_mask,
+            value_projected=memory_value,   # (this layer's value_proj(memory), made for all layers at once by the decoder)
         ).transpose(0, 1)
         tgt = self.norm1(tgt + self.dropout1(tgt2))
         return self.forward_ffn(tgt)
@@ -770,6 +773,8 @@ class TransformerEncoder(nn.Module):
 class TransformerDecoder(nn.Module):
     """Six layers with iterative box refinement (reference transformer_for_adapter.py:665-806)."""
 
+    batch_value_projections = True   # class-level switch (tests compare both ways)
+
     def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False, d_model=256,
                  query_dim=4, num_feature_levels=1):
         super().__init__()
@@ -801,6 +806,10 @@ class TransformerDecoder(nn.Module):
         # the same for every layer: the ratios of a 4-d reference point and the [tokens, batch, C] text memory
         ratios4 = torch.cat([valid_ratios, valid_ratios], -1)[None, :] if reference_points.shape[-1] == 4 else None
         memory_text_lb = memory_text.transpose(0, 1).contiguous() if memory_text is not None else None
+        # ... and the value projections of all layers' deformable cross-attention: one autograd node whose input gradient
+        # is accumulated by the GEMMs themselves (None: the layers project for themselves)
+        memory_values = multi_value_projections([layer.cross_attn for layer in self.layers], memory.transpose(0, 1),
+                                                memory_key_padding_mask) if self.batch_value_projections else None
         for layer_id, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
                 reference_points_input = reference_points[:, :, None] * ratios4
@@ -819,7 +828,8 @@ class TransformerDecoder(nn.Module):
                 memory_key_padding_mask=memory_key_padding_mask,
                 memory_level_start_index=level_start_index, memory_spatial_shapes=spatial_shapes,
                 memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask,
-                memory_text_lb=memory_text_lb)
+                memory_text_lb=memory_text_lb,
+                memory_value=None if memory_values is None else memory_values[layer_id])
             adapter_loss = adapter_loss + adapter_loss_
 
             if self.bbox_embed is not None:  # iterative refinement, detached between layers
