@@ -171,6 +171,14 @@ int zira_attn_bwd_f32(const float *q, const float *k, const float *v, const floa
                       const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
                       float scale, float *dq, float *dk, float *dv, float *scratch, size_t scratch_floats, void *stream);
 
+/* The same with row strides lddq / lddk / lddv (floats between consecutive (l, b) rows; multiples of 4, >= H*32) for the
+ * gradients: dq, dk and dv may be column slices of one [rows, B, 3*H*32] buffer, which the input gradient of a packed
+ * in-projection then reads as ONE operand (the decoder's self-attention: q, k, v come from one GEMM and go back through one). */
+int zira_attn_bwd_ld_f32(const float *q, const float *k, const float *v, const float *key_mask, const float *out,
+                         const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
+                         float scale, float *dq, float *dk, float *dv, int lddq, int lddk, int lddv, float *scratch,
+                         size_t scratch_floats, void *stream);
+
 /* ---- ZiRa reparameterizable side branch (RSB): fused epilogue ---------------------------
  * Replaces the elementwise / reduction tail of RepZeroConv2d.forward and
  * RepZeroLinear.forward in training mode (reference
@@ -326,6 +334,51 @@ int zira_msda_sampling_fwd_f32(const float *proj, int ld, const float *ref, int 
                                int L, int P, float *loc, float *attn, void *stream);
 int zira_msda_sampling_bwd_f32(const float *grad_loc, const float *grad_attn, const float *attn, const float *ref, int R,
                                const int64_t *shapes, long long N, int M, int L, int P, float *grad_proj, int ld, void *stream);
+
+/* ---- Row-block GEMM of the decoder's queries with its prologues and epilogues (csrc/rowgemm.hip) ----------------
+ * C[M, N] = epilogue( prologue(A)[M, K] * op(W) ) in float32 on v_mfma_f32_16x16x4_f32 (exact fp32 products), 16 rows per
+ * workgroup: the nn.Linear calls of a decoder layer on its B x 900 query rows (reference transformer_for_adapter.py:
+ * 1001-1006 FFN, :1029-1071 attention in / out projections; ms_deform_attn.py:262-288, :338 the MSDA module's) together
+ * with the position-code add in front of them and the residual add + LayerNorm behind them, and the same for their input
+ * gradients.  All pointers are device pointers; every field not used stays 0 / NULL.
+ *   a, lda            A [M, K], row stride lda floats (rows in batch-first order when a_batch_first, see below)
+ *   pos, ldpos        optional [M, K]: the block's A is a + pos for output columns < pos_cols (a multiple of 128), a beyond
+ *   w, ldw, w_is_nk   w_is_nk = 1: W [N, K] and C = A W^T (forward of nn.Linear with its weight as stored);
+ *                     w_is_nk = 0: W [K, N] and C = A W   (the input gradient, again with the weight as stored)
+ *   bias              optional [N]
+ *   res, ldres        optional [M, N] added to the product (residual connection; or beta = 1 accumulation of a gradient)
+ *   mask              optional [M, N] contiguous: C = 0 where mask <= 0 (ReLU gradient, mask = the ReLU's output)
+ *   relu              C = max(C, 0)
+ *   ln_gamma, ln_beta, ln_eps, ln_sum, ln_mean, ln_rstd
+ *                     LayerNorm epilogue, taken when ln_gamma or ln_sum is set; needs N == 256.  c receives the normalised
+ *                     rows; ln_sum [M, N] (optional) the rows before normalisation, ln_mean / ln_rstd [M] (optional) the
+ *                     statistics: what the backward needs.  Two-pass variance.
+ *   lnb_x, lnb_gamma, lnb_mean, lnb_rstd, lnb_dx
+ *                     LayerNorm-backward prologue, taken when lnb_x is set (K == 256): a is dy [M, K], the operand of the
+ *                     product is dx = rstd (g - mean_c g - xhat mean_c(g xhat)), g = dy gamma, and dx is also written to
+ *                     lnb_dx [M, K] (optional): the gradient of the residual connection in front of the LayerNorm.
+ *   batch, a_batch_first, c_batch_first
+ *                     logical row r = q * batch + b ([queries, batch, C] tensors, as the decoder holds them); an operand marked
+ *                     batch-first lives at row b * (M / batch) + q ([batch, queries, C]: the MSDA op's side).  pos, res, mask
+ *                     and the LayerNorm arrays are always in logical row order.
+ * Shapes: K a multiple of 128 and <= 2048; N a multiple of 128; pointers 16-byte aligned, strides multiples of 4.
+ * Returns 0, -1 (NULL pointer), -2 (bad sizes), -3 (unsupported shape / alignment), -4 (launch failure). */
+typedef struct zira_rowgemm_args {
+    const float *a; int lda;
+    const float *pos; int ldpos; int pos_cols;
+    const float *w; int ldw; int w_is_nk;
+    const float *bias;
+    const float *res; int ldres;
+    const float *mask;
+    int relu;
+    const float *ln_gamma; const float *ln_beta; float ln_eps; float *ln_sum; float *ln_mean; float *ln_rstd;
+    const float *lnb_x; const float *lnb_gamma; const float *lnb_mean; const float *lnb_rstd; float *lnb_dx;
+    float *c; int ldc;
+    int m, n, k;
+    int batch, a_batch_first, c_batch_first;
+} zira_rowgemm_args;
+
+int zira_rowgemm_f32(const zira_rowgemm_args *args, void *stream);
 
 /* ---- Frozen FFN backward: GEMM with the ReLU gradient in its epilogue --------------------------
  * C[M, N] = (A[M, K] * B[K, N]) where H[M, N] > 0, else 0 (all row-major, contiguous; N % 128 == 0, K % 16 == 0; A and B

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device time of one decoder layer forward+backward at the bench shape, by kernel."""
+"""Device time of one decoder layer forward+backward at the bench shape, by kernel (NATIVE=0: the module composition)."""
 import os, sys, torch
 from torch.profiler import profile, ProfilerActivity
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +18,12 @@ shapes = torch.tensor(NORTH_STAR_SHAPES, device=dev)
 start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
 ref = torch.rand(Q, B, 4, 4, device=dev) * 0.5 + 0.25
 g = torch.randn(Q, B, 256, device=dev)
+NATIVE = os.environ.get("NATIVE", "1") == "1"
+layer.native_layer = NATIVE
 def step():
-    out = layer(tgt=tgt, tgt_query_pos=qpos, tgt_query_sine_embed=None, tgt_key_padding_mask=None,
+    # (the decoder projects the memory for all its layers at once: the layer's share is this GEMM and its gradient)
+    mv = layer.cross_attn.value_proj(memory.transpose(0, 1))
+    out = layer(memory_value=mv, tgt=tgt, tgt_query_pos=qpos, tgt_query_sine_embed=None, tgt_key_padding_mask=None,
                 tgt_reference_points=ref, memory_text=text, text_attention_mask=tmask, memory=memory,
                 memory_key_padding_mask=None, memory_level_start_index=start, memory_spatial_shapes=shapes,
                 memory_pos=None, self_attn_mask=None, cross_attn_mask=None)

@@ -1,0 +1,114 @@
+"""The decoder layer as one native autograd node (decoder_layer.py: rowgemm prologues / epilogues, attention, MSDA) against the
+module composition it replaces (reference transformer_for_adapter.py:910-1073): same output and the same gradients for the
+queries, the text memory and the projected image memory, to fp32 re-association."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(Q, B, T, shapes, seed=0, box_refs=True, pad_text=True):
+    from ziragroundingdino_amd import transformer
+    dev = torch.device("cuda")
+    torch.manual_seed(seed)
+    layer = transformer.DeformableTransformerDecoderLayer(256, 2048, 0.0, "relu", 4, 8, 4, use_text_cross_attention=True).to(dev).train()
+    with torch.no_grad():
+        for p in layer.parameters():   # (zero-initialised sampling offsets would hide errors in that path)
+            if p.dim() > 1:
+                p.normal_(0, 0.05)
+            else:
+                p.normal_(0, 0.1)
+        for n in (layer.norm1, layer.norm2, layer.norm3, layer.catext_norm):
+            n.weight.add_(1.0)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    inputs = dict(
+        tgt=rnd(Q, B, 256).requires_grad_(True), qpos=rnd(Q, B, 256),
+        text=rnd(B, T, 256).requires_grad_(True), value=rnd(B, S, 256).requires_grad_(True),
+        memory=rnd(S, B, 256),
+        ref=(torch.rand(Q, B, 4, 4 if box_refs else 2, generator=g) * 0.5 + 0.25).to(dev),
+        tmask=torch.zeros(B, T, dtype=torch.bool, device=dev),
+        shapes=torch.tensor(shapes, device=dev),
+        gout=rnd(Q, B, 256),
+    )
+    if pad_text:
+        inputs["tmask"][0, T - 3:] = True
+    sh = inputs["shapes"]
+    inputs["start"] = torch.cat([sh.new_zeros(1), (sh[:, 0] * sh[:, 1]).cumsum(0)[:-1]])
+    return layer, inputs
+
+
+def _run(layer, x, native):
+    layer.native_layer = native
+    out = layer(tgt=x["tgt"], tgt_query_pos=x["qpos"], tgt_query_sine_embed=None, tgt_key_padding_mask=None,
+                tgt_reference_points=x["ref"], memory_text=x["text"], text_attention_mask=x["tmask"], memory=x["memory"],
+                memory_key_padding_mask=None, memory_level_start_index=x["start"], memory_spatial_shapes=x["shapes"],
+                memory_pos=None, self_attn_mask=None, cross_attn_mask=None, memory_value=x["value"])[0]
+    grads = torch.autograd.grad((out * x["gout"]).sum(), [x["tgt"], x["text"], x["value"]])
+    return (out,) + grads
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("Q,B,T,shapes,box_refs", [
+    (900, 2, 16, [(25, 34), (13, 17), (7, 9), (4, 5)], True),
+    (100, 1, 7, [(12, 10), (6, 5), (3, 3), (2, 2)], True),
+    (37, 3, 32, [(16, 16), (8, 8), (4, 4), (2, 2)], False),
+])
+def test_native_layer_matches_module_composition(Q, B, T, shapes, box_refs):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    layer, x = _setup(Q, B, T, shapes, box_refs=box_refs)
+    import ziragroundingdino_amd.decoder_layer as native
+    calls = []
+    orig = native.decoder_layer_forward
+    native.decoder_layer_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        got = _run(layer, x, True)
+    finally:
+        native.decoder_layer_forward = orig
+    assert calls, "the native path did not run"
+    ref = _run(layer, x, False)
+    for name, a, b in zip(("out", "d tgt", "d text", "d value"), got, ref):
+        assert a.shape == b.shape, name
+        assert _rel(a, b) < 2e-4, (name, _rel(a, b))
+
+
+def test_native_layer_declines_what_it_does_not_cover():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ziragroundingdino_amd.decoder_layer as native
+    layer, x = _setup(50, 2, 8, [(8, 8), (4, 4), (2, 2), (1, 1)])
+    args = (layer, x["tgt"], x["qpos"], x["ref"], x["text"], x["value"], None, None)
+    assert native.applies(*args)
+    layer.linear1.weight.requires_grad_(True)      # a trainable weight: autograd must see the modules
+    assert not native.applies(*args)
+    layer.linear1.weight.requires_grad_(False)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not native.applies(*args)
+    assert not native.applies(layer, x["tgt"], x["qpos"], x["ref"], x["text"], x["value"], torch.zeros(50, 50, device="cuda"), None)
+    assert not native.applies(layer, x["tgt"], x["qpos"].requires_grad_(True), x["ref"], x["text"], x["value"], None, None)
+
+
+def test_native_layer_follows_weight_updates_in_place():
+    """The transposed weight copies are refreshed in place when a parameter changes (graphs keep reading the same buffers)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    layer, x = _setup(64, 2, 8, [(8, 8), (4, 4), (2, 2), (1, 1)])
+    _run(layer, x, True)
+    w = layer._native_weights
+    ptr = w.sa_in_t.data_ptr()
+    with torch.no_grad():
+        layer.self_attn.in_proj_weight.mul_(1.5)
+        layer.cross_attn.output_proj.weight.add_(0.01)
+    layer.refresh_fused_projection()
+    assert w.sa_in_t.data_ptr() == ptr
+    got = _run(layer, x, True)
+    ref = _run(layer, x, False)
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-4

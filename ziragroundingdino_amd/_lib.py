@@ -21,11 +21,32 @@ SYMBOLS = (
     "zira_layernorm_fwd_f32", "zira_layernorm_bwd_f32", "zira_add_layernorm_fwd_f32",
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32", "zira_window_attn_bf16",
-    "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32", "zira_gemm_drelu_f32",
+    "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_ld_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32", "zira_gemm_drelu_f32",
+    "zira_rowgemm_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
 _lib = None
+
+
+class RowGemmArgs(ctypes.Structure):
+    """``zira_rowgemm_args`` of include/zira_msda.h, field for field."""
+    _fields_ = [
+        ("a", ctypes.c_void_p), ("lda", ctypes.c_int),
+        ("pos", ctypes.c_void_p), ("ldpos", ctypes.c_int), ("pos_cols", ctypes.c_int),
+        ("w", ctypes.c_void_p), ("ldw", ctypes.c_int), ("w_is_nk", ctypes.c_int),
+        ("bias", ctypes.c_void_p),
+        ("res", ctypes.c_void_p), ("ldres", ctypes.c_int),
+        ("mask", ctypes.c_void_p),
+        ("relu", ctypes.c_int),
+        ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
+        ("ln_sum", ctypes.c_void_p), ("ln_mean", ctypes.c_void_p), ("ln_rstd", ctypes.c_void_p),
+        ("lnb_x", ctypes.c_void_p), ("lnb_gamma", ctypes.c_void_p), ("lnb_mean", ctypes.c_void_p),
+        ("lnb_rstd", ctypes.c_void_p), ("lnb_dx", ctypes.c_void_p),
+        ("c", ctypes.c_void_p), ("ldc", ctypes.c_int),
+        ("m", ctypes.c_int), ("n", ctypes.c_int), ("k", ctypes.c_int),
+        ("batch", ctypes.c_int), ("a_batch_first", ctypes.c_int), ("c_batch_first", ctypes.c_int),
+    ]
 
 
 class ExtensionMissingError(ImportError):
@@ -55,6 +76,8 @@ def load():
     lib.zira_attn_fwd_f32.restype = i
     lib.zira_attn_bwd_f32.argtypes = [vp] * 7 + [i] * 8 + [f32] + [vp] * 4 + [ctypes.c_size_t, vp]
     lib.zira_attn_bwd_f32.restype = i
+    lib.zira_attn_bwd_ld_f32.argtypes = [vp] * 7 + [i] * 8 + [f32] + [vp] * 3 + [i] * 3 + [vp, ctypes.c_size_t, vp]
+    lib.zira_attn_bwd_ld_f32.restype = i
     lib.zira_attn_bwd_scratch_floats.argtypes = [i] * 4
     lib.zira_attn_bwd_scratch_floats.restype = ctypes.c_size_t
     lib.zira_msda_fwd_cpu_f32.argtypes, lib.zira_msda_fwd_cpu_f32.restype = fwd_args[:-1], i   # host pointers, no stream
@@ -71,6 +94,8 @@ def load():
     lib.zira_msda_fwd_plan_f32.restype = i
     lib.zira_msda_bwd_planned_f32.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]
     lib.zira_msda_bwd_planned_f32.restype = i
+    lib.zira_rowgemm_f32.argtypes = [ctypes.POINTER(RowGemmArgs), vp]
+    lib.zira_rowgemm_f32.restype = i
     sz = ctypes.c_size_t
     lib.zira_rsb_workspace_floats.argtypes = [sz]
     lib.zira_rsb_workspace_floats.restype = sz

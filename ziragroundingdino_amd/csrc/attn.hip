@@ -45,6 +45,7 @@ struct AttnDims {
     int L, S, B, H;
     int ldq, ldk, ldv;
     float scale;
+    int lddq, lddk, lddv;   // row strides of the gradients (the backward's outputs)
 };
 
 // 16 floats: features 16 hh .. 16 hh + 15 of row `row` of a [rows, B, ld] tensor, head h, batch b
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq(const float *__restrict__ q, 
     const unsigned qq = tid >> 3, d4 = tid & 7;
     if (q0 + (int)qq < A.L) {
         const float *src = &so[qq][d4 * 4];
-        *reinterpret_cast<float4 *>(dq + ((size_t)(q0 + qq) * A.B + b) * E + h * kD + d4 * 4) =
+        *reinterpret_cast<float4 *>(dq + ((size_t)(q0 + qq) * A.B + b) * A.lddq + h * kD + d4 * 4) =
             make_float4(src[0] * A.scale, src[1] * A.scale, src[2] * A.scale, src[3] * A.scale);
     }
 }
@@ -352,27 +353,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const float *__restrict__ q,
     __syncthreads();
     const unsigned kk = tid >> 3, d4 = tid & 7;
     if (k0 + (int)kk < A.S) {
-        const size_t o = (((size_t)blockIdx.z * A.S + (k0 + kk)) * A.B + b) * E + h * kD + d4 * 4;   // (share z of the partial sums)
+        // QS > 1: share z of the partial sums, contiguous rows in scratch; otherwise the results with their own row strides
+        const size_t rowi = ((size_t)blockIdx.z * A.S + (k0 + kk)) * A.B + b, f = h * kD + d4 * 4;
         const float *a = &sk[kk][d4 * 4], *c = &sv[kk][d4 * 4];
-        *reinterpret_cast<float4 *>(dk + o) = make_float4(a[0] * A.scale, a[1] * A.scale, a[2] * A.scale, a[3] * A.scale);
-        *reinterpret_cast<float4 *>(dv + o) = make_float4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<float4 *>(dk + rowi * (QS > 1 ? E : A.lddk) + f) = make_float4(a[0] * A.scale, a[1] * A.scale, a[2] * A.scale, a[3] * A.scale);
+        *reinterpret_cast<float4 *>(dv + rowi * (QS > 1 ? E : A.lddv) + f) = make_float4(c[0], c[1], c[2], c[3]);
     }
 }
 
 // out[i] = part[0][i] + part[1][i] + ... (n4 float4 elements per part)
 __global__ __launch_bounds__(256) void attn_sum_parts(const float4 *__restrict__ pk, const float4 *__restrict__ pv, int parts, size_t n4,
-                                                      float4 *__restrict__ dk, float4 *__restrict__ dv)
+                                                      float4 *__restrict__ dk, float4 *__restrict__ dv, int e4, int lddk4, int lddv4)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
+    const size_t row = i / e4, col = i - row * e4;   // (rows of e4 float4s; the results have their own row strides)
     float4 a = pk[i], c = pv[i];
     for (int z = 1; z < parts; ++z) {
         const float4 x = pk[z * n4 + i], y = pv[z * n4 + i];
         a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
         c.x += y.x; c.y += y.y; c.z += y.z; c.w += y.w;
     }
-    dk[i] = a;
-    dv[i] = c;
+    dk[row * lddk4 + col] = a;
+    dv[row * lddv4 + col] = c;
 }
 
 // shares of the query tiles in the dK / dV kernel when there are few key blocks: enough blocks for ~1000, at least one
@@ -404,7 +407,7 @@ int zira_attn_fwd_f32(const float *q, const float *k, const float *v, const floa
                       int d, int ldq, int ldk, int ldv, float scale, float *out, float *lse, void *stream)
 {
     if (!attn_args_ok(q, k, v, L, S, B, H, d, ldq, ldk, ldv) || !out || !lse) return ZIRA_MSDA_EINVAL;
-    const AttnDims A = {L, S, B, H, ldq, ldk, ldv, scale};
+    const AttnDims A = {L, S, B, H, ldq, ldk, ldv, scale, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     const int nqt = (L + 31) / 32;
     if (S >= 256) {
@@ -428,10 +431,22 @@ int zira_attn_bwd_f32(const float *q, const float *k, const float *v, const floa
                       const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
                       float scale, float *dq, float *dk, float *dv, float *scratch, size_t scratch_floats, void *stream)
 {
+    return zira_attn_bwd_ld_f32(q, k, v, key_mask, out, dout, lse, L, S, B, H, d, ldq, ldk, ldv, scale, dq, dk, dv, H * kD, H * kD,
+                                H * kD, scratch, scratch_floats, stream);
+}
+
+int zira_attn_bwd_ld_f32(const float *q, const float *k, const float *v, const float *key_mask, const float *out,
+                         const float *dout, const float *lse, int L, int S, int B, int H, int d, int ldq, int ldk, int ldv,
+                         float scale, float *dq, float *dk, float *dv, int lddq, int lddk, int lddv, float *scratch,
+                         size_t scratch_floats, void *stream)
+{
     if (!attn_args_ok(q, k, v, L, S, B, H, d, ldq, ldk, ldv) || !out || !dout || !lse || !dq || !dk || !dv || !scratch ||
         scratch_floats < (size_t)B * H * L || ((uintptr_t)scratch & 15))
         return ZIRA_MSDA_EINVAL;
-    const AttnDims A = {L, S, B, H, ldq, ldk, ldv, scale};
+    if (lddq < H * kD || lddk < H * kD || lddv < H * kD || ((lddq | lddk | lddv) & 3) ||
+        (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15))
+        return ZIRA_MSDA_EINVAL;
+    const AttnDims A = {L, S, B, H, ldq, ldk, ldv, scale, lddq, lddk, lddv};
     hipStream_t st = (hipStream_t)stream;
     const int nqt = (L + 31) / 32, nkt = (S + 31) / 32;
     float *delta = scratch;                                   // [B, H, L]
@@ -448,7 +463,8 @@ int zira_attn_bwd_f32(const float *q, const float *k, const float *v, const floa
     }
     if (qs > 1)
         hipLaunchKernelGGL(attn_sum_parts, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(pk),
-                           reinterpret_cast<const float4 *>(pv), qs, n / 4, reinterpret_cast<float4 *>(dk), reinterpret_cast<float4 *>(dv));
+                           reinterpret_cast<const float4 *>(pv), qs, n / 4, reinterpret_cast<float4 *>(dk), reinterpret_cast<float4 *>(dv),
+                           H * kD / 4, lddk / 4, lddv / 4);
     return (int)hipGetLastError();
 }
 

@@ -608,6 +608,14 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     fuse_bias_relu = True   # bias + ReLU in the GEMM epilogue, as in the encoder layer
+    native_layer = True     # frozen fp32 GPU calls: the layer as one autograd node (decoder_layer.py); False: the module composition
+
+    def refresh_fused_projection(self, *unused):
+        """Weights the native path keeps transposed follow the parameters in place (GraphedTransformer calls this when a
+        parameter changed: a replayed graph re-runs no Python)."""
+        w = getattr(self, "_native_weights", None)
+        if w is not None:
+            w.refresh(self)
 
     def forward_ffn(self, tgt):
         with torch.amp.autocast("cuda", enabled=False):  # reference :1004 keeps the FFN in fp32
@@ -630,6 +638,19 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
                 cross_attn_mask=None, memory_text_lb=None, memory_value=None):
         assert cross_attn_mask is None
+        if self.native_layer and memory_value is not None:
+            # every weight frozen (a ZiRa task), fp32 on the GPU: the whole layer is one autograd node whose launches carry the
+            # adds, LayerNorms and their gradients in the GEMMs' prologues / epilogues (decoder_layer.py)
+            from . import decoder_layer as native
+            if native.applies(self, tgt, tgt_query_pos, tgt_reference_points, memory_text, memory_value, self_attn_mask,
+                              tgt_key_padding_mask):
+                text_lb = memory_text_lb if memory_text_lb is not None else memory_text.transpose(0, 1)
+                kpm = text_attention_mask
+                if kpm is not None and kpm.dtype == torch.bool:
+                    kpm = _additive_mask(kpm, tgt.dtype)
+                out = native.decoder_layer_forward(self, tgt, tgt_query_pos, tgt_reference_points, text_lb, kpm, memory_value,
+                                                   memory_spatial_shapes, memory_level_start_index)
+                return out, tgt.new_zeros(1)
         if self.self_attn is not None:
             q = k = self.with_pos_embed(tgt, tgt_query_pos)
             tgt2 = _mha(self.self_attn, q, k, tgt, attn_mask=self_attn_mask)
