@@ -11,7 +11,8 @@ for p in layer.parameters(): p.requires_grad_(False)
 S = sum(h * w for h, w in NORTH_STAR_SHAPES); Q, B, T = 900, 2, 16
 tgt = torch.randn(Q, B, 256, device=dev, requires_grad=True)
 qpos = torch.randn(Q, B, 256, device=dev)
-memory = torch.randn(S, B, 256, device=dev, requires_grad=True)
+memory_bf = torch.randn(B, S, 256, device=dev, requires_grad=True)   # (the encoder's output is batch-first)
+memory = memory_bf.transpose(0, 1)
 text = torch.randn(B, T, 256, device=dev, requires_grad=True)
 tmask = torch.zeros(B, T, dtype=torch.bool, device=dev)
 shapes = torch.tensor(NORTH_STAR_SHAPES, device=dev)
@@ -28,7 +29,7 @@ def step():
                 memory_key_padding_mask=None, memory_level_start_index=start, memory_spatial_shapes=shapes,
                 memory_pos=None, self_attn_mask=None, cross_attn_mask=None)
     out = out[0] if isinstance(out, tuple) else out
-    torch.autograd.grad((out * g).sum(), [tgt, memory, text])
+    torch.autograd.grad(out, [tgt, memory_bf, text], grad_outputs=g)
 for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:

@@ -8,7 +8,7 @@ a tensor has several consumers, and the copies between the decoder's [queries, b
 (``rowgemm``, csrc/rowgemm.hip), and the backward is written down once:
 
   forward                                            backward (gradient g of the layer output)
-  qkv  = [tgt + pos | tgt] Win^T                     ds4, gh = LNbwd(g), (ds4 W2) * (h > 0)        (layernorm + gemm_drelu)
+  qkv  = [tgt + pos | tgt] Win^T                     ds4, gh = LNbwd(g), (ds4 W2) * (h > 0)
   o1   = attention(q, k, v)                          g3   = gh W1 + ds4                            (addmm, beta = 1)
   t1   = LN(tgt + o1 Wo^T)                           go3, ds3 = (LNbwd(g3)) Wout, LNbwd(g3)        -> MSDA backward, batch-first
   q2   = (t1 + pos) Wq^T ; kv2 = text Wkv^T          g2   = gproj Wsamp + ds3
@@ -215,15 +215,9 @@ class _FrozenDecoderLayer(torch.autograd.Function):
         scale = 1.0 / math.sqrt(32.0)
         g = g.contiguous().view(Q * B, E)
         with torch.cuda.device(dev):
-            # ---- FFN ----
-            ds4, gh = torch.empty_like(s4), torch.empty_like(h)
-            rc = lib.zira_layernorm_bwd_f32(g.data_ptr(), s4.data_ptr(), layer.norm3.weight.data_ptr(), stats4[0].data_ptr(),
-                                            stats4[1].data_ptr(), Q * B, E, ds4.data_ptr(), st)
-            if rc == 0:
-                rc = lib.zira_gemm_drelu_f32(ds4.data_ptr(), layer.linear2.weight.data_ptr(), h.data_ptr(), Q * B, h.shape[1], E,
-                                             gh.data_ptr(), st)
-            if rc != 0:
-                raise RuntimeError("decoder FFN backward failed with code %d" % rc)
+            # ---- FFN ----  (LayerNorm gradient, product with W2 and the ReLU gradient in one launch)
+            gh, ds4 = rowgemm(g, layer.linear2.weight, w_is_nk=False, mask=h, lnb=(s4, layer.norm3.weight, stats4[0], stats4[1]),
+                              lnb_save=True)
             g3 = torch.addmm(ds4, gh, layer.linear1.weight)
             # ---- MSDA cross-attention ----
             go3, ds3 = rowgemm(g3, ms.output_proj.weight, w_is_nk=False, lnb=(s3, layer.norm1.weight, m3, r3), lnb_save=True,
