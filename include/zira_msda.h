@@ -395,6 +395,17 @@ int zira_gemm_drelu_f32(const float *A, const float *B, const float *H, int M, i
 int zira_sine_embed_f32(const float *pos, const float *dim_t, long long rows, int C, int T, float scale, float *out,
                         void *stream);
 
+/* Iterative box refinement of the decoder (transformer_for_adapter.py:790-797, inverse_sigmoid util/misc.py:704-708): the
+ * last layer of the box MLP (4 outputs) with the inverse-sigmoid of the current boxes added and the sigmoid taken,
+ *   new_ref[r, j] = sigmoid(<h[r, :], w[j, :]> + b[j] + log(max(x, eps) / max(1 - x, eps))),  x = clamp(ref[r, j], 0, 1),
+ * for h [rows, K] (the MLP's second hidden layer after its ReLU), w [4, K], b [4], ref / new_ref [rows, 4]; and the gradient
+ * it sends back in front of that ReLU: g_h[r, k] = (sum_j g_new[r, j] s (1 - s) w[j, k]) where h[r, k] > 0, s = new_ref[r, j].
+ * K a multiple of 4; h, w, g_h 16-byte aligned.  Device pointers. */
+int zira_box_refine_fwd_f32(const float *h, const float *w, const float *b, const float *ref, long long rows, int K, float eps,
+                            float *new_ref, void *stream);
+int zira_box_refine_bwd_f32(const float *g_new, const float *new_ref, const float *w, const float *h, long long rows, int K,
+                            float *g_h, void *stream);
+
 
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);

@@ -139,3 +139,54 @@ def test_native_layer_follows_weight_updates_in_place():
     ref = _run(layer, x, False)
     assert _rel(got[0], ref[0]) < 2e-5
     assert _bad_row_fraction(got[1], ref[1], 2e-4) < 0.02 and _rel(got[2], ref[2]) < 5e-3
+
+
+def _glue_setup(Q=900, B=2, seed=3):
+    import types
+    from ziragroundingdino_amd.dense import LayerNorm
+    from ziragroundingdino_amd.utils import MLP
+    dev = torch.device("cuda")
+    torch.manual_seed(seed)
+    mlp = MLP(256, 256, 4, 3).to(dev)
+    norm = LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.normal_(1.0, 0.1)
+        norm.bias.normal_(0.0, 0.1)
+        mlp.layers[2].weight.normal_(0, 0.05)
+    for p in list(mlp.parameters()) + list(norm.parameters()):
+        p.requires_grad_(False)
+    dec = types.SimpleNamespace(bbox_embed=torch.nn.ModuleList([mlp]), norm=norm)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = torch.randn(Q, B, 256, generator=g).to(dev).requires_grad_(True)
+    ref = torch.rand(Q, B, 4, generator=g).to(dev)
+    ref[0, 0] = torch.tensor([0.0, 1.0, 0.0005, 0.9999])     # the clamps of inverse_sigmoid
+    g_new = torch.randn(Q, B, 4, generator=g).to(dev)
+    g_norm = torch.randn(Q, B, 256, generator=g).to(dev)
+    return dec, out, ref, g_new, g_norm
+
+
+@pytest.mark.parametrize("Q,B", [(900, 2), (37, 3)])
+def test_refine_and_norm_matches_the_op_chain(Q, B):
+    """Box MLP + inverse_sigmoid + sigmoid and the intermediate LayerNorm as one node (reference
+    transformer_for_adapter.py:790-803) against the PyTorch ops, forward and backward, with either output unused."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ziragroundingdino_amd.decoder_layer as native
+    from ziragroundingdino_amd.utils import inverse_sigmoid
+    dec, out, ref, g_new, g_norm = _glue_setup(Q, B)
+    assert native.refine_applies(dec, 0, out, ref)
+    new_ref, normed = native.refine_and_norm(dec, 0, out, ref)
+    r_new = (dec.bbox_embed[0](out) + inverse_sigmoid(ref)).sigmoid()
+    r_norm = torch.nn.functional.layer_norm(out, (256,), dec.norm.weight, dec.norm.bias, dec.norm.eps)
+    assert _rel(new_ref, r_new) < 1e-5 and _rel(normed, r_norm) < 1e-5
+    for use_new, use_norm in ((True, True), (True, False), (False, True)):
+        outs, refs, gs = [], [], []
+        if use_new:
+            outs.append(new_ref); refs.append(r_new); gs.append(g_new)
+        if use_norm:
+            outs.append(normed); refs.append(r_norm); gs.append(g_norm)
+        (got,) = torch.autograd.grad(outs, [out], gs, retain_graph=True)
+        (want,) = torch.autograd.grad(refs, [out], gs, retain_graph=True)
+        assert _rel(got, want) < 2e-5, (use_new, use_norm, _rel(got, want))
+    dec.bbox_embed[0].layers[0].weight.requires_grad_(True)
+    assert not native.refine_applies(dec, 0, out, ref)

@@ -31,7 +31,94 @@ __global__ __launch_bounds__(256) void sine_embed_kernel(const float *__restrict
     out[idx] = (i & 1) ? cosf(arg) : sinf(arg);
 }
 
+// ---- iterative box refinement: the last layer of the box MLP with the inverse-sigmoid / sigmoid around it ----
+// new_ref[row, j] = sigmoid(<h[row, :], w[j, :]> + b[j] + log(max(x, eps) / max(1 - x, eps))),  x = clamp(ref[row, j], 0, 1)
+// (reference transformer_for_adapter.py:790-797: delta_unsig = bbox_embed(output); (delta_unsig + inverse_sigmoid(ref)).sigmoid();
+// util/misc.py:704-708).  A wave per row: a lane takes float4s of the row, four dot products, wave reduction.
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void box_refine_fwd_kernel(const float *__restrict__ h, const float *__restrict__ w,
+                                                             const float *__restrict__ b, const float *__restrict__ ref,
+                                                             long long rows, int K, float eps, float *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 4 * lane; k < K; k += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(h + row * K + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 y = *reinterpret_cast<const float4 *>(w + (long long)j * K + k);
+            acc[j] += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+    if (lane < 4) {
+        const float d = (lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + b[lane];
+        const float x = fminf(fmaxf(ref[row * 4 + lane], 0.f), 1.f);
+        const float inv = logf(fmaxf(x, eps) / fmaxf(1.f - x, eps));
+        out[row * 4 + lane] = 1.f / (1.f + expf(-(d + inv)));
+    }
+}
+
+// g_h[row, k] = (sum_j g_new[row, j] * s (1 - s) * w[j, k]) where h[row, k] > 0, s = new_ref[row, j]: the gradient in front
+// of the ReLU that feeds the last layer of the box MLP
+__global__ __launch_bounds__(256) void box_refine_bwd_kernel(const float *__restrict__ g_new, const float *__restrict__ new_ref,
+                                                             const float *__restrict__ w, const float *__restrict__ h,
+                                                             long long rows, int K, float *__restrict__ g_h)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float gd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float s = new_ref[row * 4 + j];
+        gd[j] = g_new[row * 4 + j] * (s * (1.f - s));
+    }
+    for (int k = 4 * lane; k < K; k += 256) {
+        const float4 m = *reinterpret_cast<const float4 *>(h + row * K + k);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 y = *reinterpret_cast<const float4 *>(w + (long long)j * K + k);
+            r.x += gd[j] * y.x; r.y += gd[j] * y.y; r.z += gd[j] * y.z; r.w += gd[j] * y.w;
+        }
+        r.x = m.x > 0.f ? r.x : 0.f; r.y = m.y > 0.f ? r.y : 0.f; r.z = m.z > 0.f ? r.z : 0.f; r.w = m.w > 0.f ? r.w : 0.f;
+        *reinterpret_cast<float4 *>(g_h + row * K + k) = r;
+    }
+}
+
 }  // namespace
+
+extern "C" int zira_box_refine_fwd_f32(const float *h, const float *w, const float *b, const float *ref, long long rows, int K,
+                                       float eps, float *new_ref, void *stream)
+{
+    if (!h || !w || !b || !ref || !new_ref || rows < 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
+    if ((((uintptr_t)h | (uintptr_t)w) & 15) != 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(box_refine_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, w, b, ref,
+                       rows, K, eps, new_ref);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_box_refine_bwd_f32(const float *g_new, const float *new_ref, const float *w, const float *h, long long rows,
+                                       int K, float *g_h, void *stream)
+{
+    if (!g_new || !new_ref || !w || !h || !g_h || rows < 0 || K <= 0 || (K & 3)) return (int)hipErrorInvalidValue;
+    if ((((uintptr_t)h | (uintptr_t)w | (uintptr_t)g_h) & 15) != 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(box_refine_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_new, new_ref,
+                       w, h, rows, K, g_h);
+    return (int)hipGetLastError();
+}
 
 extern "C" int zira_sine_embed_f32(const float *pos, const float *dim_t, long long rows, int C, int T, float scale,
                                    float *out, void *stream)

@@ -277,3 +277,128 @@ def decoder_layer_forward(layer, tgt: Tensor, pos: Tensor, ref: Tensor, text_lb:
     memory_value = memory_value.view(B, S, ms.num_heads, -1)
     ref_bf = ref.transpose(0, 1).contiguous()
     return _FrozenDecoderLayer.apply(layer, tgt, pos, ref_bf, text_lb, text_mask, memory_value, shapes, level_start)
+
+
+# ---- between the layers: iterative box refinement + the LayerNorm of the intermediate output --------------------------------
+# (reference TransformerDecoder.forward, transformer_for_adapter.py:700-806: per layer  delta = bbox_embed(output);
+#  new_ref = sigmoid(delta + inverse_sigmoid(ref));  intermediate.append(norm(output)) -- as PyTorch ops 14 launches forward
+#  and 8 backward on 1800 rows, plus the add autograd needs because `output` feeds both.)
+
+class MLPWeights:
+    """Transposed copies of the first two layers of a frozen box MLP (the forward's rowgemm wants [K, N])."""
+
+    def __init__(self, mlp):
+        self.key = None
+        self.refresh(mlp)
+
+    def refresh(self, mlp):
+        l0, l1 = mlp.layers[0], mlp.layers[1]
+        key = tuple((p.data_ptr(), p._version) for p in (l0.weight, l1.weight))
+        if key == self.key:
+            return
+        with torch.no_grad():
+            if self.key is None:
+                self.w0_t, self.w1_t = l0.weight.t().contiguous().clone(), l1.weight.t().contiguous().clone()
+            else:   # in place: captured graphs read these buffers
+                self.w0_t.copy_(l0.weight.t())
+                self.w1_t.copy_(l1.weight.t())
+        self.key = key
+
+
+def _mlp_weights(mlp) -> MLPWeights:
+    w = getattr(mlp, "_native_weights", None)
+    if w is None:
+        w = mlp._native_weights = MLPWeights(mlp)
+    else:
+        w.refresh(mlp)
+    return w
+
+
+def refine_applies(decoder, layer_id, output, ref) -> bool:
+    """Whether ``refine_and_norm`` can run: fp32 GPU call outside autocast, frozen 256 -> 256 -> 256 -> 4 box MLP with
+    biases, frozen affine LayerNorm, 4-d reference boxes that take no part in autograd."""
+    if not (output.is_cuda and output.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")):
+        return False
+    if decoder.bbox_embed is None or decoder.norm is None or ref.shape[-1] != 4 or ref.requires_grad:
+        return False
+    mlp, norm = decoder.bbox_embed[layer_id], decoder.norm
+    layers = getattr(mlp, "layers", None)
+    if layers is None or len(layers) != 3 or output.shape[-1] != 256:
+        return False
+    if [tuple(l.weight.shape) for l in layers] != [(256, 256), (256, 256), (4, 256)] or any(l.bias is None for l in layers):
+        return False
+    params = [p for l in layers for p in (l.weight, l.bias)] + [norm.weight, norm.bias]
+    if any(p is None or p.requires_grad or p.dtype != torch.float32 for p in params):
+        return False
+    return tuple(norm.normalized_shape) == (256,)
+
+
+class _RefineAndNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, decoder, layer_id, output, ref):
+        lib = _lib.load()
+        mlp, norm = decoder.bbox_embed[layer_id], decoder.norm
+        w = _mlp_weights(mlp)
+        l0, l1, l2 = mlp.layers
+        Q, B, E = output.shape
+        rows = Q * B
+        dev = output.device
+        output = output.contiguous()
+        ref = ref.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            h1 = rowgemm(output, w.w0_t, w_is_nk=False, bias=l0.bias, relu=True)
+            h2 = rowgemm(h1, w.w1_t, w_is_nk=False, bias=l1.bias, relu=True)
+            new_ref = torch.empty((Q, B, 4), **f32)
+            rc = lib.zira_box_refine_fwd_f32(h2.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(), ref.data_ptr(), rows, E, 1e-3,
+                                             new_ref.data_ptr(), st)
+            if rc != 0:
+                raise RuntimeError("zira_box_refine_fwd_f32 failed with code %d" % rc)
+            normed = torch.empty_like(output)
+            stats = torch.empty((2, rows), **f32)
+            rc = lib.zira_layernorm_fwd_f32(output.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), rows, E, float(norm.eps),
+                                            normed.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), st)
+            if rc != 0:
+                raise RuntimeError("zira_layernorm_fwd_f32 failed with code %d" % rc)
+        ctx.mods = (mlp, norm)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(output, h1, h2, new_ref, stats)
+        return new_ref, normed
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_new, g_normed):
+        output, h1, h2, new_ref, stats = ctx.saved_tensors
+        mlp, norm = ctx.mods
+        l0, l1, l2 = mlp.layers
+        lib = _lib.load()
+        Q, B, E = output.shape
+        rows = Q * B
+        dev = output.device
+        gx = None
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            if g_normed is not None:
+                g_normed = g_normed.contiguous()
+                gx = torch.empty_like(output)
+                rc = lib.zira_layernorm_bwd_f32(g_normed.data_ptr(), output.data_ptr(), norm.weight.data_ptr(), stats[0].data_ptr(),
+                                                stats[1].data_ptr(), rows, E, gx.data_ptr(), st)
+                if rc != 0:
+                    raise RuntimeError("zira_layernorm_bwd_f32 failed with code %d" % rc)
+            if g_new is not None:
+                g_new = g_new.contiguous()
+                gh2 = torch.empty_like(h2)
+                rc = lib.zira_box_refine_bwd_f32(g_new.data_ptr(), new_ref.data_ptr(), l2.weight.data_ptr(), h2.data_ptr(), rows, E,
+                                                 gh2.data_ptr(), st)
+                if rc != 0:
+                    raise RuntimeError("zira_box_refine_bwd_f32 failed with code %d" % rc)
+                gh1 = rowgemm(gh2, l1.weight, w_is_nk=False, mask=h1)
+                gx = rowgemm(gh1, l0.weight, w_is_nk=False, res=gx).view(Q, B, E)
+        return None, None, gx, None
+
+
+def refine_and_norm(decoder, layer_id, output: Tensor, ref: Tensor):
+    """(sigmoid(bbox_embed[layer_id](output) + inverse_sigmoid(ref)), norm(output)) as one autograd node: 4 launches forward,
+    4 backward, and the two gradients of ``output`` meet inside the last GEMM.  Call only when ``refine_applies()`` said so."""
+    return _RefineAndNorm.apply(decoder, layer_id, output, ref)

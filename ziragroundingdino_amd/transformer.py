@@ -795,6 +795,7 @@ class TransformerDecoder(nn.Module):
     """Six layers with iterative box refinement (reference transformer_for_adapter.py:665-806)."""
 
     batch_value_projections = True   # class-level switch (tests compare both ways)
+    native_glue = True               # frozen fp32 GPU calls: box refinement + intermediate LayerNorm as one node (decoder_layer.py)
 
     def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False, d_model=256,
                  query_dim=4, num_feature_levels=1):
@@ -853,6 +854,15 @@ class TransformerDecoder(nn.Module):
                 memory_value=None if memory_values is None else memory_values[layer_id])
             adapter_loss = adapter_loss + adapter_loss_
 
+            if self.native_glue and self.bbox_embed is not None and output.is_cuda:
+                from . import decoder_layer as native
+                if native.refine_applies(self, layer_id, output, reference_points):
+                    # box MLP + inverse-sigmoid + sigmoid and the LayerNorm of the intermediate output: one autograd node
+                    new_reference_points, normed = native.refine_and_norm(self, layer_id, output, reference_points)
+                    reference_points = new_reference_points.detach()
+                    ref_points.append(new_reference_points)
+                    intermediate.append(normed)
+                    continue
             if self.bbox_embed is not None:  # iterative refinement, detached between layers
                 delta_unsig = self.bbox_embed[layer_id](output)
                 new_reference_points = (delta_unsig + inverse_sigmoid(reference_points)).sigmoid()

@@ -65,6 +65,13 @@ class MLP(nn.Module):
                 x = F.relu(x)
         return x
 
+    def refresh_fused_projection(self, *unused):
+        """Transposed weight copies kept by the native decoder path (decoder_layer.MLPWeights) follow the parameters in
+        place (GraphedTransformer calls this when a parameter changed: a replayed graph re-runs no Python)."""
+        w = getattr(self, "_native_weights", None)
+        if w is not None:
+            w.refresh(self)
+
 
 _SINE_CONSTS = {}
 
