@@ -395,6 +395,14 @@ int zira_gemm_drelu_f32(const float *A, const float *B, const float *H, int M, i
 int zira_sine_embed_f32(const float *pos, const float *dim_t, long long rows, int C, int T, float scale, float *out,
                         void *stream);
 
+/* What a decoder layer needs of the current boxes, in one launch (transformer_for_adapter.py:760-770): for ref [Q, B, 4] (sigmoid
+ * space, no gradient) and valid ratios ratio [B, L, 2]
+ *   ref_in [Q, B, L, 4] = ref[:, :, None] * cat([ratio, ratio], -1)     ref_bf [B, Q, L, 4] = the same, batch-first
+ *   sine   [Q, B, 4 T]  = zira_sine_embed_f32 of ref_in[:, :, 0, :]     (T >= L)
+ * with the multiplies and divides of the PyTorch op chain (bit-identical to it). */
+int zira_decoder_prep_f32(const float *ref, const float *ratio, const float *dim_t, int Q, int B, int L, int T, float scale,
+                          float *ref_in, float *ref_bf, float *sine, void *stream);
+
 /* Iterative box refinement of the decoder (transformer_for_adapter.py:790-797, inverse_sigmoid util/misc.py:704-708): the
  * last layer of the box MLP (4 outputs) with the inverse-sigmoid of the current boxes added and the sigmoid taken,
  *   new_ref[r, j] = sigmoid(<h[r, :], w[j, :]> + b[j] + log(max(x, eps) / max(1 - x, eps))),  x = clamp(ref[r, j], 0, 1),

@@ -190,3 +190,30 @@ def test_refine_and_norm_matches_the_op_chain(Q, B):
         assert _rel(got, want) < 2e-5, (use_new, use_norm, _rel(got, want))
     dec.bbox_embed[0].layers[0].weight.requires_grad_(True)
     assert not native.refine_applies(dec, 0, out, ref)
+
+
+def test_prep_queries_matches_the_op_chain():
+    """Boxes per level in both layouts and their sine embedding: bit-identical to the PyTorch ops (reference
+    transformer_for_adapter.py:760-770); the position MLP to 1e-5."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import types
+    import ziragroundingdino_amd.decoder_layer as native
+    from ziragroundingdino_amd.utils import MLP, gen_sineembed_for_position
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    head = MLP(512, 256, 256, 2).to(dev)
+    for p in head.parameters():
+        p.requires_grad_(False)
+    dec = types.SimpleNamespace(ref_point_head=head, query_scale=None, query_pos_sine_scale=None)
+    for Q, B, L in ((900, 2, 4), (33, 3, 4), (7, 1, 2)):
+        ref = torch.rand(Q, B, 4, device=dev)
+        ratios = torch.rand(B, L, 2, device=dev) * 0.5 + 0.5
+        assert native.prep_applies(dec, ref, ratios)
+        ref_in, ref_bf, sine, qpos = native.prep_queries(dec, ref, ratios)
+        want_in = ref[:, :, None] * torch.cat([ratios, ratios], -1)[None, :]
+        want_sine = gen_sineembed_for_position(want_in[:, :, 0, :])
+        assert torch.equal(ref_in, want_in) and torch.equal(ref_bf, want_in.transpose(0, 1).contiguous())
+        assert torch.equal(sine, want_sine)
+        assert _rel(qpos, head(want_sine)) < 1e-5
+    assert not native.prep_applies(dec, ref.requires_grad_(True), ratios)

@@ -22,7 +22,7 @@ SYMBOLS = (
     "zira_lsap_workspace_bytes", "zira_lsap_f32", "zira_match_cost_f32",
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32", "zira_window_attn_bf16",
     "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_ld_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32", "zira_gemm_drelu_f32",
-    "zira_rowgemm_f32", "zira_box_refine_fwd_f32", "zira_box_refine_bwd_f32",
+    "zira_rowgemm_f32", "zira_box_refine_fwd_f32", "zira_box_refine_bwd_f32", "zira_decoder_prep_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -95,6 +95,8 @@ def load():
     lib.zira_msda_bwd_planned_f32.argtypes = bwd_args[:-1] + [vp, ctypes.c_size_t, vp]
     lib.zira_msda_bwd_planned_f32.restype = i
     lib.zira_rowgemm_f32.argtypes = [ctypes.POINTER(RowGemmArgs), vp]
+    lib.zira_decoder_prep_f32.argtypes = [vp, vp, vp, i, i, i, i, ctypes.c_float, vp, vp, vp, vp]
+    lib.zira_decoder_prep_f32.restype = i
     lib.zira_box_refine_fwd_f32.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, i, ctypes.c_float, vp, vp]
     lib.zira_box_refine_fwd_f32.restype = i
     lib.zira_box_refine_bwd_f32.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, i, vp, vp]

@@ -31,6 +31,36 @@ __global__ __launch_bounds__(256) void sine_embed_kernel(const float *__restrict
     out[idx] = (i & 1) ? cosf(arg) : sinf(arg);
 }
 
+// ---- what a decoder layer needs of the current boxes, one launch (reference transformer_for_adapter.py:760-770) ----
+//   ref_in[q, b, l, c] = ref[q, b, c] * ratio[b, l, c & 1]      (reference_points[:, :, None] * cat([valid_ratios, valid_ratios], -1))
+//   ref_bf[b, q, l, c] = the same, batch-first (the layout the MSDA sampling kernel reads)
+//   sine[q, b, :]      = the sine embedding of ref_in[q, b, 0, :]  (gen_sineembed_for_position: the kernel above)
+// A thread per sine element; the threads with i < L also write the two box tensors.  Same multiplies and divides as the op chain.
+__global__ __launch_bounds__(256) void decoder_prep_kernel(const float *__restrict__ ref, const float *__restrict__ ratio,
+                                                           const float *__restrict__ dim_t, int Q, int B, int L, int T, float scale,
+                                                           float *__restrict__ ref_in, float *__restrict__ ref_bf,
+                                                           float *__restrict__ sine)
+{
+#pragma clang fp contract(off)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Q * B * 4 * T) return;
+    const int i = (int)(idx % T);
+    const long long rp = idx / T;
+    const int part = (int)(rp & 3);
+    const long long row = rp >> 2;           // q * B + b
+    const int b = (int)(row % B);
+    const long long q = row / B;
+    if (i < L) {
+        const float v = __fmul_rn(ref[row * 4 + part], ratio[((long long)b * L + i) * 2 + (part & 1)]);
+        ref_in[(row * L + i) * 4 + part] = v;
+        ref_bf[(((long long)b * Q + q) * L + i) * 4 + part] = v;
+    }
+    const int coord = part == 0 ? 1 : (part == 1 ? 0 : part);   // (y, x, w, h) <- (x, y, w, h)
+    const float x = __fmul_rn(ref[row * 4 + coord], ratio[(long long)b * L * 2 + (coord & 1)]);
+    const float arg = __fdiv_rn(__fmul_rn(x, scale), dim_t[i]);
+    sine[idx] = (i & 1) ? cosf(arg) : sinf(arg);
+}
+
 // ---- iterative box refinement: the last layer of the box MLP with the inverse-sigmoid / sigmoid around it ----
 // new_ref[row, j] = sigmoid(<h[row, :], w[j, :]> + b[j] + log(max(x, eps) / max(1 - x, eps))),  x = clamp(ref[row, j], 0, 1)
 // (reference transformer_for_adapter.py:790-797: delta_unsig = bbox_embed(output); (delta_unsig + inverse_sigmoid(ref)).sigmoid();
@@ -117,6 +147,17 @@ extern "C" int zira_box_refine_bwd_f32(const float *g_new, const float *new_ref,
     if (rows == 0) return 0;
     hipLaunchKernelGGL(box_refine_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_new, new_ref,
                        w, h, rows, K, g_h);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_decoder_prep_f32(const float *ref, const float *ratio, const float *dim_t, int Q, int B, int L, int T,
+                                    float scale, float *ref_in, float *ref_bf, float *sine, void *stream)
+{
+    if (!ref || !ratio || !dim_t || !ref_in || !ref_bf || !sine || Q < 0 || B <= 0 || L <= 0 || T < L) return (int)hipErrorInvalidValue;
+    const long long n = (long long)Q * B * 4 * T;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(decoder_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref, ratio, dim_t,
+                       Q, B, L, T, scale, ref_in, ref_bf, sine);
     return (int)hipGetLastError();
 }
 

@@ -266,7 +266,7 @@ class _FrozenDecoderLayer(torch.autograd.Function):
 
 
 def decoder_layer_forward(layer, tgt: Tensor, pos: Tensor, ref: Tensor, text_lb: Tensor, text_mask: Optional[Tensor],
-                          memory_value: Tensor, shapes: Tensor, level_start: Tensor) -> Tensor:
+                          memory_value: Tensor, shapes: Tensor, level_start: Tensor, ref_bf: Optional[Tensor] = None) -> Tensor:
     """The layer's output [Q, B, C] for ``tgt`` / ``pos`` [Q, B, C], reference points ``ref`` [Q, B, L, 2 | 4], text memory
     ``text_lb`` [T, B, C] with additive key mask ``text_mask`` [B, T] (or None) and ``memory_value`` = the layer's
     value_proj(memory) [B, S, M, D] with padded rows zeroed.  Call only when ``applies()`` said so."""
@@ -275,7 +275,8 @@ def decoder_layer_forward(layer, tgt: Tensor, pos: Tensor, ref: Tensor, text_lb:
     B, S = memory_value.shape[:2]
     _check_levels_cover_value(shapes, S, level_start)
     memory_value = memory_value.view(B, S, ms.num_heads, -1)
-    ref_bf = ref.transpose(0, 1).contiguous()
+    if ref_bf is None:   # (``ref_bf``: the reference points batch-first, when the caller has them: prep_queries)
+        ref_bf = ref.transpose(0, 1).contiguous()
     return _FrozenDecoderLayer.apply(layer, tgt, pos, ref_bf, text_lb, text_mask, memory_value, shapes, level_start)
 
 
@@ -402,3 +403,56 @@ def refine_and_norm(decoder, layer_id, output: Tensor, ref: Tensor):
     """(sigmoid(bbox_embed[layer_id](output) + inverse_sigmoid(ref)), norm(output)) as one autograd node: 4 launches forward,
     4 backward, and the two gradients of ``output`` meet inside the last GEMM.  Call only when ``refine_applies()`` said so."""
     return _RefineAndNorm.apply(decoder, layer_id, output, ref)
+
+
+# ---- in front of a layer: the boxes scaled per level, their sine embedding and the query position code -----------------------
+
+def prep_applies(decoder, reference_points, valid_ratios) -> bool:
+    """Whether ``prep_queries`` can run: fp32 GPU boxes [Q, B, 4] outside autograd and autocast, frozen 512 -> 256 -> 256
+    position MLP with biases, no query scale."""
+    from .utils import NATIVE_REFPOINT_OPS
+    if not (NATIVE_REFPOINT_OPS and reference_points.is_cuda and reference_points.dtype == torch.float32
+            and reference_points.dim() == 3 and reference_points.shape[-1] == 4 and not torch.is_autocast_enabled("cuda")):
+        return False
+    if reference_points.requires_grad or valid_ratios.requires_grad or valid_ratios.dtype != torch.float32:
+        return False
+    if decoder.query_scale is not None or decoder.query_pos_sine_scale is not None:
+        return False
+    layers = getattr(decoder.ref_point_head, "layers", None)
+    if layers is None or len(layers) != 2 or [tuple(l.weight.shape) for l in layers] != [(256, 512), (256, 256)]:
+        return False
+    return all(l.bias is not None and not l.weight.requires_grad and not l.bias.requires_grad and l.weight.dtype == torch.float32
+               for l in layers)
+
+
+_DIM_T = {}
+
+
+def prep_queries(decoder, reference_points: Tensor, valid_ratios: Tensor):
+    """(reference_points_input [Q, B, L, 4], the same batch-first [B, Q, L, 4], query_sine_embed [Q, B, 512], query_pos [Q, B, 256])
+    of a decoder layer (reference transformer_for_adapter.py:760-776) in three launches; no autograd (nothing here has a
+    gradient when ``prep_applies()``)."""
+    from .utils import _dim_t
+    lib = _lib.load()
+    dev = reference_points.device
+    Q, B, _ = reference_points.shape
+    L = valid_ratios.shape[1]
+    dim_t = _DIM_T.get(str(dev))
+    if dim_t is None:
+        dim_t = _DIM_T[str(dev)] = _dim_t(128, 10000, dev)
+    ref = reference_points.contiguous()
+    ratio = valid_ratios.contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    ref_in = torch.empty((Q, B, L, 4), **f32)
+    ref_bf = torch.empty((B, Q, L, 4), **f32)
+    sine = torch.empty((Q, B, 512), **f32)
+    mlp = decoder.ref_point_head
+    w = _mlp_weights(mlp)
+    with torch.cuda.device(dev):
+        rc = lib.zira_decoder_prep_f32(ref.data_ptr(), ratio.data_ptr(), dim_t.data_ptr(), Q, B, L, 128, 2 * math.pi,
+                                       ref_in.data_ptr(), ref_bf.data_ptr(), sine.data_ptr(), _stream(dev))
+        if rc != 0:
+            raise RuntimeError("zira_decoder_prep_f32 failed with code %d" % rc)
+        h = rowgemm(sine, w.w0_t, w_is_nk=False, bias=mlp.layers[0].bias, relu=True)
+        query_pos = rowgemm(h, w.w1_t, w_is_nk=False, bias=mlp.layers[1].bias).view(Q, B, 256)
+    return ref_in, ref_bf, sine, query_pos

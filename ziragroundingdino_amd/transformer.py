@@ -636,7 +636,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 tgt_reference_points=None, memory_text=None, text_attention_mask=None, memory=None,
                 memory_key_padding_mask=None, memory_level_start_index=None,
                 memory_spatial_shapes=None, memory_pos=None, self_attn_mask=None,
-                cross_attn_mask=None, memory_text_lb=None, memory_value=None):
+                cross_attn_mask=None, memory_text_lb=None, memory_value=None, tgt_reference_points_bf=None):
         assert cross_attn_mask is None
         if self.native_layer and memory_value is not None:
             # every weight frozen (a ZiRa task), fp32 on the GPU: the whole layer is one autograd node whose launches carry the
@@ -649,8 +649,9 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 if kpm is not None and kpm.dtype == torch.bool:
                     kpm = _additive_mask(kpm, tgt.dtype)
                 out = native.decoder_layer_forward(self, tgt, tgt_query_pos, tgt_reference_points, text_lb, kpm, memory_value,
-                                                   memory_spatial_shapes, memory_level_start_index)
-                return out, tgt.new_zeros(1)
+                                                   memory_spatial_shapes, memory_level_start_index,
+                                                   ref_bf=tgt_reference_points_bf)
+                return out, None
         if self.self_attn is not None:
             q = k = self.with_pos_embed(tgt, tgt_query_pos)
             tgt2 = _mha(self.self_attn, q, k, tgt, attn_mask=self_attn_mask)
@@ -832,15 +833,22 @@ class TransformerDecoder(nn.Module):
         # is accumulated by the GEMMs themselves (None: the layers project for themselves)
         memory_values = multi_value_projections([layer.cross_attn for layer in self.layers], memory.transpose(0, 1),
                                                 memory_key_padding_mask) if self.batch_value_projections else None
+        native = None
+        if self.native_glue and output.is_cuda:
+            from . import decoder_layer as native
         for layer_id, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                reference_points_input = reference_points[:, :, None] * ratios4
+            ref_bf = None
+            if native is not None and native.prep_applies(self, reference_points, valid_ratios):
+                # boxes per level (both layouts), their sine embedding and the position MLP: three launches, no autograd
+                reference_points_input, ref_bf, query_sine_embed, query_pos = native.prep_queries(self, reference_points, valid_ratios)
             else:
-                reference_points_input = reference_points[:, :, None] * valid_ratios[None, :]
-            query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :])
-            raw_query_pos = self.ref_point_head(query_sine_embed)
-            pos_scale = self.query_scale(output) if self.query_scale is not None else 1
-            query_pos = pos_scale * raw_query_pos
+                if reference_points.shape[-1] == 4:
+                    reference_points_input = reference_points[:, :, None] * ratios4
+                else:
+                    reference_points_input = reference_points[:, :, None] * valid_ratios[None, :]
+                query_sine_embed = gen_sineembed_for_position(reference_points_input[:, :, 0, :])
+                raw_query_pos = self.ref_point_head(query_sine_embed)
+                query_pos = raw_query_pos if self.query_scale is None else self.query_scale(output) * raw_query_pos
 
             output, adapter_loss_ = layer(
                 tgt=output, tgt_query_pos=query_pos, tgt_query_sine_embed=query_sine_embed,
@@ -851,8 +859,10 @@ class TransformerDecoder(nn.Module):
                 memory_level_start_index=level_start_index, memory_spatial_shapes=spatial_shapes,
                 memory_pos=pos, self_attn_mask=tgt_mask, cross_attn_mask=memory_mask,
                 memory_text_lb=memory_text_lb,
-                memory_value=None if memory_values is None else memory_values[layer_id])
-            adapter_loss = adapter_loss + adapter_loss_
+                memory_value=None if memory_values is None else memory_values[layer_id],
+                tgt_reference_points_bf=ref_bf)
+            if adapter_loss_ is not None:   # (the native layer path has no adapter term and returns None for it)
+                adapter_loss = adapter_loss + adapter_loss_
 
             if self.native_glue and self.bbox_embed is not None and output.is_cuda:
                 from . import decoder_layer as native
