@@ -536,6 +536,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     fuse_bias_relu = True   # bias + ReLU in the GEMM epilogue: -117 us per layer (scripts/enclayer_profile.py)
+    native_attention = True   # frozen fp32 GPU calls without padding: the attention sublayer as one autograd node (encoder_layer.py)
 
     def forward_ffn(self, src):
         if (self.fuse_bias_relu and self.activation is F.relu and src.is_cuda and src.dtype == torch.float32
@@ -556,6 +557,13 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index,
                 key_padding_mask=None):
+        if self.native_attention and src.is_cuda:
+            from . import encoder_layer as native
+            if native.applies(self, src, pos, reference_points, spatial_shapes, key_padding_mask):
+                # projections, sampling plan, MSDA, output projection, residual + LayerNorm: one autograd node whose backward
+                # lets the three gradients of src meet inside its GEMMs (encoder_layer.py)
+                return self.forward_ffn(native.attention_sublayer(self, src, pos, reference_points, spatial_shapes,
+                                                                  level_start_index))
         # (query = src + pos, value = src: handed over as ONE tensor + pos so that the module can treat them as one node)
         src2 = self.self_attn(query=src, query_pos=pos, reference_points=reference_points,
                               value=src, spatial_shapes=spatial_shapes,
