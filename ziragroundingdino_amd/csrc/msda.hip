@@ -1784,8 +1784,10 @@ const char *zira_msda_variant_f32(int D)
     // D = 16 / 32 / 64 take the lean kernels (and, with a workspace, the tiled backward) whenever
     // the call passes lean_ok(); the other specialised widths use the row-per-group kernels
     if (D == 16 || D == 32 || D == 64)
-        return D == 32 ? "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_accum + msda_bwd_fold (dense calls) / "
-                         "msda_plan + msda_bwd_zero_split + msda_bwd_tile_accum (sparse calls); without: msda_bwd_lean_atomic"
+        return D == 32 ? "fwd msda_fwd_lean (sparse calls that need gradients: msda_fwd_plan = forward + the backward's plan in one "
+                         "launch); bwd with workspace: msda_bwd_bin + msda_bwd_accum + msda_bwd_fold (dense calls) / "
+                         "[msda_plan unless planned by the forward] + msda_bwd_tile_accum + msda_bwd_fold (sparse calls); "
+                         "without: msda_bwd_lean_atomic"
                        : "fwd msda_fwd_lean; bwd with workspace: msda_bwd_bin + msda_bwd_walk + msda_bwd_fold (dense calls) / "
                          "msda_bwd_items + msda_bwd_tiles_wave (sparse calls); without: msda_bwd_lean_atomic";
     switch (lpr_for(D)) {
