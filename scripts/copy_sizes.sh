@@ -8,7 +8,7 @@ import csv, glob, collections, re
 rows = []
 for f in glob.glob("/tmp/cs/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-for pat, label in (("direct_copy", "copies"), ("CUDAFunctor_add", "adds"), ("FillFunctor", "fills"), ("MulFunctor", "muls")):
+for pat, label in (("copyBuffer", "hipMemcpy D2D (tensor.copy_ of contiguous tensors, graph static inputs)"), ("direct_copy", "copies"), ("CUDAFunctor_add", "adds"), ("FillFunctor", "fills"), ("MulFunctor", "muls")):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         if pat in r["Kernel_Name"]:

@@ -142,7 +142,16 @@ class _WideMatmul(torch.autograd.Function):
     def forward(ctx, L, R, bias):
         ctx.save_for_backward(L, R)
         ctx.has_bias = bias is not None
-        return torch.bmm(L, R) if bias is None else torch.baddbmm(bias, L, R)
+        if bias is None:
+            return torch.bmm(L, R)
+        if L.is_cuda and L.dim() == 3 and L.shape[0] <= 4 and bias.dim() == 1:
+            # baddbmm first broadcasts the bias into the [B, N, m] result (a 45 MB copy at the encoder's size) and then reads
+            # it back as the GEMM's addend; per image the bias rides in the GEMM epilogue instead
+            out = L.new_empty((L.shape[0], L.shape[1], R.shape[2]))
+            for i in range(L.shape[0]):
+                torch.addmm(bias, L[i], R[i], out=out[i])
+            return out
+        return torch.baddbmm(bias, L, R)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")

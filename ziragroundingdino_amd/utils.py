@@ -157,8 +157,9 @@ def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor, sp
     output_proposals = torch.log(output_proposals / (1 - output_proposals))
     output_proposals = output_proposals.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf"))
     output_proposals = output_proposals.masked_fill(~valid, float("inf"))
-    output_memory = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0)
-    output_memory = output_memory.masked_fill(~valid, 0.0)
+    # (one fill with the union of the two masks instead of the reference's two passes over the 45 MB tokens -- and two more
+    #  in the backward; the same zeros)
+    output_memory = memory.masked_fill(memory_padding_mask.unsqueeze(-1) | ~valid, 0.0)
     return output_memory, output_proposals
 
 
