@@ -44,25 +44,28 @@ def conv_columns(x, kernel, stride=1, padding=0):
 
 def conv2d_as_gemm(x, weight, bias=None, stride=1, padding=0):
     """conv2d (dilation 1, groups 1, zero padding) via GEMM.  x [B,C,H,W], weight [O,C,kh,kw]."""
-    O = weight.shape[0]
     cols, Ho, Wo = conv_columns(x, weight.shape[2:], stride, padding)
-    y = torch.matmul(weight.view(O, -1), cols)                               # [B, O, Ho*Wo]
+    return _columns_gemm(cols, weight, bias).view(x.shape[0], weight.shape[0], Ho, Wo)
+
+
+def _columns_gemm(cols, weight, bias):
+    """weight [O, ...] applied to im2col columns [B, K, N] -> [B, O, N].  bmm with the weight expanded over the batch:
+    matmul(2-D, 3-D) transposes and clones the columns first (25 MB at the first level); the bias joins in place."""
+    O = weight.shape[0]
+    y = torch.bmm(weight.view(1, O, -1).expand(cols.shape[0], -1, -1), cols)
     if bias is not None:
-        y = y + bias.view(1, O, 1)
-    return y.view(x.shape[0], O, Ho, Wo)
+        y = y.add_(bias.view(1, O, 1))
+    return y
 
 
 def conv2d_pair_as_gemm(x, weight_a, bias_a, weight_b, bias_b, stride=1, padding=0):
-    """Two convolutions of the same input with equally shaped kernels as ONE batched GEMM
-    (the activations / im2col columns are read once); returns two contiguous [B,O,Ho,Wo]."""
-    O = weight_a.shape[0]
+    """Two convolutions of the same input with equally shaped kernels; returns two contiguous [B,O,Ho,Wo].
+    (Round 1 ran them as ONE batched GEMM over the stacked weights; the broadcast made matmul clone the columns for both
+    weight sets, the results had to be selected out of the stacked tensor -- two zero-filled 2x-sized gradients in the
+    backward -- and the bias was a pass over both: two plain GEMMs on the same columns move less.)"""
     cols, Ho, Wo = conv_columns(x, weight_a.shape[2:], stride, padding)
-    w = torch.stack([weight_a.view(O, -1), weight_b.view(O, -1)])            # [2, O, K]
-    y = torch.matmul(w[:, None], cols[None])                                 # [2, B, O, Ho*Wo]
-    if bias_a is not None:
-        y = y + torch.stack([bias_a, bias_b]).view(2, 1, O, 1)
-    y = y.view(2, x.shape[0], O, Ho, Wo)
-    return y[0], y[1]
+    shape = (x.shape[0], weight_a.shape[0], Ho, Wo)
+    return _columns_gemm(cols, weight_a, bias_a).view(shape), _columns_gemm(cols, weight_b, bias_b).view(shape)
 
 
 def conv_module_as_gemm(conv: torch.nn.Conv2d, x):
