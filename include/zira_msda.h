@@ -94,25 +94,30 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
 /* Planned backward for sparse calls (decoder cross-attention: B*M*Q < 65536, D = 32).  How the backward's work is cut
  * -- which samples add to which 16 x 8-pixel tile of grad_value, which tiles are split, which CU takes which tile --
  * depends on spatial_shapes / level_start_index / sampling_loc only, all of which exist in the FORWARD pass
- * (reference ms_deform_attn.py:50: the autograd Function saves them there).  So the planning is a call of its own:
+ * (reference ms_deform_attn.py:50: the autograd Function saves them there), as does the attention weight that the plan
+ * writes into every sample's record.  So the planning is a call of its own:
  *
  *   zira_msda_plan_bytes      size of the plan buffer for these dimensions on the current device (0: no planned path;
  *                             use zira_msda_bwd_f32_ws)
  *   zira_msda_fwd_plan_f32    the forward AND the plan in ONE launch: the first 64 workgroups plan a (head, level) unit
  *                             each, the others run the gather (17 us for both at the north-star shape against 10.6 +
  *                             12.5 us apart: two kernels on two streams do not overlap on this stack, one grid does)
- *   zira_msda_plan_f32        the plan alone: reads no value / attention data
- *   zira_msda_bwd_planned_f32 the backward from a plan: the accumulate kernel + a small launch that adds up the partial
+ *   zira_msda_plan_f32        the plan alone: reads the level tables, sampling_loc and attn_weight
+ *   zira_msda_bwd_planned_f32 the backward from a plan: a gather pass like the forward's for grad_sampling_loc /
+ *                             grad_attn_weight (a wave per (b, q, m)), the accumulate kernel for grad_value -- with up to
+ *                             960 queries a workgroup serves one head and keeps that head's grad_out rows in LDS, so that
+ *                             no load of its inner loop depends on another -- and a small launch that adds up the partial
  *                             tiles of split tiles.  `plan` must come from zira_msda_*plan_f32 for the same dimensions,
- *                             level tables and sampling_loc (those three arguments are not read again).  Same outputs /
- *                             contract as zira_msda_bwd_f32_ws; deterministic apart from the order of the LDS sums in
- *                             double (no fp32 atomics anywhere).
+ *                             level tables, sampling_loc AND attn_weight.  Same outputs / contract as
+ *                             zira_msda_bwd_f32_ws; deterministic apart from the order of the LDS sums in double (no fp32
+ *                             atomics anywhere).
  * The plan buffer needs no initialisation and 16-byte alignment; the backward uses a region of it as scratch (the partial
  * tiles), so a plan may serve several backward calls one after the other on a stream, not concurrently. */
 size_t zira_msda_plan_bytes(int B, int S, int M, int D, int L, int Q, int P);
 
 int zira_msda_plan_f32(const int64_t *spatial_shapes, const int64_t *level_start_index, const float *sampling_loc,
-                       int B, int S, int M, int D, int L, int Q, int P, void *plan, size_t plan_bytes, void *stream);
+                       const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P, void *plan,
+                       size_t plan_bytes, void *stream);
 
 int zira_msda_fwd_plan_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
                            const float *sampling_loc, const float *attn_weight, int B, int S, int M, int D, int L,

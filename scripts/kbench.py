@@ -69,11 +69,11 @@ def main():
         print("%-18s fwd med %8.2f us (min %8.2f) %7.0f GB/s | bwd med %8.2f us (min %8.2f) %7.0f GB/s"
               % (name, np.median(tf), min(tf), fb / np.median(tf) / 1e3,
                  np.median(tb), min(tb), bb / np.median(tb) / 1e3), flush=True)
-        plan = _C.ms_deform_attn_plan(v, sh, st, loc, 64)
+        plan = _C.ms_deform_attn_plan(v, sh, st, loc, attn, 64)
         if plan is not None:   # sparse calls: the plan made right behind the forward gather, the backward from the plan
             fwdp = lambda: _C.ms_deform_attn_forward_plan(v, sh, st, loc, attn, 64)
             bwdp = lambda: _C.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64, plan=plan)
-            planonly = lambda: _C.ms_deform_attn_plan(v, sh, st, loc, 64)
+            planonly = lambda: _C.ms_deform_attn_plan(v, sh, st, loc, attn, 64)
             for _ in range(3):
                 fwdp(); bwdp()
             gfp, gbp, gpo = graphed(fwdp, per), graphed(bwdp, per), graphed(planonly, per)

@@ -541,7 +541,7 @@ def test_planned_backward_through_the_c_abi(oracle, name, kw):
     _close(out, want_out, 2e-5, "output")
     # the plan alone (zira_msda_plan_f32) serves the same backward
     plan2 = torch.full((n,), 0x5C, dtype=torch.uint8, device=DEV)
-    assert lib.zira_msda_plan_f32(tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), B, S, M, D, 4, Q, P, plan2.data_ptr(), n, st) == 0
+    assert lib.zira_msda_plan_f32(tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), tattn.data_ptr(), B, S, M, D, 4, Q, P, plan2.data_ptr(), n, st) == 0
     for scale, plan in ((1.0, plan), (-3.0, plan), (1.0, plan2)):
         gv, gl, ga = torch.full_like(v, float("nan")), torch.full_like(tloc, float("nan")), torch.full_like(tattn, float("nan"))
         g = (tgo * scale).contiguous()
@@ -556,7 +556,7 @@ def test_planned_backward_through_the_c_abi(oracle, name, kw):
             _close(got, w * scale, 2e-5 * abs(scale), "planned %s (x %g)" % (nm, scale))
     # argument errors are returned, not raised: no planned path for a dense call, a short plan buffer
     assert lib.zira_msda_plan_bytes(B, S, M, D, 4, S, P) == 0
-    assert lib.zira_msda_plan_f32(tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), B, S, M, D, 4, Q, P, plan.data_ptr(), n - 1, st) != 0
+    assert lib.zira_msda_plan_f32(tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(), tattn.data_ptr(), B, S, M, D, 4, Q, P, plan.data_ptr(), n - 1, st) != 0
     assert lib.zira_msda_bwd_planned_f32(tgo.data_ptr(), v.data_ptr(), tsh.data_ptr(), tst.data_ptr(), tloc.data_ptr(),
                                          tattn.data_ptr(), B, S, M, D, 4, Q, P, gv.data_ptr(), gl.data_ptr(),
                                          ga.data_ptr(), plan.data_ptr(), n - 1, st) != 0

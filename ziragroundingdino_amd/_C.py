@@ -143,9 +143,10 @@ def plan_applies(value, spatial_shapes, level_start_index, sampling_loc, im2col_
     return _plan_dims(value, spatial_shapes, level_start_index, sampling_loc, im2col_step) is not None
 
 
-def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
+def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """-> plan (an opaque uint8 device tensor) or None.  The backward of a sparse float32 call (decoder
-    cross-attention) is cut into tiles by a plan that depends on the level tables and the sampling locations only, so
+    cross-attention) is cut into tiles by a plan that depends on the level tables, the sampling locations and (for the
+    records' weights) the attention weights only, so
     it can be made in the forward pass, off the backward's critical path: this enqueues the planning kernel on the
     current stream (C ABI ``zira_msda_plan_f32``); hand the result to ``ms_deform_attn_backward(..., plan=plan)``.
     None where no planned backward exists (``plan_applies``) or with ``USE_FORWARD_PLAN`` off: the backward then plans
@@ -158,7 +159,7 @@ def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, 
     plan = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
     with torch.cuda.device(value.device), _Timed("plan", dims):
         rc = lib.zira_msda_plan_f32(spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                                    *dims, plan.data_ptr(), nbytes, _stream())
+                                    attn_weight.data_ptr(), *dims, plan.data_ptr(), nbytes, _stream())
     _raise_on(rc, "ms_deform_attn_plan")
     return plan
 

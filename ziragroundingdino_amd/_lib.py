@@ -88,7 +88,7 @@ def load():
     lib.zira_msda_bwd_f32_ws.restype = i
     lib.zira_msda_plan_bytes.argtypes = [i] * 7
     lib.zira_msda_plan_bytes.restype = ctypes.c_size_t
-    lib.zira_msda_plan_f32.argtypes = [vp, vp, vp] + [i] * 7 + [vp, ctypes.c_size_t, vp]
+    lib.zira_msda_plan_f32.argtypes = [vp, vp, vp, vp] + [i] * 7 + [vp, ctypes.c_size_t, vp]
     lib.zira_msda_plan_f32.restype = i
     lib.zira_msda_fwd_plan_f32.argtypes = fwd_args[:-1] + [vp, ctypes.c_size_t, vp]
     lib.zira_msda_fwd_plan_f32.restype = i

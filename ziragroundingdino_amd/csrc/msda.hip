@@ -306,74 +306,12 @@ __global__ __launch_bounds__(kBlock, 8) void msda_fwd_lean(
 // DPP quad permutes / row mirrors inside a 16-lane row.  Each dot product travels back to the
 // lane that owns the (sample, corner) entry with one ds_bpermute; the four corners of a
 // sample are then combined with two more quad permutes.
-template <int CQ>
-__device__ __forceinline__ float sum_over_row_lanes(float x)
-{
-    x = dpp_add<0xB1>(x);                 // quad_perm:[1,0,3,2]   (xor 1)
-    x = dpp_add<0x4E>(x);                 // quad_perm:[2,3,0,1]   (xor 2)
-    if (CQ >= 8) x = dpp_add<0x141>(x);   // row_half_mirror       (xor 4 on quad sums)
-    if (CQ >= 16) x = dpp_add<0x140>(x);  // row_mirror            (xor 8 on octet sums)
-    return x;
-}
+// (sum_over_row_lanes, chunk_dots, store_sample_grads and bwd_home_item: csrc/msda_fwd_lean.h, shared with the fused
+// home + accumulate launch of csrc/msda_tiles.hip)
 
-// <grad_out row, value row> for the 64 entries of a chunk; entry e's result lands in lane e.
-template <int CQ>
-__device__ __forceinline__ float chunk_dots(const float *__restrict__ vb, const Entry &k,
-                                            float4 g4, unsigned lane)
-{
-    constexpr unsigned SLOTS = 64 / CQ, NI = CQ;
-    const unsigned slot = lane / CQ, cq = lane % CQ;
-    const int bp = (int)(slot * 4);
-    const int back = (int)((lane % SLOTS) * CQ * 4);
-    const int offb_i = (int)k.offb;
-    float mine = 0.f;
-    // All NI row gathers are issued before the first dot product.  Written as two loops with a
-    // scheduling barrier in between: left to itself the compiler put `s_waitcnt vmcnt(0)` behind
-    // every load (NI dependent round trips per chunk, K1 at twice the forward's time).
-    constexpr unsigned G = NI < ZIRA_K1_GATHERS ? NI : ZIRA_K1_GATHERS;  // gathers in flight
-#pragma unroll
-    for (unsigned j0 = 0; j0 < NI; j0 += G) {
-        float4 v[G];
-#pragma unroll
-        for (unsigned j = 0; j < G; ++j) {
-            const unsigned oj =
-                (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)((j0 + j) * SLOTS * 4), offb_i);
-            v[j] = load_row16(vb, oj + cq * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (unsigned j = 0; j < G; ++j) {
-            float d = v[j].x * g4.x;
-            d = fmaf(v[j].y, g4.y, d);
-            d = fmaf(v[j].z, g4.z, d);
-            d = fmaf(v[j].w, g4.w, d);
-            d = sum_over_row_lanes<CQ>(d);
-            const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d)));
-            if (lane / SLOTS == j0 + j) mine = t;
-        }
-    }
-    return k.inb ? mine : 0.f;
-}
-
-// grad_sampling_loc / grad_attn_weight of the chunk's 16 samples from the per-entry dots
-__device__ __forceinline__ void store_sample_grads(const Entry &k, float d, unsigned lane,
-                                                   unsigned s, unsigned LP,
-                                                   float *__restrict__ gl_i,
-                                                   float *__restrict__ ga_i)
-{
-    float ga = k.wb * d, gx = k.cx * d, gy = k.cy * d;
-    ga = dpp_add<0xB1>(ga); gx = dpp_add<0xB1>(gx); gy = dpp_add<0xB1>(gy);
-    ga = dpp_add<0x4E>(ga); gx = dpp_add<0x4E>(gx); gy = dpp_add<0x4E>(gy);
-    if ((lane & 3) == 0 && s < LP) {
-        ga_i[s] = ga;
-        float2 gl;
-        gl.x = k.Wf * k.a * gx;
-        gl.y = k.Hf * k.a * gy;
-        *reinterpret_cast<float2 *>(gl_i + 2 * s) = gl;
-    }
-}
-
-template <int CQR>
+// kScatter = false (msda_bwd_home): grad_sampling_loc and grad_attn_weight only -- the gather half of the backward, a wave
+// per (b, q, m) like the forward; grad_value then comes from the tile accumulate kernel (csrc/msda_tiles.hip).
+template <int CQR, bool kScatter>
 __global__ __launch_bounds__(kBlock, 8) void msda_bwd_lean_atomic(
     const float *__restrict__ grad_out, const float *__restrict__ value,
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
@@ -407,7 +345,7 @@ __global__ __launch_bounds__(kBlock, 8) void msda_bwd_lean_atomic(
         constexpr unsigned RPA = 64 / D >= 1 ? 64 / D : 1;
         const unsigned ch = lane % D, rr = lane / D;
         const int w_i = __float_as_int(k.w), offb_i = (int)k.offb;
-        if (D <= 64) {
+        if (kScatter && D <= 64) {
             const float gch = g_i[ch];
 #pragma unroll 4
             for (unsigned it = 0; it < 64 / RPA; ++it) {
@@ -1397,10 +1335,24 @@ int launch_bwd_lean_atomic(const float *grad_out, const float *value, const int6
                            hipStream_t st)
 {
     const unsigned nitems = (unsigned)B * Q * M;
-    hipLaunchKernelGGL(msda_bwd_lean_atomic<CQR>, dim3(head_major_grid(nitems)), dim3(kBlock), 0,
+    hipLaunchKernelGGL((msda_bwd_lean_atomic<CQR, true>), dim3(head_major_grid(nitems)), dim3(kBlock), 0,
                        st, grad_out, value, shapes, start, loc, attn, (unsigned)S,
                        make_fast_div((unsigned)M), (unsigned)(L * P), make_fast_div((unsigned)Q),
                        1.0f / (float)P, nitems, (nitems + 7) >> 3, gv, gl, ga);
+    return (int)hipGetLastError();
+}
+
+// grad_sampling_loc and grad_attn_weight alone (the planned sparse backward's gather half)
+template <int CQR>
+int launch_bwd_home(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
+                    const float *loc, const float *attn, int B, int S, int M, int L, int Q, int P, float *gl, float *ga,
+                    hipStream_t st)
+{
+    const unsigned nitems = (unsigned)B * Q * M;
+    hipLaunchKernelGGL((msda_bwd_lean_atomic<CQR, false>), dim3(head_major_grid(nitems)), dim3(kBlock), 0,
+                       st, grad_out, value, shapes, start, loc, attn, (unsigned)S,
+                       make_fast_div((unsigned)M), (unsigned)(L * P), make_fast_div((unsigned)Q),
+                       1.0f / (float)P, nitems, (nitems + 7) >> 3, static_cast<float *>(nullptr), gl, ga);
     return (int)hipGetLastError();
 }
 
@@ -1585,6 +1537,19 @@ int bwd_generic(const T *grad_out, const T *value, const int64_t *shapes, const 
 
 }  // namespace
 
+namespace {
+// The planned sparse backward (D = 32): grad_sampling_loc / grad_attn_weight from a gather pass like the forward's (a wave per
+// (b, q, m); every sample, also those outside the window, whose gradients are zero), grad_value from the plan's tiles -- one launch.
+int planned_backward(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start, const float *loc,
+                     const float *attn, int B, int S, int M, int D, int L, int Q, int P, float *gv, float *gl, float *ga,
+                     const void *plan, size_t plan_bytes, hipStream_t st)
+{
+    if (D != 32 || !lean_ok(B, S, M, D, L, Q, P)) return -1;
+    return zira::tiles_backward_planned_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P, gv, gl, ga, plan,
+                                            plan_bytes, st);
+}
+}  // namespace
+
 extern "C" {
 
 int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *start,
@@ -1689,10 +1654,9 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
         // no plan from the forward pass: plan here, in front of the accumulate kernel (the workspace is the plan buffer)
         const size_t need = zira::tiles_plan_bytes(B, S, M, D, L, Q, P);
         if (need && workspace_bytes >= need) {
-            int rc = zira::tiles_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, workspace, workspace_bytes, (hipStream_t)stream);
-            if (rc == 0)
-                rc = zira::tiles_backward_planned_f32(grad_out, value, attn, B, S, M, D, L, Q, P, gv, gl, ga, workspace,
-                                                      workspace_bytes, (hipStream_t)stream);
+            int rc = zira::tiles_plan_f32(shapes, start, loc, attn, B, S, M, D, L, Q, P, workspace, workspace_bytes, (hipStream_t)stream);
+            if (rc == 0) rc = planned_backward(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P, gv, gl, ga, workspace,
+                                               workspace_bytes, (hipStream_t)stream);
             if (rc != -1) return rc;
         }
     }
@@ -1714,14 +1678,14 @@ size_t zira_msda_plan_bytes(int B, int S, int M, int D, int L, int Q, int P)
     return zira::tiles_plan_bytes(B, S, M, D, L, Q, P);
 }
 
-int zira_msda_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc, int B, int S, int M, int D, int L,
-                       int Q, int P, void *plan, size_t plan_bytes, void *stream)
+int zira_msda_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc, const float *attn, int B, int S, int M,
+                       int D, int L, int Q, int P, void *plan, size_t plan_bytes, void *stream)
 {
-    if (!shapes || !start || !loc || !plan || B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0)
+    if (!shapes || !start || !loc || !attn || !plan || B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Q <= 0 || P <= 0)
         return ZIRA_MSDA_EINVAL;
     const size_t need = zira_msda_plan_bytes(B, S, M, D, L, Q, P);
     if (!need || plan_bytes < need || ((uintptr_t)plan & 15)) return ZIRA_MSDA_EINVAL;
-    const int rc = zira::tiles_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, plan, plan_bytes, (hipStream_t)stream);
+    const int rc = zira::tiles_plan_f32(shapes, start, loc, attn, B, S, M, D, L, Q, P, plan, plan_bytes, (hipStream_t)stream);
     return rc == -1 ? ZIRA_MSDA_EINVAL : rc;
 }
 
@@ -1739,7 +1703,7 @@ int zira_msda_fwd_plan_f32(const float *value, const int64_t *shapes, const int6
     }
     const int rc = zira_msda_fwd_f32(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out, stream);
     if (rc != 0) return rc;
-    return zira_msda_plan_f32(shapes, start, loc, B, S, M, D, L, Q, P, plan, plan_bytes, stream);
+    return zira_msda_plan_f32(shapes, start, loc, attn, B, S, M, D, L, Q, P, plan, plan_bytes, stream);
 }
 
 int zira_msda_bwd_planned_f32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
@@ -1750,8 +1714,8 @@ int zira_msda_bwd_planned_f32(const float *grad_out, const float *value, const i
         return ZIRA_MSDA_EINVAL;
     const size_t need = zira_msda_plan_bytes(B, S, M, D, L, Q, P);
     if (!need || plan_bytes < need || ((uintptr_t)plan & 15)) return ZIRA_MSDA_EINVAL;
-    const int rc = zira::tiles_backward_planned_f32(grad_out, value, attn, B, S, M, D, L, Q, P, gv, gl, ga, plan, plan_bytes,
-                                                    (hipStream_t)stream);
+    const int rc = planned_backward(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P, gv, gl, ga, plan, plan_bytes,
+                                    (hipStream_t)stream);
     return rc == -1 ? ZIRA_MSDA_EINVAL : rc;
 }
 

@@ -8,6 +8,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef ZIRA_K1_GATHERS
+#define ZIRA_K1_GATHERS 8   // row gathers a wave keeps in flight in chunk_dots
+#endif
+
 namespace {
 
 constexpr unsigned kLeanWavesPerBlock = 4;
@@ -170,6 +174,101 @@ __device__ __forceinline__ void fwd_lean_item(const float *__restrict__ value, c
     acc.x = dpp_add<0x128>(acc.x); acc.y = dpp_add<0x128>(acc.y);
     acc.z = dpp_add<0x128>(acc.z); acc.w = dpp_add<0x128>(acc.w);
     if (slot == 0) *reinterpret_cast<float4 *>(out + (size_t)id.item * D + cq * 4) = acc;
+}
+
+
+// ---- the gather half of the backward: grad_sampling_loc and grad_attn_weight of one (b, q, m) item by one wave ----
+// (reference ms_deform_im2col_cuda.cuh:123-158; the four corner rows of a sample are gathered as in the forward and dotted
+//  with the query's grad_out row)
+template <int CQ>
+__device__ __forceinline__ float sum_over_row_lanes(float x)
+{
+    x = dpp_add<0xB1>(x);                 // quad_perm:[1,0,3,2]   (xor 1)
+    x = dpp_add<0x4E>(x);                 // quad_perm:[2,3,0,1]   (xor 2)
+    if (CQ >= 8) x = dpp_add<0x141>(x);   // row_half_mirror       (xor 4 on quad sums)
+    if (CQ >= 16) x = dpp_add<0x140>(x);  // row_mirror            (xor 8 on octet sums)
+    return x;
+}
+
+// <grad_out row, value row> for the 64 entries of a chunk; entry e's result lands in lane e.
+template <int CQ>
+__device__ __forceinline__ float chunk_dots(const float *__restrict__ vb, const Entry &k,
+                                            float4 g4, unsigned lane)
+{
+    constexpr unsigned SLOTS = 64 / CQ, NI = CQ;
+    const unsigned slot = lane / CQ, cq = lane % CQ;
+    const int bp = (int)(slot * 4);
+    const int back = (int)((lane % SLOTS) * CQ * 4);
+    const int offb_i = (int)k.offb;
+    float mine = 0.f;
+    // All NI row gathers are issued before the first dot product.  Written as two loops with a
+    // scheduling barrier in between: left to itself the compiler put `s_waitcnt vmcnt(0)` behind
+    // every load (NI dependent round trips per chunk, K1 at twice the forward's time).
+    constexpr unsigned G = NI < ZIRA_K1_GATHERS ? NI : ZIRA_K1_GATHERS;  // gathers in flight
+#pragma unroll
+    for (unsigned j0 = 0; j0 < NI; j0 += G) {
+        float4 v[G];
+#pragma unroll
+        for (unsigned j = 0; j < G; ++j) {
+            const unsigned oj =
+                (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)((j0 + j) * SLOTS * 4), offb_i);
+            v[j] = load_row16(vb, oj + cq * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (unsigned j = 0; j < G; ++j) {
+            float d = v[j].x * g4.x;
+            d = fmaf(v[j].y, g4.y, d);
+            d = fmaf(v[j].z, g4.z, d);
+            d = fmaf(v[j].w, g4.w, d);
+            d = sum_over_row_lanes<CQ>(d);
+            const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d)));
+            if (lane / SLOTS == j0 + j) mine = t;
+        }
+    }
+    return k.inb ? mine : 0.f;
+}
+
+// grad_sampling_loc / grad_attn_weight of the chunk's 16 samples from the per-entry dots
+__device__ __forceinline__ void store_sample_grads(const Entry &k, float d, unsigned lane,
+                                                   unsigned s, unsigned LP,
+                                                   float *__restrict__ gl_i,
+                                                   float *__restrict__ ga_i)
+{
+    float ga = k.wb * d, gx = k.cx * d, gy = k.cy * d;
+    ga = dpp_add<0xB1>(ga); gx = dpp_add<0xB1>(gx); gy = dpp_add<0xB1>(gy);
+    ga = dpp_add<0x4E>(ga); gx = dpp_add<0x4E>(gx); gy = dpp_add<0x4E>(gy);
+    if ((lane & 3) == 0 && s < LP) {
+        ga_i[s] = ga;
+        float2 gl;
+        gl.x = k.Wf * k.a * gx;
+        gl.y = k.Hf * k.a * gy;
+        *reinterpret_cast<float2 *>(gl_i + 2 * s) = gl;
+    }
+}
+
+
+template <int CQR>
+__device__ __forceinline__ void bwd_home_item(const float *__restrict__ grad_out, const float *__restrict__ value,
+                                              const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                              const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, unsigned M,
+                                              unsigned LP, float invP, const ItemId id, float *__restrict__ grad_loc,
+                                              float *__restrict__ grad_attn)
+{
+    constexpr unsigned D = 16 * CQR, CQ = 4 * CQR;
+    const unsigned lane = threadIdx.x & 63;
+    const float *vb = value + (size_t)id.b * S * M * D;
+    const float *loc_i = loc + (size_t)id.item * LP * 2;
+    const float *att_i = attn + (size_t)id.item * LP;
+    float *gl_i = grad_loc + (size_t)id.item * LP * 2;
+    float *ga_i = grad_attn + (size_t)id.item * LP;
+    const float4 g4 = *reinterpret_cast<const float4 *>(grad_out + (size_t)id.item * D + (lane % CQ) * 4);
+    for (unsigned s0 = 0; s0 < LP; s0 += 16) {
+        const unsigned s = s0 + (lane >> 2);
+        const Entry k = entry_setup<true>(shapes, start, loc_i, att_i, s, lane & 3, LP, invP, M, D, id.m);
+        const float d = chunk_dots<CQ>(vb, k, g4, lane);
+        store_sample_grads(k, d, lane, s, LP, gl_i, ga_i);
+    }
 }
 
 }  // namespace

@@ -61,13 +61,22 @@
 #define ZIRA_TILE_CAP 640      // records a work item holds at most (plan: K = ceil(records / cap); 320: +3 us, 224: +10 us)
 #endif
 #ifndef ZIRA_TILE_BLOCKS_PER_CU
-#define ZIRA_TILE_BLOCKS_PER_CU 4
+#define ZIRA_TILE_BLOCKS_PER_CU 3   // accumulate blocks per CU ...
+#endif
+#ifndef ZIRA_TILE_SLOTS_PER_CU
+#define ZIRA_TILE_SLOTS_PER_CU 4    // ... of the four that fit (LDS, registers): the fourth is where the gather blocks pass through
 #endif
 #ifndef ZIRA_TILE_ROWS
 #define ZIRA_TILE_ROWS 16      // pixel rows of a tile (x 8 columns)
 #endif
 #ifndef ZIRA_TILE_THREADS
 #define ZIRA_TILE_THREADS 256  // threads of an accumulate block
+#endif
+#ifndef ZIRA_TILE_RES_THREADS
+#define ZIRA_TILE_RES_THREADS 512
+#endif
+#ifndef ZIRA_RESQ
+#define ZIRA_RESQ 0     // 960: the resident form (measured: 39.4 us against 24.9 us for the gathered rows at 4 blocks per CU -- with one block per CU an item's header and first records are a serial latency chain)
 #endif
 
 namespace zira {
@@ -81,6 +90,8 @@ constexpr unsigned kRowBytes = 32 * 8;  // one accumulator row: 32 channels in d
 constexpr unsigned kTrash = kNPix * kRowBytes;   // LDS byte offset of the trash row (corners owned by another tile)
 static_assert(kTrash < 65536, "a corner's LDS offset is 16 bits of a record");
 constexpr unsigned kAccThreads = ZIRA_TILE_THREADS;
+constexpr unsigned kResThreads = ZIRA_TILE_RES_THREADS;   // threads of a resident accumulate block (one per CU)
+constexpr unsigned kResQ = ZIRA_RESQ;            // queries whose grad_out rows fit the LDS beside the tile (960 * 128 + 33 KB <= 160 KB)
 constexpr unsigned kPlanThreads = 1024;
 constexpr unsigned kClasses = 6;        // size classes of the deal, by block steps (32 records): > 8, 5-8, 3-4, 2, 1, none (empty tiles)
 __host__ __device__ constexpr unsigned size_class(unsigned n)
@@ -261,8 +272,12 @@ struct RecCtx {
     unsigned lP;     // l * P
     unsigned P;
 };
-__device__ __forceinline__ Rec make_record(unsigned q, unsigned p, unsigned cy, unsigned cx, unsigned lw, unsigned lh,
-                                           const TLevel &Lv, unsigned ty, unsigned tx, bool home, const RecCtx &C)
+// A record = one sample in one tile its 2 x 2 corner block touches: where the query's grad_out row is (byte offset of the
+// row in a [Q][32] float array: the accumulate kernel keeps the head's rows in LDS, or multiplies by M for the global
+// tensor), the attention weight, the LDS byte offsets of the four corner rows in the tile's accumulators (kTrash for a
+// corner outside the map or in another tile) and the bilinear fractions.  24 of 32 bytes.
+__device__ __forceinline__ Rec make_record(unsigned q, unsigned abits, unsigned cy, unsigned cx, unsigned lw, unsigned lh,
+                                           const TLevel &Lv, unsigned ty, unsigned tx)
 {
     const unsigned H = (unsigned)Lv.H, W = (unsigned)Lv.W, ty0 = ty * kTH, tx0 = tx * kTW;
     unsigned o[4];
@@ -272,24 +287,9 @@ __device__ __forceinline__ Rec make_record(unsigned q, unsigned p, unsigned cy, 
         const bool in = y < H && x < W && (y - ty0) < kTH && (x - tx0) < kTW;
         o[cc] = in ? ((y - ty0) * kTW + (x - tx0)) * kRowBytes : kTrash;
     }
-    const unsigned hy = cy < H ? cy : H - 1, hx = cx < W ? cx : W - 1;
-    const unsigned yA = cy >= 1 ? cy - 1 : 0u, xA = cx >= 1 ? cx - 1 : 0u;
-    unsigned fl = kFlLive | (home ? kFlHome : 0u);
-    fl |= (hx != xA) ? kFlXStep : 0u;                          // the right column is another pixel
-    fl |= (hy != yA) ? kFlYStep : 0u;                          // the bottom row is another pixel
-    const bool y0in = cy >= 1, y1in = cy < H, x0in = cx >= 1, x1in = cx < W;
-    fl |= (y0in && x0in ? kFl00 : 0u) | (y0in && x1in ? kFl01 : 0u) | (y1in && x0in ? kFl10 : 0u) | (y1in && x1in ? kFl11 : 0u);
     Rec r;
-    r.a = make_uint4(q * C.rs4, q * C.mlp + C.lP + p, home ? (yA * W + xA) * C.rs4 : 0u, o[0] | (o[1] << 16));
-    r.b = make_uint4(o[2] | (o[3] << 16), fl, lw, lh);
-    return r;
-}
-// a sample outside the window (cuh:288 fails): no corner, no value row; its home record stores zero gradients
-__device__ __forceinline__ Rec make_outside_record(unsigned q, unsigned p, const RecCtx &C)
-{
-    Rec r;
-    r.a = make_uint4(q * C.rs4, q * C.mlp + C.lP + p, 0u, kTrash | (kTrash << 16));
-    r.b = make_uint4(kTrash | (kTrash << 16), kFlHome, 0u, 0u);
+    r.a = make_uint4(q * 128u, abits, o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    r.b = make_uint4(lw, lh, 0u, 0u);
     return r;
 }
 
@@ -306,7 +306,8 @@ __device__ __forceinline__ void store_item(uint4 *dst, unsigned off, unsigned n,
 // in registers between the count and the copy-out, so the sampling locations are read once.
 template <bool kOnePass>
 __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                                          const float *__restrict__ loc, const PlanGeom &G, const PlanPtrs &W, const unsigned unit)
+                                          const float *__restrict__ loc, const float *__restrict__ attn, const PlanGeom &G,
+                                          const PlanPtrs &W, const unsigned unit)
 {
     constexpr unsigned D = 32;
     extern __shared__ unsigned lds_plan[];
@@ -332,14 +333,8 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
     __syncthreads();
     TSTAMP(0);
 
-    RecCtx RC;
-    RC.rs4 = G.M * D * 4u;
-    RC.mlp = G.M * G.LP;
-    RC.lP = l * G.P;
-    RC.P = G.P;
-
     // pass 1: records per tile (a sample counts in every tile one of its corners falls into; a sample outside the
-    // window counts once, in a tile picked by its index)
+    // window has no record: its gradients are zero, and msda_bwd_home writes them)
     unsigned cellv[4], lwv[4], lhv[4], trk[4][4];   // kOnePass: cell word, fractions, rank inside each touched tile
     if (kOnePass) {
 #pragma unroll
@@ -377,9 +372,6 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                         if (i == 0) trk[p][0] = w; else if (i == 1) trk[p][1] = w; else if (i == 2) trk[p][2] = w; else trk[p][3] = w;
                         ++i;
                     });
-                } else {
-                    cellv[p] = kOutside;
-                    trk[p][0] = atomicAdd(&hist[(q * G.P + p) % ntl], 1u);
                 }
             }
         } else {
@@ -388,8 +380,6 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                 const Cell c = cell_of(xy.x, xy.y, Lv.H, Lv.W);
                 if (c.valid)
                     for_each_touched_tile(c, Lv, [&](unsigned t, unsigned, unsigned, bool) { atomicAdd(&hist[t], 1u); });
-                else
-                    atomicAdd(&hist[(q * G.P + p) % ntl], 1u);
             }
         }
     }
@@ -436,24 +426,19 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
     uint4 *rc = W.recs + (size_t)rbase * 2;
     if (kOnePass) {
         if (tid < G.Q) {
+            const size_t abase = ((size_t)(b * G.Q + tid) * G.M + m) * G.LP + (size_t)l * G.P;
 #pragma unroll
             for (unsigned p = 0; p < 4; ++p) {
                 if (cellv[p] == kNoCell) continue;
-                if (cellv[p] == kOutside) {
-                    const Rec r = make_outside_record(tid, p, RC);
-                    const size_t o = (size_t)(hist[(tid * G.P + p) % ntl] + trk[p][0]) * 2;
-                    rc[o] = r.a;
-                    rc[o + 1] = r.b;
-                    continue;
-                }
+                const unsigned ab = __float_as_uint(attn[abase + p]);
                 Cell c;
                 c.valid = true;
                 c.cy = (int)(cellv[p] >> 16);
                 c.cx = (int)(cellv[p] & 0xFFFFu);
                 unsigned i = 0;
-                for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool home) {   // (the same order as in pass 1)
+                for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool) {   // (the same order as in pass 1)
                     const unsigned rank = i == 0 ? trk[p][0] : (i == 1 ? trk[p][1] : (i == 2 ? trk[p][2] : trk[p][3]));
-                    const Rec r = make_record(tid, p, (unsigned)c.cy, (unsigned)c.cx, lwv[p], lhv[p], Lv, ty, tx, home, RC);
+                    const Rec r = make_record(tid, ab, (unsigned)c.cy, (unsigned)c.cx, lwv[p], lhv[p], Lv, ty, tx);
                     const size_t o = (size_t)(hist[t] + rank) * 2;
                     rc[o] = r.a;
                     rc[o + 1] = r.b;
@@ -468,17 +453,13 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                 const float2 xy = *reinterpret_cast<const float2 *>(loc + (base + p) * 2);
                 const Cell c = cell_of(xy.x, xy.y, Lv.H, Lv.W);
                 if (c.valid) {
-                    for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool home) {
+                    const unsigned ab = __float_as_uint(attn[base + p]);
+                    for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool) {
                         const size_t o = (size_t)atomicAdd(&hist[t], 1u) * 2;   // (the offsets become cursors)
-                        const Rec r = make_record(q, p, (unsigned)c.cy, (unsigned)c.cx, __float_as_uint(c.lw), __float_as_uint(c.lh), Lv, ty, tx, home, RC);
+                        const Rec r = make_record(q, ab, (unsigned)c.cy, (unsigned)c.cx, __float_as_uint(c.lw), __float_as_uint(c.lh), Lv, ty, tx);
                         rc[o] = r.a;
                         rc[o + 1] = r.b;
                     });
-                } else {
-                    const size_t o = (size_t)atomicAdd(&hist[(q * G.P + p) % ntl], 1u) * 2;
-                    const Rec r = make_outside_record(q, p, RC);
-                    rc[o] = r.a;
-                    rc[o + 1] = r.b;
                 }
             }
         }
@@ -513,9 +494,10 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
 
 template <bool kOnePass>
 __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
-                                                          const float *__restrict__ loc, PlanGeom G, PlanPtrs W)
+                                                          const float *__restrict__ loc, const float *__restrict__ attn,
+                                                          PlanGeom G, PlanPtrs W)
 {
-    plan_unit<kOnePass>(shapes, start, loc, G, W, blockIdx.x);
+    plan_unit<kOnePass>(shapes, start, loc, attn, G, W, blockIdx.x);
 }
 
 // Forward gather + plan in ONE launch (zira_msda_fwd_plan_f32): the first `units8` blocks plan a (head, level) unit each
@@ -539,8 +521,8 @@ __global__ __launch_bounds__(kPlanThreads, ZIRA_FUSED_WAVES) void msda_fwd_plan(
 {
     if (blockIdx.x < units8) {
         if (blockIdx.x < units) {
-            if (onepass) plan_unit<true>(shapes, start, loc, G, W, blockIdx.x);
-            else plan_unit<false>(shapes, start, loc, G, W, blockIdx.x);
+            if (onepass) plan_unit<true>(shapes, start, loc, attn, G, W, blockIdx.x);
+            else plan_unit<false>(shapes, start, loc, attn, G, W, blockIdx.x);
         }
         return;
     }
@@ -608,25 +590,12 @@ __device__ __forceinline__ float dot4f(float4 a, float4 b)
 }
 __device__ __forceinline__ unsigned uni(unsigned x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// what a record says about its sample in this tile (the same in the 8 lanes of the sample's group)
-struct Dec {
-    float lw, lh;
-    unsigned o01, o23;    // LDS byte offsets of the four corner rows
-    unsigned pixb;        // byte offset of the clamped top-left pixel's value row in the level (home records), else 0
-    unsigned fl;          // record flags; 0 for the padding of the last step
-    unsigned oi;          // index of the sample in grad_attn (x 2 in grad_loc), relative to query 0 of the head
-    unsigned gob;         // byte offset of the query's grad_out row, relative to query 0 of the head
-};
-struct Ld {
-    float a;
-    float4 g, v00, v01, v10, v11;
-};
 // a work item: a tile or a share of a split tile; everything block-uniform (scalar registers)
 struct Item {
     unsigned n, ty0, tx0, the, twe, H, W;
     unsigned share, slot; // a share of a split tile: its sums go to partial tile `slot` of the workspace
     unsigned hq;          // item index of query 0 of the head: b * Q * M + m
-    size_t voff;          // float offset of the level's pixel 0, this head, in value / grad_value
+    size_t voff;          // float offset of the level's pixel 0, this head, in grad_value
     size_t roff;          // first record
 };
 struct Hdr {
@@ -638,33 +607,65 @@ __device__ __forceinline__ T ldg(const void *base, unsigned byte_off)   // scala
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-__global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd_tile_accum(
-    const float *__restrict__ grad_out, const float *__restrict__ value, const float *__restrict__ attn, PlanGeom G,
-    const unsigned *__restrict__ ucnt, const uint4 *__restrict__ citems, const uint4 *__restrict__ recs,
-    float *__restrict__ dump, float *__restrict__ partial, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn)
+// kRes: a block works for ONE head (b, m) and keeps that head's grad_out rows (Q x 128 bytes) in LDS beside the tile --
+// the step loop then has no load that depends on another load's result: records stream in (requested steps ahead), the
+// grad_out row comes out of LDS, the adds go to LDS.  (Round 4's first kernel gathered the row, the attention weight and the
+// four value rows of a record from global memory each step: a chain of two dependent L2 / HBM round trips per step, 1.3 us
+// per step with two steps in flight, which bounded the kernel whatever its LDS work.)  Otherwise (more queries than fit):
+// the row is gathered from global memory, requested a step ahead.
+// The gather half of the backward (grad_sampling_loc, grad_attn_weight: a wave per (b, q, m), csrc/msda_fwd_lean.h) rides
+// in the same launch: blocks [0, nacc) accumulate -- three per CU --, the others take NTHR / 64 items each and pass through
+// the fourth slot of every CU while the accumulate blocks wait on their loads (two kernels one after the other: 9.2 + 24.9 us).
+struct HomeArgs {
+    const float *value, *loc, *attn;
+    const int64_t *shapes, *start;
+    float *grad_loc, *grad_attn;
+    unsigned S, LP, nitems, per_xcd, nacc;
+    float invP;
+    FastDiv Mdiv, Qdiv;
+};
+template <bool kRes, unsigned NTHR>
+__global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_accum(
+    const float *__restrict__ grad_out, PlanGeom G, const unsigned *__restrict__ ucnt, const uint4 *__restrict__ citems,
+    const uint4 *__restrict__ recs, float *__restrict__ dump, float *__restrict__ partial, float *__restrict__ grad_value,
+    const HomeArgs HA)
 {
-    constexpr unsigned D = 32, LPS = 8, NTHR = kAccThreads, NW = NTHR / 64, NG = 8;
+    if (blockIdx.x >= HA.nacc) {
+        const ItemId id = lean_item(HA.nitems, HA.per_xcd, HA.Qdiv, HA.Mdiv, blockIdx.x - HA.nacc, NTHR / 64);
+        if (!id.ok) return;  // wave-uniform
+        bwd_home_item<2>(grad_out, HA.value, HA.shapes, HA.start, HA.loc, HA.attn, HA.S, HA.Mdiv.d, HA.LP, HA.invP, id,
+                         HA.grad_loc, HA.grad_attn);
+        return;
+    }
+    constexpr unsigned D = 32, LPS = 8, NW = NTHR / 64, NG = 8;
     constexpr unsigned SPB = NW * NG;     // records per block step
-    extern __shared__ double lds_acc[];   // [(kNPix + 1) * D]: the tile, then the trash row
+    extern __shared__ double lds_acc[];   // [(kNPix + 1) * D]: the tile, then the trash row; the deal's table; (kRes) the head's grad_out rows
     double *acc = lds_acc;
 
     TSTAMP_DECL;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned grp = lane / LPS, j = lane % LPS;
-    // this block's list of items (group g = the heads whose value slices this XCD keeps in its L2; placement is for speed only)
-    const unsigned g = G.ng > 1 ? blockIdx.x & 7u : 0u, k = G.ng > 1 ? blockIdx.x >> 3 : blockIdx.x;
-    // This block's items.  The units of the group (nug of them) publish three class counts each; laid end to end --
-    // class-major, so heavy items first -- they form one ring, and block k takes positions k, k + nbg, ...
-    unsigned *tab = reinterpret_cast<unsigned *>(acc + (kNPix + 1) * D);   // [3 nug] prefix, then [nug] first item slot of the unit
+    // this block's list of items: group g = the heads it works for (kRes: one head; else the heads whose value slices an
+    // XCD keeps in its L2), k = its number inside the group
+    const unsigned g = blockIdx.x % G.ng, k = blockIdx.x / G.ng;
+    // The units of the group (nug of them) publish their class counts; laid end to end -- class-major, so heavy items
+    // first -- they form one ring, and block k takes positions k, k + nbg, ...
+    unsigned *tab = reinterpret_cast<unsigned *>(acc + (kNPix + 1) * D);   // [kClasses nug] prefix, then [nug] first item slot of the unit
     const unsigned h0 = g * G.hp;
+    if (h0 >= G.heads) return;
     const unsigned nug = (G.heads - h0 < G.hp ? G.heads - h0 : G.hp) * G.L, ne = kClasses * nug;
-    if (G.ng > 1 && h0 >= G.heads) return;
+    float *rows = reinterpret_cast<float *>(tab + ((ne + nug + 1 + 3) & ~3u));   // (kRes) [Q][32]
     for (unsigned e = tid; e < ne; e += NTHR) {
         const unsigned c = e / nug, u = e - c * nug;
         tab[e] = ucnt[(h0 * G.L + u) * kUcnt + c];
     }
     for (unsigned u = tid; u < nug; u += NTHR) tab[ne + u] = ucnt[(h0 * G.L + u) * kUcnt + kClasses];
+    if (kRes) {   // the head's grad_out rows: row q at [q][32] (eight lanes a row; the rows are M * 128 bytes apart)
+        const unsigned b = fdiv(h0, G.Mdiv), m = h0 - b * G.M;
+        const float *src = grad_out + ((size_t)b * G.Q * G.M + m) * D;
+        for (unsigned x = tid; x < G.Q * 8u; x += NTHR)
+            reinterpret_cast<float4 *>(rows)[x] = *reinterpret_cast<const float4 *>(src + (size_t)(x >> 3) * G.M * D + (x & 7u) * 4u);
+    }
     __syncthreads();
     if (wave == 0) {   // exclusive prefix over the ne counts, 64 at a time
         unsigned run = 0;
@@ -739,9 +740,9 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
         it.voff = (size_t)vrow * D;
         return it;
     };
-    // Every load and store of the item pipeline is issued unconditionally (clamped or redirected addresses): loads
-    // and stores share one in-order counter on gfx950, and the compiler can only let a wave wait for exactly the
-    // load it needs when it knows how many memory operations were issued after it.
+    // Every load of the item pipeline is issued unconditionally (clamped addresses): loads and stores share one in-order
+    // counter on gfx950, and the compiler can only let a wave wait for exactly the load it needs when it knows how many
+    // memory operations were issued after it.
     struct Raw {
         uint4 a, b;
     };
@@ -753,66 +754,25 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
         r.b = ldg<uint4>(recs + it.roff, o + 16u);
         return r;
     };
-    auto decode = [&](const Item &it, const Raw &r, unsigned s) {
-        Dec d;
+    auto row_of = [&](const Item &it, const Raw &r) {   // this lane's four channels of the record's grad_out row
+        if (kRes) return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rows) + r.a.x + j * 16u);
+        return ldg<float4>(grad_out + (size_t)it.hq * D, r.a.x * G.M + j * 16u);
+    };
+    auto compute = [&](const Item &it, const Raw &r, const float4 g4, unsigned s) {
         const bool ok = s * SPB + gsel < it.n;
-        d.gob = ok ? r.a.x : 0u;
-        d.oi = ok ? r.a.y : 0u;
-        d.pixb = ok ? r.a.z : 0u;
-        d.o01 = ok ? r.a.w : (kTrash | (kTrash << 16));
-        d.o23 = ok ? r.b.x : (kTrash | (kTrash << 16));
-        d.fl = ok ? r.b.y : 0u;
-        d.lw = __uint_as_float(r.b.z);
-        d.lh = __uint_as_float(r.b.w);
-        return d;
-    };
-    auto issue = [&](const Item &it, const Dec &d) {
-        Ld x;
-        x.a = ldg<float>(attn + (size_t)it.hq * G.LP, d.oi * 4u);
-        x.g = ldg<float4>(grad_out + (size_t)it.hq * D, d.gob + j * 16u);
-        // (records in a neighbour's halo read pixel 0's rows and ignore them)
-        const float *vb = value + it.voff;
-        const unsigned o = d.pixb + j * 16u;
-        const unsigned dx = (d.fl & kFlXStep) ? rs * 4u : 0u, dy = (d.fl & kFlYStep) ? it.W * rs * 4u : 0u;
-        x.v00 = ldg<float4>(vb, o);
-        x.v01 = ldg<float4>(vb, o + dx);
-        x.v10 = ldg<float4>(vb, o + dy);
-        x.v11 = ldg<float4>(vb, o + dy + dx);
-        return x;
-    };
-    auto compute = [&](const Item &it, const Dec &d, const Ld &x) {
-        const float lw = d.lw, lh = d.lh;
-        const float a = (d.fl & kFlLive) ? x.a : 0.f;
+        const float lw = __uint_as_float(r.b.x), lh = __uint_as_float(r.b.y);
+        const float a = ok ? __uint_as_float(r.a.y) : 0.f;
         const float hh = 1.f - lh, hw = 1.f - lw;
         const float w00 = __fmul_rn(hh, hw), w01 = __fmul_rn(hh, lw), w10 = __fmul_rn(lh, hw), w11 = __fmul_rn(lh, lw);
-        const float4 g4 = x.g;
-        {   // home tile of the sample: grad_attn_weight, grad_sampling_loc (cuh:123-158); the others store to a dump word
-            const float p00 = (d.fl & kFl00) ? dot4f(g4, x.v00) : 0.f, p01 = (d.fl & kFl01) ? dot4f(g4, x.v01) : 0.f;
-            const float p10 = (d.fl & kFl10) ? dot4f(g4, x.v10) : 0.f, p11 = (d.fl & kFl11) ? dot4f(g4, x.v11) : 0.f;
-            float ga = __fmul_rn(w00, p00);
-            ga = fmaf(w01, p01, ga);
-            ga = fmaf(w10, p10, ga);
-            ga = fmaf(w11, p11, ga);
-            float gx = fmaf(hh, __fsub_rn(p01, p00), __fmul_rn(lh, __fsub_rn(p11, p10)));
-            float gy = fmaf(hw, __fsub_rn(p10, p00), __fmul_rn(lw, __fsub_rn(p11, p01)));
-            ga = group_sum8(ga);
-            gx = group_sum8(gx);
-            gy = group_sum8(gy);
-            const bool st = (d.fl & kFlHome) && j == 0;
-            float *ga_h = grad_attn + (size_t)it.hq * G.LP, *gl_h = grad_loc + (size_t)it.hq * G.LP * 2;
-            *(st ? ga_h + d.oi : dump + lane) = ga;
-            *reinterpret_cast<float2 *>(st ? gl_h + 2 * (size_t)d.oi : dump + 64 + 2 * lane) =
-                make_float2(__fmul_rn(__fmul_rn((float)it.W, a), gx), __fmul_rn(__fmul_rn((float)it.H, a), gy));
-        }
-        // corner rows: term = w * (a * g), both factors rounded to fp32 as the reference forms them, the product
-        // and the sum in double.  Layout of an accumulator row (32 words of 8 bytes): see kAccLayout.
-        // The two groups of a 16-lane LDS row issue their four adds in different orders (kk ^ swap), so that one
-        // instruction finds them in different halves of the banks (steps alone 33.4 -> 28.4 us).
+        // corner rows: term = w * (a * g), both factors rounded to fp32 as the reference forms them (cuh:117-147), the
+        // product and the sum in double.  The two groups of a 16-lane LDS row issue their four adds in different orders
+        // (kk ^ swap), so that one instruction finds them in different halves of the banks.
         const float gs[4] = {odd ? g4.y : g4.x, odd ? g4.x : g4.y, odd ? g4.w : g4.z, odd ? g4.z : g4.w};
         const double tt[4] = {(double)__fmul_rn(gs[0], a), (double)__fmul_rn(gs[1], a), (double)__fmul_rn(gs[2], a),
                               (double)__fmul_rn(gs[3], a)};
         const double wc[4] = {(double)w00, (double)w01, (double)w10, (double)w11};
-        const unsigned oc[4] = {d.o01 & 0xFFFFu, d.o01 >> 16, d.o23 & 0xFFFFu, d.o23 >> 16};
+        const unsigned o01 = ok ? r.a.z : (kTrash | (kTrash << 16)), o23 = ok ? r.a.w : (kTrash | (kTrash << 16));
+        const unsigned oc[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
 #pragma unroll
         for (unsigned cc = 0; cc < 4; ++cc) {
             char *ap = reinterpret_cast<char *>(acc) + oc[cc];
@@ -822,62 +782,52 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
         }
     };
 
-    // Items are pipelined: the header of item i + 2 is requested when item i starts; the first records of item i + 1 are
-    // requested before item i's steps and the loads of its first step issued before item i is written out, so that an
-    // item begins with its operands in flight.
+    // Items are pipelined: the header of item i + 2 is requested when item i starts, the first records of item i + 1 before
+    // item i's steps.  Inside an item the records of steps s + 4, s + 5 and the grad_out rows of steps s + 2, s + 3 are on
+    // their way while steps s, s + 1 are summed.
     Hdr h1 = load_hdr(cnt > 1 ? 1u : 0u);
     Item it = make_item(load_hdr(0));
-    Raw r1 = fetch(it, 0), r2 = fetch(it, 1);
-    Dec d0 = decode(it, r1, 0);
-    Ld x0 = issue(it, d0);
-    r1 = r2;
-    r2 = fetch(it, 2);
+    Raw ra = fetch(it, 0), rb = fetch(it, 1), rc = fetch(it, 2), rd = fetch(it, 3);
     Item nx = make_item(h1);
-    __syncthreads();   // (the accumulators are clear)
+    __syncthreads();   // (the accumulators are clear, the rows are there)
     TSTAMP(0);
     for (unsigned i = 0;; ++i) {
         const bool more = i + 1 < cnt;
         const Hdr h2 = load_hdr(i + 2 < cnt ? i + 2 : cnt - 1);
-        const Raw n1 = fetch(nx, 0);
-        // (wave w holds records 8 w .. 8 w + 7 of every 32: a wave without records at a step skips it)
+        const Raw na = fetch(nx, 0), nb = fetch(nx, 1), nc = fetch(nx, 2), nd = fetch(nx, 3);
+        // (wave w holds records 8 w .. 8 w + 7 of every SPB: a wave without records at a step skips it)
         const unsigned nsteps = it.n > wave * NG ? (it.n - wave * NG + SPB - 1) / SPB : 0u;
-        for (unsigned s = 0; s < nsteps; s += 2) {   // two steps in flight: the loads of step s + 1 are issued before step s is
-            const Dec d1 = decode(it, r1, s + 1);      // summed (two copies of the body: no register moves between steps)
-            const Ld x1 = issue(it, d1);
-            r1 = fetch(it, s + 3);
-            compute(it, d0, x0);
-            if (s + 1 >= nsteps) break;
-            d0 = decode(it, r2, s + 2);
-            x0 = issue(it, d0);
-            r2 = fetch(it, s + 4);
-            compute(it, d1, x1);
+        float4 g0 = row_of(it, ra), g1 = row_of(it, rb);
+        for (unsigned s = 0; s < nsteps; s += 2) {   // (two copies of the body per round)
+            const float4 g2 = row_of(it, rc);
+            const Raw re = fetch(it, s + 4);
+            compute(it, ra, g0, s);
+            const float4 g3 = row_of(it, rd);
+            const Raw rf = fetch(it, s + 5);
+            if (s + 1 < nsteps) compute(it, rb, g1, s + 1);
+            ra = rc; rb = rd; rc = re; rd = rf;
+            g0 = g2; g1 = g3;
         }
         TSTAMP(1);
-        r2 = fetch(nx, 1);
         if (it.n) __syncthreads();   // every add of the item has landed
-        d0 = decode(nx, n1, 0);
-        x0 = issue(nx, d0);
-        r1 = r2;
-        r2 = fetch(nx, 2);
+        ra = na; rb = nb; rc = nc; rd = nd;
         TSTAMP(2);
 
         // ---- write-out (each thread clears the accumulator words it reads) -------------------------------
-        // Thread t gets channels 4 (t & 7) .. + 3 of pixel 32 i + (t >> 3) in round i and stores them with one 16-byte
-        // store -- a wave writes eight whole 128-byte rows (4-byte stores of a bank-conflict-free linear read of the tile
-        // were measured first: the write-out alone 20.8 against 12.1 us).
+        // Thread t gets channels 4 (t & 7) .. + 3 of pixel PPR i + (t >> 3) in round i and stores them with one 16-byte
+        // store -- a wave writes eight whole 128-byte rows.
         {
             constexpr unsigned PPR = NTHR / 8, NR = kNPix / PPR;          // pixels per round, rounds
-            static_assert(PPR % kTW == 0, "a round covers whole pixel rows");
+            static_assert(PPR % kTW == 0 && kNPix % PPR == 0, "a round covers whole pixel rows");
             const unsigned c4 = tid & 7u, p0 = tid >> 3;                  // channel quad, pixel of round 0 (then + PPR per round)
             const unsigned pc = p0 % kTW, pr0 = p0 / kTW;
             const bool colin = pc < it.twe;
             float *gbase = grad_value + it.voff + ((size_t)(it.ty0 + pr0) * it.W + (it.tx0 + pc)) * rs + c4 * 4;
             const size_t rstep = (size_t)(PPR / kTW) * it.W * rs;
-            // (thread t: pixel row (t >> 3) of the round, channel quad t & 7)
             char *lp = reinterpret_cast<char *>(acc) + (tid >> 3) * kRowBytes + (tid & 7u) * 8u;
             constexpr unsigned kRound = PPR * kRowBytes;
-            auto take4 = [&](unsigned i) {   // read this thread's four channels of round i and clear them
-                char *q = lp + i * kRound;
+            auto take4 = [&](unsigned ii) {   // read this thread's four channels of round ii and clear them
+                char *q = lp + ii * kRound;
                 float4 o;
                 double *w = reinterpret_cast<double *>(q);
                 o = make_float4((float)w[0], (float)w[8], (float)w[16], (float)w[24]);
@@ -886,16 +836,16 @@ __global__ __launch_bounds__(kAccThreads, ZIRA_TILE_BLOCKS_PER_CU) void msda_bwd
             };
             if (!it.share) {   // every pixel of the tile once, plain stores (grad_value is never zero-filled)
 #pragma unroll
-                for (unsigned i = 0; i < NR; ++i) {
+                for (unsigned ii = 0; ii < NR; ++ii) {
                     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (it.n) o = take4(i);
-                    float *dst = (colin && (PPR / kTW) * i + pr0 < it.the) ? gbase + i * rstep : dump + 192 + 4 * lane;   // (pixels of an edge tile outside the map)
+                    if (it.n) o = take4(ii);
+                    float *dst = (colin && (PPR / kTW) * ii + pr0 < it.the) ? gbase + ii * rstep : dump + 192 + 4 * lane;   // (pixels of an edge tile outside the map)
                     *reinterpret_cast<float4 *>(dst) = o;
                 }
             } else {            // a share of a split tile: the whole tile, as it is, to its partial tile (msda_bwd_fold adds the shares up)
                 float *pb = partial + (size_t)it.slot * kNPix * D + (size_t)p0 * D + c4 * 4;
 #pragma unroll
-                for (unsigned i = 0; i < NR; ++i) *reinterpret_cast<float4 *>(pb + (size_t)i * PPR * D) = take4(i);
+                for (unsigned ii = 0; ii < NR; ++ii) *reinterpret_cast<float4 *>(pb + (size_t)ii * PPR * D) = take4(ii);
             }
         }
         if (it.n) __syncthreads();   // the tile is clear again before the next item adds to it
@@ -913,7 +863,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct TilesLayout {
     PlanGeom G;
     size_t ctl_bytes, off_usplit, off_citems, off_dump, off_recs, off_partial, total;
-    bool one_pass;
+    bool one_pass, resident;
     size_t lds_plan, lds_acc;
     unsigned units, grid;
 };
@@ -954,12 +904,22 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     G.ecap = (unsigned)(((unsigned long long)G.rcap * 2) / G.cap) + 1;   // sum of K over split tiles <= 2 records / cap
     G.iph = G.ntmax + G.L * G.ecap;
     if ((unsigned long long)T.units * G.rcap >= (1ull << 31)) return false;   // 32-bit record indices
-    G.ng = heads >= 8 ? 8u : 1u;
-    G.hp = G.ng > 1 ? (unsigned)((heads + 7) / 8) : G.heads;
-    T.grid = tiles_cu_count() * ZIRA_TILE_BLOCKS_PER_CU;
-    if (G.ng > 1) T.grid &= ~7u;
-    if (T.grid < G.ng) return false;
-    G.nbg = T.grid / G.ng;
+    // Accumulate blocks.  Resident form (the head's grad_out rows in LDS: Q <= kResQ): a group = one head, one block per CU,
+    // cus / heads blocks per head (at least one).  Otherwise: a group = the heads whose value slices one XCD keeps in its L2.
+    T.resident = (unsigned)Q <= kResQ;
+    if (T.resident) {
+        G.ng = G.heads;
+        G.hp = 1;
+        G.nbg = tiles_cu_count() / G.heads > 0 ? tiles_cu_count() / G.heads : 1u;
+        T.grid = G.ng * G.nbg;
+    } else {
+        G.ng = heads >= 8 ? 8u : 1u;
+        G.hp = G.ng > 1 ? (unsigned)((heads + 7) / 8) : G.heads;
+        T.grid = tiles_cu_count() * ZIRA_TILE_BLOCKS_PER_CU;
+        if (G.ng > 1) T.grid &= ~7u;
+        if (T.grid < G.ng) return false;
+        G.nbg = T.grid / G.ng;
+    }
     if (heads * G.iph >= (1ull << 28)) return false;
     G.ccap = (unsigned)(heads * G.iph);
     if ((unsigned long long)G.hp * L * (kClasses + 1) + 1 > 1024) return false;   // (the deal's prefix table lives in LDS beside the tile)
@@ -967,7 +927,8 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     G.NBGdiv = make_fdiv(G.nbg);
     T.lds_plan = (kTLevelWords * kTMaxLevels + 16 + kPlanThreads / 64 + 1 + G.ntmax) * 4;
     if (T.lds_plan > 64 * 1024) return false;
-    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + ((size_t)G.hp * L * (kClasses + 1) + 1) * 4;
+    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + (((size_t)G.hp * L * (kClasses + 1) + 1 + 3) & ~(size_t)3) * 4 +
+                (T.resident ? (size_t)Q * 128 : 0);
     T.one_pass = (unsigned)Q <= kPlanThreads && P <= 4;
     size_t o = 0;
     T.ctl_bytes = align256((size_t)T.units * (kUcnt + 1) * 4);   // ucnt[units][kUcnt], scount[units]
@@ -1004,16 +965,16 @@ size_t tiles_plan_bytes(int B, int S, int M, int D, int L, int Q, int P)
     return make_tiles_layout(B, S, M, D, L, Q, P, T) ? T.total : 0;
 }
 
-int tiles_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc, int B, int S, int M, int D, int L, int Q,
-                   int P, void *plan, size_t plan_bytes, hipStream_t st)
+int tiles_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc, const float *attn, int B, int S, int M, int D,
+                   int L, int Q, int P, void *plan, size_t plan_bytes, hipStream_t st)
 {
     TilesLayout T;
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
     const PlanPtrs W = plan_ptrs(T, plan);
     if (T.one_pass)
-        hipLaunchKernelGGL(msda_plan<true>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, T.G, W);
+        hipLaunchKernelGGL(msda_plan<true>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, attn, T.G, W);
     else
-        hipLaunchKernelGGL(msda_plan<false>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, T.G, W);
+        hipLaunchKernelGGL(msda_plan<false>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, attn, T.G, W);
     return (int)hipGetLastError();
 }
 
@@ -1033,16 +994,36 @@ int tiles_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t 
     return (int)hipGetLastError();
 }
 
-int tiles_backward_planned_f32(const float *grad_out, const float *value, const float *attn, int B, int S, int M, int D,
-                               int L, int Q, int P, float *gv, float *gl, float *ga, const void *plan, size_t plan_bytes,
-                               hipStream_t st)
+int tiles_backward_planned_f32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
+                               const float *loc, const float *attn, int B, int S, int M, int D, int L, int Q, int P, float *gv,
+                               float *gl, float *ga, const void *plan, size_t plan_bytes, hipStream_t st)
 {
     TilesLayout T;
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
     const PlanPtrs W = plan_ptrs(T, const_cast<void *>(plan));
     float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<void *>(plan)) + T.off_dump);
-    hipLaunchKernelGGL(msda_bwd_tile_accum, dim3(T.grid), dim3(kAccThreads), T.lds_acc, st, grad_out, value, attn, T.G,
-                       W.ucnt, W.citems, W.recs, dump, W.partial, gv, gl, ga);
+    if ((unsigned long long)B * Q * M >= (1ull << 31) || L * P > 64) return -1;
+    HomeArgs HA;
+    HA.value = value; HA.loc = loc; HA.attn = attn; HA.shapes = shapes; HA.start = start; HA.grad_loc = gl; HA.grad_attn = ga;
+    HA.S = (unsigned)S; HA.LP = (unsigned)(L * P); HA.nitems = (unsigned)B * Q * M; HA.per_xcd = (HA.nitems + 7) >> 3;
+    HA.nacc = T.grid; HA.invP = 1.0f / (float)P; HA.Mdiv = make_fast_div((unsigned)M); HA.Qdiv = make_fast_div((unsigned)Q);
+    if (T.grid & 7u) return -1;   // (the gather blocks' XCD interleave starts at a multiple of 8)
+    if (T.resident) {
+        static bool attr_set = false;   // (one device per process)
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tile_accum<true, kResThreads>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess)
+                return -1;
+            attr_set = true;
+        }
+        const unsigned wpb = kResThreads / 64;
+        hipLaunchKernelGGL((msda_bwd_tile_accum<true, kResThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kResThreads),
+                           T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
+    } else {
+        const unsigned wpb = kAccThreads / 64;
+        hipLaunchKernelGGL((msda_bwd_tile_accum<false, kAccThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kAccThreads),
+                           T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(msda_bwd_fold, dim3(T.units * kFoldParts), dim3(256), 0, st, T.G, W.scount, W.usplit, W.partial, gv);
