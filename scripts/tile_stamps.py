@@ -28,6 +28,11 @@ for i, nme in enumerate(names):
     x = a[:, i] / 100.0
     print("  %-34s mean %6.2f us  max %6.2f   per item %5.2f" % (nme, x.mean(), x.max(), (a[:, i] / np.maximum(a[:, 8], 1)).mean() / 100.0))
 
+order = np.argsort(-tot)
+print("slowest / fastest blocks: busy us (prologue, steps, barrier, flush) items")
+for i in list(order[:6]) + list(order[-3:]):
+    print("   %6.2f  (%5.2f %5.2f %5.2f %5.2f)  %d" % (tot[i], a[i, 0] / 100.0, a[i, 1] / 100.0, a[i, 2] / 100.0, a[i, 3] / 100.0, a[i, 8]))
+print("busy-time percentiles (us):", " ".join("%d%%=%.1f" % (q, np.percentile(tot, q)) for q in (10, 25, 50, 75, 90, 99)))
 lib.zira_dev_read_plan_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.zira_dev_read_plan_stamps(buf, n) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16).astype(np.int64)

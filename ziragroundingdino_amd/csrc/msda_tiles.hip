@@ -9,37 +9,43 @@
 // (scripts/lds_atomic_rates2.hip; `ds_add_f32` takes 193), so a 16 x 8-pixel tile of grad_value can simply be SUMMED
 // IN LDS IN DOUBLE, in any order, and a pile-up of the decoder's queries on a few pixels costs nothing extra.  What
 // has to be organised is which samples go to which tile and how the tiles are dealt to the CUs -- and all of that
-// depends on the sampling locations only, which are known in the FORWARD pass.  Round 3 planned inside the backward
+// depends on the sampling locations (and, for the records' weights, the attention weights) only, which are known in the
+// FORWARD pass.  Round 3 planned inside the backward
 // call (15 us on 64 CUs in front of the accumulate kernel); since round 4 the plan is made in the forward pass -- by
 // the first 64 blocks of the forward's own grid (msda_fwd_plan / zira_msda_fwd_plan_f32; msda_plan is the same code as a
 // kernel of its own) -- and the backward (zira_msda_bwd_planned_f32) starts with everything resolved:
 //
-//   plan   (plan_unit)  one 1024-thread block per (head, level) unit; touches only the sampling locations.  Pass 1: a
+//   plan   (plan_unit)  one 1024-thread block per (head, level) unit; touches only the sampling locations and attention weights.  Pass 1: a
 //          thread per query computes the pixel cells of its samples and counts each sample into every tile its
 //          2 x 2 corner block touches (LDS histogram; the rank inside the tile comes back from the atomic).  A block
 //          scan turns the histogram into record offsets.  Per tile a 32-byte WORK ITEM {first record, records, tile
 //          origin, level size, value row of the level's pixel 0, query 0 of the head, ...}; a tile with more than
 //          `cap` records is SPLIT into K = ceil(n / cap) items whose sums meet in a small fold launch behind the
 //          accumulate kernel.  Pass 2 writes one 32-byte RECORD per
-//          (sample, touched tile) with everything the accumulate kernel needs already resolved: byte offset of the
-//          query's grad_out row, index of the sample in grad_attn, byte offset of its top-left value row, the LDS
-//          byte offsets of its four corner rows (a trash row for corners outside this tile), flags, lw, lh.  A sample
-//          outside (-1, H) x (-1, W) gets one record without corners whose only effect is zero gradients.
-//          The items of a unit are stored by size class (six classes by record count, i.e. by 32-record block steps) and the unit's three
-//          counts published; nothing else crosses between plan blocks -- no atomics on global memory, no fence, nothing
-//          to initialise.  The deal is made by the accumulate blocks themselves: a prefix over the class counts of
+//          (sample, touched tile) with everything the accumulate kernel needs already resolved: where the query's
+//          grad_out row is, the attention weight, the LDS byte offsets of its four corner rows (a trash row for corners
+//          outside this tile), lw, lh.  A sample outside (-1, H) x (-1, W) has no record.
+//          The items of a unit are stored by size class (eight classes by record count, i.e. by 32-record block steps) and the
+//          unit's counts published; nothing else crosses between plan blocks -- no atomics on global memory, no fence,
+//          nothing to initialise.  The deal is made by the accumulate blocks themselves: a prefix over the class counts of
 //          the units of a group of heads (= one XCD's share) lays all items of the group on one virtual ring, heavy
-//          ones first, and block k takes ring positions k, k + nbg, ...: longest-processing-time-first in three steps,
-//          the same for every run.  (Measured on the way: a sort by the group's last plan block costs 6 us for the
+//          ones first, and block k takes position k of the even rounds of nbg positions and nbg - 1 - k of the odd ones:
+//          longest-processing-time-first in eight steps, the same for every run.  (Measured on the way: a sort by the group's last plan block costs 6 us for the
 //          device-scope release / acquire + 3 us for the sort; ring cursors in global memory need a clearing launch --
 //          hipMemsetAsync is replayed out of order inside a hipGraph on ROCm 7.2 -- that rocprofv3 shows at 4.6 us.)
-//   accum  (msda_bwd_tile_accum)  persistent blocks (256 threads, 4 per CU).  Per item: 32 records per block step, 8
-//          lanes x 4 channels per record: the grad_out row (one 128-byte gather), the corner terms w * (attn * g) added
-//          to the tile's accumulators in LDS (`ds_add_f64`), and -- in the tile that owns the sample -- the four value
-//          rows, their dot products with the grad_out row and grad_sampling_loc / grad_attn_weight.  Two-stage software
-//          pipeline, all loads and stores unconditional (clamped record index, dump line) so that the compiler's
-//          in-order vmcnt waits stay exact; the next item's first records are requested before the current item's steps,
-//          its first loads before the current tile is flushed.  Flush: every pixel of an unsplit tile once with 16-byte
+//   accum  (msda_bwd_tile_accum)  ONE launch with two kinds of blocks (256 threads): persistent accumulate blocks, 3 per CU,
+//          and behind them gather blocks that pass through the fourth slot of every CU -- a wave per (b, q, m) forms
+//          grad_sampling_loc / grad_attn_weight exactly as the forward forms its output (csrc/msda_fwd_lean.h:
+//          bwd_home_item).  Accumulate, per item: 32 records per block step, 8 lanes x 4 channels per record: the grad_out
+//          row (one 128-byte gather, the step's only dependent load) and the corner terms w * (attn * g) added to the
+//          tile's accumulators in LDS (`ds_add_f64`).  Records are requested four steps ahead, rows two; all loads
+//          unconditional (clamped record index) so that the compiler's in-order vmcnt waits stay exact; the next item's
+//          first records are requested before the current item's steps.  (Until the middle of round 4 the accumulate
+//          blocks also did the gather half for the tile that owns a sample -- attention weight, four value rows, dot
+//          products -- from loads that depended on the record: two dependent round trips per step, 1.3 us per step,
+//          35 us for the kernel; with the weight in the record and the gather half in its own waves a step is bound by
+//          the LDS adds -- 13 us of steps per block for 9.3 us of `ds_add_f64` issue per CU -- and the launch takes 27.8 us
+//          for both halves.)  Flush: every pixel of an unsplit tile once with 16-byte
 //          stores (no zero-fill of grad_value anywhere), each thread clearing the accumulator words it read; empty
 //          tiles are written as zeros without touching LDS; shares of split tiles store their sums to partial tiles that a small second launch (msda_bwd_fold) adds up.
 //
@@ -72,12 +78,6 @@
 #ifndef ZIRA_TILE_THREADS
 #define ZIRA_TILE_THREADS 256  // threads of an accumulate block
 #endif
-#ifndef ZIRA_TILE_RES_THREADS
-#define ZIRA_TILE_RES_THREADS 512
-#endif
-#ifndef ZIRA_RESQ
-#define ZIRA_RESQ 0     // 960: the resident form (measured: 39.4 us against 24.9 us for the gathered rows at 4 blocks per CU -- with one block per CU an item's header and first records are a serial latency chain)
-#endif
 
 namespace zira {
 namespace {
@@ -90,20 +90,15 @@ constexpr unsigned kRowBytes = 32 * 8;  // one accumulator row: 32 channels in d
 constexpr unsigned kTrash = kNPix * kRowBytes;   // LDS byte offset of the trash row (corners owned by another tile)
 static_assert(kTrash < 65536, "a corner's LDS offset is 16 bits of a record");
 constexpr unsigned kAccThreads = ZIRA_TILE_THREADS;
-constexpr unsigned kResThreads = ZIRA_TILE_RES_THREADS;   // threads of a resident accumulate block (one per CU)
-constexpr unsigned kResQ = ZIRA_RESQ;            // queries whose grad_out rows fit the LDS beside the tile (960 * 128 + 33 KB <= 160 KB)
 constexpr unsigned kPlanThreads = 1024;
-constexpr unsigned kClasses = 6;        // size classes of the deal, by block steps (32 records): > 8, 5-8, 3-4, 2, 1, none (empty tiles)
+constexpr unsigned kClasses = 8;        // size classes of the deal, by block steps (32 records): 17+, 13-16, 9-12, 5-8, 3-4, 2, 1, none (empty tiles)
 __host__ __device__ constexpr unsigned size_class(unsigned n)
 {
-    return n > 256 ? 0u : (n > 128 ? 1u : (n > 64 ? 2u : (n > 32 ? 3u : (n > 0 ? 4u : 5u))));
+    return n > 512 ? 0u : (n > 384 ? 1u : (n > 256 ? 2u : (n > 128 ? 3u : (n > 64 ? 4u : (n > 32 ? 5u : (n > 0 ? 6u : 7u))))));
 }
-constexpr unsigned kUcnt = 8;           // words a unit publishes: kClasses counts, its first item slot, spare
-constexpr unsigned kNoCell = 0xFFFFFFFFu, kOutside = 0xFFFFFFFEu, kNoRank = 0xFFFFFFFFu;
+constexpr unsigned kUcnt = 16;          // words a unit publishes: kClasses counts, its first item slot, spare
+constexpr unsigned kNoCell = 0xFFFFFFFFu, kNoRank = 0xFFFFFFFFu;
 constexpr unsigned kItemShare = 1u << 16;    // item flag: a share of a split tile (its sums go to a partial tile of the workspace)
-// record flags
-constexpr unsigned kFlHome = 1u, kFlXStep = 2u, kFlYStep = 4u, kFl00 = 8u, kFl01 = 16u, kFl10 = 32u, kFl11 = 64u, kFlLive = 128u;
-
 struct FastDivT {
     unsigned mul, shift, d;
 };
@@ -257,24 +252,11 @@ __device__ __forceinline__ void for_each_touched_tile(const Cell &c, const TLeve
     }
 }
 
-// The 32-byte record of a sample in one of the tiles it touches, everything resolved:
-//   a = {byte offset of the query's grad_out row from query 0 of the head,
-//        index of the sample in grad_attn_weight (x 2 in grad_sampling_loc) from query 0 of the head,
-//        byte offset of the clamped top-left pixel's value row from the level's pixel 0 (home records, else 0),
-//        LDS byte offsets of corner rows 00 | 01 << 16}
-//   b = {LDS byte offsets of corner rows 10 | 11 << 16, flags, lw, lh}
 struct Rec {
     uint4 a, b;
 };
-struct RecCtx {
-    unsigned rs4;    // bytes between pixels of a head: M * D * 4
-    unsigned mlp;    // M * L * P
-    unsigned lP;     // l * P
-    unsigned P;
-};
 // A record = one sample in one tile its 2 x 2 corner block touches: where the query's grad_out row is (byte offset of the
-// row in a [Q][32] float array: the accumulate kernel keeps the head's rows in LDS, or multiplies by M for the global
-// tensor), the attention weight, the LDS byte offsets of the four corner rows in the tile's accumulators (kTrash for a
+// row in a [Q][32] float array; times M in the global tensor), the attention weight, the LDS byte offsets of the four corner rows in the tile's accumulators (kTrash for a
 // corner outside the map or in another tile) and the bilinear fractions.  24 of 32 bytes.
 __device__ __forceinline__ Rec make_record(unsigned q, unsigned abits, unsigned cy, unsigned cx, unsigned lw, unsigned lh,
                                            const TLevel &Lv, unsigned ty, unsigned tx)
@@ -567,27 +549,6 @@ __global__ __launch_bounds__(256) void msda_bwd_fold(PlanGeom G, const unsigned 
 // ------------------------------------------------------------------------------------------
 // accumulate
 // ------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_addf(float x)
-{
-    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
-}
-// sum over the 8 consecutive lanes of a sample group; every lane gets the total
-__device__ __forceinline__ float group_sum8(float x)
-{
-    x = dpp_addf<0xB1>(x);    // quad_perm:[1,0,3,2]
-    x = dpp_addf<0x4E>(x);    // quad_perm:[2,3,0,1]
-    x = dpp_addf<0x141>(x);   // row_half_mirror
-    return x;
-}
-__device__ __forceinline__ float dot4f(float4 a, float4 b)
-{
-    float acc = a.x * b.x;
-    acc = fmaf(a.y, b.y, acc);
-    acc = fmaf(a.z, b.z, acc);
-    acc = fmaf(a.w, b.w, acc);
-    return acc;
-}
 __device__ __forceinline__ unsigned uni(unsigned x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // a work item: a tile or a share of a split tile; everything block-uniform (scalar registers)
@@ -607,12 +568,11 @@ __device__ __forceinline__ T ldg(const void *base, unsigned byte_off)   // scala
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// kRes: a block works for ONE head (b, m) and keeps that head's grad_out rows (Q x 128 bytes) in LDS beside the tile --
-// the step loop then has no load that depends on another load's result: records stream in (requested steps ahead), the
-// grad_out row comes out of LDS, the adds go to LDS.  (Round 4's first kernel gathered the row, the attention weight and the
-// four value rows of a record from global memory each step: a chain of two dependent L2 / HBM round trips per step, 1.3 us
-// per step with two steps in flight, which bounded the kernel whatever its LDS work.)  Otherwise (more queries than fit):
-// the row is gathered from global memory, requested a step ahead.
+// The step loop's only dependent load is the record's grad_out row (requested two steps ahead, the records four): the
+// attention weight rides in the record, the value rows are the gather blocks' business.  (Measured and dropped: a "resident"
+// form -- a block serves ONE head and keeps that head's 900 grad_out rows, 115 KB, in LDS beside the tile, so that no load of
+// the loop depends on another -- leaves room for one block per CU, and an item's header and first records are then a serial
+// latency chain nothing else on the CU hides: 39.4 us at 512 threads, 45.4 at 256, 40.8 at 1024, against 24.9 us for this form.)
 // The gather half of the backward (grad_sampling_loc, grad_attn_weight: a wave per (b, q, m), csrc/msda_fwd_lean.h) rides
 // in the same launch: blocks [0, nacc) accumulate -- three per CU --, the others take NTHR / 64 items each and pass through
 // the fourth slot of every CU while the accumulate blocks wait on their loads (two kernels one after the other: 9.2 + 24.9 us).
@@ -624,8 +584,8 @@ struct HomeArgs {
     float invP;
     FastDiv Mdiv, Qdiv;
 };
-template <bool kRes, unsigned NTHR>
-__global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_accum(
+template <unsigned NTHR>
+__global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_accum(
     const float *__restrict__ grad_out, PlanGeom G, const unsigned *__restrict__ ucnt, const uint4 *__restrict__ citems,
     const uint4 *__restrict__ recs, float *__restrict__ dump, float *__restrict__ partial, float *__restrict__ grad_value,
     const HomeArgs HA)
@@ -639,14 +599,14 @@ __global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_
     }
     constexpr unsigned D = 32, LPS = 8, NW = NTHR / 64, NG = 8;
     constexpr unsigned SPB = NW * NG;     // records per block step
-    extern __shared__ double lds_acc[];   // [(kNPix + 1) * D]: the tile, then the trash row; the deal's table; (kRes) the head's grad_out rows
+    extern __shared__ double lds_acc[];   // [(kNPix + 1) * D]: the tile, then the trash row; the deal's table
     double *acc = lds_acc;
 
     TSTAMP_DECL;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned grp = lane / LPS, j = lane % LPS;
-    // this block's list of items: group g = the heads it works for (kRes: one head; else the heads whose value slices an
-    // XCD keeps in its L2), k = its number inside the group
+    // this block's list of items: group g = the heads it works for (those whose value slices an XCD keeps in its L2;
+    // placement is for speed only), k = its number inside the group
     const unsigned g = blockIdx.x % G.ng, k = blockIdx.x / G.ng;
     // The units of the group (nug of them) publish their class counts; laid end to end -- class-major, so heavy items
     // first -- they form one ring, and block k takes positions k, k + nbg, ...
@@ -654,18 +614,11 @@ __global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_
     const unsigned h0 = g * G.hp;
     if (h0 >= G.heads) return;
     const unsigned nug = (G.heads - h0 < G.hp ? G.heads - h0 : G.hp) * G.L, ne = kClasses * nug;
-    float *rows = reinterpret_cast<float *>(tab + ((ne + nug + 1 + 3) & ~3u));   // (kRes) [Q][32]
     for (unsigned e = tid; e < ne; e += NTHR) {
         const unsigned c = e / nug, u = e - c * nug;
         tab[e] = ucnt[(h0 * G.L + u) * kUcnt + c];
     }
     for (unsigned u = tid; u < nug; u += NTHR) tab[ne + u] = ucnt[(h0 * G.L + u) * kUcnt + kClasses];
-    if (kRes) {   // the head's grad_out rows: row q at [q][32] (eight lanes a row; the rows are M * 128 bytes apart)
-        const unsigned b = fdiv(h0, G.Mdiv), m = h0 - b * G.M;
-        const float *src = grad_out + ((size_t)b * G.Q * G.M + m) * D;
-        for (unsigned x = tid; x < G.Q * 8u; x += NTHR)
-            reinterpret_cast<float4 *>(rows)[x] = *reinterpret_cast<const float4 *>(src + (size_t)(x >> 3) * G.M * D + (x & 7u) * 4u);
-    }
     __syncthreads();
     if (wave == 0) {   // exclusive prefix over the ne counts, 64 at a time
         unsigned run = 0;
@@ -683,8 +636,11 @@ __global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_
         if (lane == 0) tab[ne + nug] = run;
     }
     __syncthreads();
+    // The ring is dealt in rounds of nbg positions, every other round backwards (block k: position k of the even rounds,
+    // nbg - 1 - k of the odd ones): the block that drew the heaviest item of a round draws the lightest of the next.
     const unsigned total = uni(tab[ne + nug]);
-    const unsigned cnt = total > k ? fdiv(total - k - 1, G.NBGdiv) + 1 : 0u;
+    const unsigned full = fdiv(total, G.NBGdiv), rem = total - full * G.nbg;
+    const unsigned cnt = full + (((full & 1u) ? G.nbg - 1u - k : k) < rem ? 1u : 0u);
     if (cnt == 0) return;
     const unsigned pre_l = lane < ne ? tab[lane] : 0xFFFFFFFFu;   // (the common case: ne <= 64, the whole prefix in one wave's lanes)
     __syncthreads();   // (tab is read; below it is only touched again through load_hdr's reads)
@@ -704,7 +660,7 @@ __global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_
     for (unsigned kk = 0; kk < 4; ++kk) lbk[kk] = lb + (odd ? kAccWord[kk ^ kSwap] : kAccWord[kk]) * 8u;
 
     auto load_hdr = [&](unsigned i) {   // item i of this block: ring position k + i nbg -> (class, unit, position in the unit's class items)
-        const unsigned r = k + i * G.nbg;
+        const unsigned r = i * G.nbg + ((i & 1u) ? G.nbg - 1u - k : k);
         unsigned e;
         if (ne <= 64) {
             e = (unsigned)__popcll(__ballot(pre_l <= r)) - 1u;
@@ -755,7 +711,6 @@ __global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_
         return r;
     };
     auto row_of = [&](const Item &it, const Raw &r) {   // this lane's four channels of the record's grad_out row
-        if (kRes) return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rows) + r.a.x + j * 16u);
         return ldg<float4>(grad_out + (size_t)it.hq * D, r.a.x * G.M + j * 16u);
     };
     auto compute = [&](const Item &it, const Raw &r, const float4 g4, unsigned s) {
@@ -789,7 +744,7 @@ __global__ __launch_bounds__(NTHR, kRes ? 1 : ZIRA_TILE_SLOTS_PER_CU) void msda_
     Item it = make_item(load_hdr(0));
     Raw ra = fetch(it, 0), rb = fetch(it, 1), rc = fetch(it, 2), rd = fetch(it, 3);
     Item nx = make_item(h1);
-    __syncthreads();   // (the accumulators are clear, the rows are there)
+    __syncthreads();   // (the accumulators are clear)
     TSTAMP(0);
     for (unsigned i = 0;; ++i) {
         const bool more = i + 1 < cnt;
@@ -863,7 +818,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct TilesLayout {
     PlanGeom G;
     size_t ctl_bytes, off_usplit, off_citems, off_dump, off_recs, off_partial, total;
-    bool one_pass, resident;
+    bool one_pass;
     size_t lds_plan, lds_acc;
     unsigned units, grid;
 };
@@ -904,22 +859,13 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     G.ecap = (unsigned)(((unsigned long long)G.rcap * 2) / G.cap) + 1;   // sum of K over split tiles <= 2 records / cap
     G.iph = G.ntmax + G.L * G.ecap;
     if ((unsigned long long)T.units * G.rcap >= (1ull << 31)) return false;   // 32-bit record indices
-    // Accumulate blocks.  Resident form (the head's grad_out rows in LDS: Q <= kResQ): a group = one head, one block per CU,
-    // cus / heads blocks per head (at least one).  Otherwise: a group = the heads whose value slices one XCD keeps in its L2.
-    T.resident = (unsigned)Q <= kResQ;
-    if (T.resident) {
-        G.ng = G.heads;
-        G.hp = 1;
-        G.nbg = tiles_cu_count() / G.heads > 0 ? tiles_cu_count() / G.heads : 1u;
-        T.grid = G.ng * G.nbg;
-    } else {
-        G.ng = heads >= 8 ? 8u : 1u;
-        G.hp = G.ng > 1 ? (unsigned)((heads + 7) / 8) : G.heads;
-        T.grid = tiles_cu_count() * ZIRA_TILE_BLOCKS_PER_CU;
-        if (G.ng > 1) T.grid &= ~7u;
-        if (T.grid < G.ng) return false;
-        G.nbg = T.grid / G.ng;
-    }
+    // accumulate blocks: a group = the heads whose value slices one XCD keeps in its L2
+    G.ng = heads >= 8 ? 8u : 1u;
+    G.hp = G.ng > 1 ? (unsigned)((heads + 7) / 8) : G.heads;
+    T.grid = tiles_cu_count() * ZIRA_TILE_BLOCKS_PER_CU;
+    T.grid &= ~7u;
+    if (T.grid < 8 || T.grid < G.ng) return false;
+    G.nbg = T.grid / G.ng;
     if (heads * G.iph >= (1ull << 28)) return false;
     G.ccap = (unsigned)(heads * G.iph);
     if ((unsigned long long)G.hp * L * (kClasses + 1) + 1 > 1024) return false;   // (the deal's prefix table lives in LDS beside the tile)
@@ -927,8 +873,7 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     G.NBGdiv = make_fdiv(G.nbg);
     T.lds_plan = (kTLevelWords * kTMaxLevels + 16 + kPlanThreads / 64 + 1 + G.ntmax) * 4;
     if (T.lds_plan > 64 * 1024) return false;
-    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + (((size_t)G.hp * L * (kClasses + 1) + 1 + 3) & ~(size_t)3) * 4 +
-                (T.resident ? (size_t)Q * 128 : 0);
+    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + (((size_t)G.hp * L * (kClasses + 1) + 1 + 3) & ~(size_t)3) * 4;
     T.one_pass = (unsigned)Q <= kPlanThreads && P <= 4;
     size_t o = 0;
     T.ctl_bytes = align256((size_t)T.units * (kUcnt + 1) * 4);   // ucnt[units][kUcnt], scount[units]
@@ -1008,22 +953,9 @@ int tiles_backward_planned_f32(const float *grad_out, const float *value, const 
     HA.S = (unsigned)S; HA.LP = (unsigned)(L * P); HA.nitems = (unsigned)B * Q * M; HA.per_xcd = (HA.nitems + 7) >> 3;
     HA.nacc = T.grid; HA.invP = 1.0f / (float)P; HA.Mdiv = make_fast_div((unsigned)M); HA.Qdiv = make_fast_div((unsigned)Q);
     if (T.grid & 7u) return -1;   // (the gather blocks' XCD interleave starts at a multiple of 8)
-    if (T.resident) {
-        static bool attr_set = false;   // (one device per process)
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_tile_accum<true, kResThreads>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess)
-                return -1;
-            attr_set = true;
-        }
-        const unsigned wpb = kResThreads / 64;
-        hipLaunchKernelGGL((msda_bwd_tile_accum<true, kResThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kResThreads),
-                           T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
-    } else {
-        const unsigned wpb = kAccThreads / 64;
-        hipLaunchKernelGGL((msda_bwd_tile_accum<false, kAccThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kAccThreads),
-                           T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
-    }
+    const unsigned wpb = kAccThreads / 64;
+    hipLaunchKernelGGL((msda_bwd_tile_accum<kAccThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kAccThreads),
+                       T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(msda_bwd_fold, dim3(T.units * kFoldParts), dim3(256), 0, st, T.G, W.scount, W.usplit, W.partial, gv);
