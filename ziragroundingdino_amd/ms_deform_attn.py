@@ -37,7 +37,7 @@ class MultiScaleDeformableAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
-        # How the backward is cut into tiles depends on the sampling locations only: for sparse GPU calls (decoder
+        # How the backward is cut into tiles depends on the sampling locations (and its records carry the attention weights): for sparse GPU calls (decoder
         # cross-attention) that plan is made here, in the forward's own launch, off the backward's critical path.
         ctx.plan = None
         if any(ctx.needs_input_grad) and _C.plan_applies(value, value_spatial_shapes, value_level_start_index,
