@@ -21,7 +21,7 @@
 //          scan turns the histogram into record offsets.  Per tile a 32-byte WORK ITEM {first record, records, tile
 //          origin, level size, value row of the level's pixel 0, query 0 of the head, ...}; a tile with more than
 //          `cap` records is SPLIT into K = ceil(n / cap) items whose sums meet in a small fold launch behind the
-//          accumulate kernel.  Pass 2 writes one 32-byte RECORD per
+//          accumulate kernel.  Pass 2 writes one 16-byte RECORD per
 //          (sample, touched tile) with everything the accumulate kernel needs already resolved: where the query's
 //          grad_out row is, the attention weight, the LDS byte offsets of its four corner rows (a trash row for corners
 //          outside this tile), lw, lh.  A sample outside (-1, H) x (-1, W) has no record.
@@ -137,7 +137,7 @@ struct PlanPtrs {
     uint4 *usplit;      // [units * ecap]       {origin, H | W << 16, value row of pixel 0, first partial tile | shares << 24} of every split tile
     float *partial;     // [units * ecap][kNPix * 32]  sums of the shares of split tiles (written by the accumulate kernel)
     uint4 *citems;      // [kClasses][ccap][2]  items by size class, a unit's at its own slots
-    uint4 *recs;        // [units * rcap][2]    records, sorted by tile inside a unit
+    uint4 *recs;        // [units * rcap]       16-byte records, sorted by tile inside a unit
 };
 
 struct TLevel {
@@ -252,28 +252,19 @@ __device__ __forceinline__ void for_each_touched_tile(const Cell &c, const TLeve
     }
 }
 
-struct Rec {
-    uint4 a, b;
-};
-// A record = one sample in one tile its 2 x 2 corner block touches: where the query's grad_out row is (byte offset of the
-// row in a [Q][32] float array; times M in the global tensor), the attention weight, the LDS byte offsets of the four corner rows in the tile's accumulators (kTrash for a
-// corner outside the map or in another tile) and the bilinear fractions.  24 of 32 bytes.
-__device__ __forceinline__ Rec make_record(unsigned q, unsigned abits, unsigned cy, unsigned cx, unsigned lw, unsigned lh,
-                                           const TLevel &Lv, unsigned ty, unsigned tx)
+// A 16-byte record = one sample in one tile its 2 x 2 corner block touches:
+//   x = query (22 bits) | tile row of the top-left corner + 1 (5 bits) << 22 | its tile column + 1 (4 bits) << 27
+//       (corners are at rows r - 1, r and columns c - 1, c of the sample's cell; a corner outside the tile or the map goes
+//        to the tile's trash row: the accumulate block tests it against the tile's extent inside the map)
+//   y = attention weight,  z = lw,  w = lh   (the bilinear fractions)
+__device__ __forceinline__ uint4 make_record(unsigned q, unsigned abits, unsigned cy, unsigned cx, unsigned lw, unsigned lh,
+                                             unsigned ty, unsigned tx)
 {
-    const unsigned H = (unsigned)Lv.H, W = (unsigned)Lv.W, ty0 = ty * kTH, tx0 = tx * kTW;
-    unsigned o[4];
-#pragma unroll
-    for (unsigned cc = 0; cc < 4; ++cc) {
-        const unsigned y = cy - 1 + (cc >> 1), x = cx - 1 + (cc & 1);     // (unsigned: -1 wraps and fails the tests)
-        const bool in = y < H && x < W && (y - ty0) < kTH && (x - tx0) < kTW;
-        o[cc] = in ? ((y - ty0) * kTW + (x - tx0)) * kRowBytes : kTrash;
-    }
-    Rec r;
-    r.a = make_uint4(q * 128u, abits, o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-    r.b = make_uint4(lw, lh, 0u, 0u);
-    return r;
+    // tile-relative position of corner 00 is (cy - 1 - ty0, cx - 1 - tx0) in [-1, kTH) x [-1, kTW); stored + 1
+    const unsigned pr = cy - ty * kTH, pc = cx - tx * kTW;   // = (cy - 1 - ty0) + 1 etc., in [0, kTH] x [0, kTW]
+    return make_uint4(q | (pr << 22) | (pc << 27), abits, lw, lh);
 }
+static_assert(kTH <= 30 && kTW <= 14, "a corner's tile position is 5 + 4 bits of a record");
 
 struct ItemCtx {
     unsigned HW, vrow, hq, lP, unit;
@@ -405,14 +396,22 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
     TSTAMP(2);
 
     // pass 2: the records, tile by tile
-    uint4 *rc = W.recs + (size_t)rbase * 2;
+    uint4 *rc = W.recs + (size_t)rbase;
     if (kOnePass) {
         if (tid < G.Q) {
             const size_t abase = ((size_t)(b * G.Q + tid) * G.M + m) * G.LP + (size_t)l * G.P;
+            unsigned abv[4];
+            if (G.P == 4) {   // 16 contiguous, aligned bytes
+                const uint4 u = *reinterpret_cast<const uint4 *>(attn + abase);
+                abv[0] = u.x; abv[1] = u.y; abv[2] = u.z; abv[3] = u.w;
+            } else {
+#pragma unroll
+                for (unsigned p = 0; p < 4; ++p) abv[p] = p < G.P ? __float_as_uint(attn[abase + p]) : 0u;
+            }
 #pragma unroll
             for (unsigned p = 0; p < 4; ++p) {
                 if (cellv[p] == kNoCell) continue;
-                const unsigned ab = __float_as_uint(attn[abase + p]);
+                const unsigned ab = abv[p];
                 Cell c;
                 c.valid = true;
                 c.cy = (int)(cellv[p] >> 16);
@@ -420,10 +419,7 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                 unsigned i = 0;
                 for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool) {   // (the same order as in pass 1)
                     const unsigned rank = i == 0 ? trk[p][0] : (i == 1 ? trk[p][1] : (i == 2 ? trk[p][2] : trk[p][3]));
-                    const Rec r = make_record(tid, ab, (unsigned)c.cy, (unsigned)c.cx, lwv[p], lhv[p], Lv, ty, tx);
-                    const size_t o = (size_t)(hist[t] + rank) * 2;
-                    rc[o] = r.a;
-                    rc[o + 1] = r.b;
+                    rc[hist[t] + rank] = make_record(tid, ab, (unsigned)c.cy, (unsigned)c.cx, lwv[p], lhv[p], ty, tx);
                     ++i;
                 });
             }
@@ -437,10 +433,8 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                 if (c.valid) {
                     const unsigned ab = __float_as_uint(attn[base + p]);
                     for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool) {
-                        const size_t o = (size_t)atomicAdd(&hist[t], 1u) * 2;   // (the offsets become cursors)
-                        const Rec r = make_record(q, ab, (unsigned)c.cy, (unsigned)c.cx, __float_as_uint(c.lw), __float_as_uint(c.lh), Lv, ty, tx);
-                        rc[o] = r.a;
-                        rc[o + 1] = r.b;
+                        const size_t o = (size_t)atomicAdd(&hist[t], 1u);   // (the offsets become cursors)
+                        rc[o] = make_record(q, ab, (unsigned)c.cy, (unsigned)c.cx, __float_as_uint(c.lw), __float_as_uint(c.lh), ty, tx);
                     });
                 }
             }
@@ -692,31 +686,26 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
         it.W = hw >> 16;
         it.the = it.H - it.ty0 < kTH ? it.H - it.ty0 : kTH;   // rows / columns of the tile inside the map
         it.twe = it.W - it.tx0 < kTW ? it.W - it.tx0 : kTW;
-        it.roff = (size_t)off * 2;
+        it.roff = (size_t)off;
         it.voff = (size_t)vrow * D;
         return it;
     };
     // Every load of the item pipeline is issued unconditionally (clamped addresses): loads and stores share one in-order
     // counter on gfx950, and the compiler can only let a wave wait for exactly the load it needs when it knows how many
     // memory operations were issued after it.
-    struct Raw {
-        uint4 a, b;
-    };
+    typedef uint4 Raw;
     auto fetch = [&](const Item &it, unsigned s) {   // the record of this group at block step s
         const unsigned e = s * SPB + gsel;
-        const unsigned o = (e < it.n ? e : 0u) * 32u;   // (record 0 is readable for every item: the record region ends with a pad)
-        Raw r;
-        r.a = ldg<uint4>(recs + it.roff, o);
-        r.b = ldg<uint4>(recs + it.roff, o + 16u);
-        return r;
+        const unsigned o = (e < it.n ? e : 0u) * 16u;   // (record 0 is readable for every item: the record region ends with a pad)
+        return ldg<uint4>(recs + it.roff, o);
     };
     auto row_of = [&](const Item &it, const Raw &r) {   // this lane's four channels of the record's grad_out row
-        return ldg<float4>(grad_out + (size_t)it.hq * D, r.a.x * G.M + j * 16u);
+        return ldg<float4>(grad_out + (size_t)it.hq * D, (r.x & 0x3FFFFFu) * (G.M * 128u) + j * 16u);
     };
     auto compute = [&](const Item &it, const Raw &r, const float4 g4, unsigned s) {
         const bool ok = s * SPB + gsel < it.n;
-        const float lw = __uint_as_float(r.b.x), lh = __uint_as_float(r.b.y);
-        const float a = ok ? __uint_as_float(r.a.y) : 0.f;
+        const float lw = __uint_as_float(r.z), lh = __uint_as_float(r.w);
+        const float a = ok ? __uint_as_float(r.y) : 0.f;
         const float hh = 1.f - lh, hw = 1.f - lw;
         const float w00 = __fmul_rn(hh, hw), w01 = __fmul_rn(hh, lw), w10 = __fmul_rn(lh, hw), w11 = __fmul_rn(lh, lw);
         // corner rows: term = w * (a * g), both factors rounded to fp32 as the reference forms them (cuh:117-147), the
@@ -726,8 +715,14 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
         const double tt[4] = {(double)__fmul_rn(gs[0], a), (double)__fmul_rn(gs[1], a), (double)__fmul_rn(gs[2], a),
                               (double)__fmul_rn(gs[3], a)};
         const double wc[4] = {(double)w00, (double)w01, (double)w10, (double)w11};
-        const unsigned o01 = ok ? r.a.z : (kTrash | (kTrash << 16)), o23 = ok ? r.a.w : (kTrash | (kTrash << 16));
-        const unsigned oc[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
+        // corner rows of the tile's accumulators (unsigned: position -1 wraps and fails the tests; outside -> the trash row)
+        const unsigned pr = ((r.x >> 22) & 31u) - 1u, pc = (r.x >> 27) - 1u;
+        unsigned oc[4];
+#pragma unroll
+        for (unsigned cc = 0; cc < 4; ++cc) {
+            const unsigned y = pr + (cc >> 1), x = pc + (cc & 1u);
+            oc[cc] = (ok && y < it.the && x < it.twe) ? (y * kTW + x) * kRowBytes : kTrash;
+        }
 #pragma unroll
         for (unsigned cc = 0; cc < 4; ++cc) {
             char *ap = reinterpret_cast<char *>(acc) + oc[cc];
@@ -855,6 +850,7 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     if (G.ntmax > 4 * kPlanThreads) return false;      // (the plan kernel keeps a level's tile counts in registers across its scan)
     G.cap = ZIRA_TILE_CAP;
     if ((unsigned long long)Q * P * 4 >= (1ull << 24)) return false;
+    if ((unsigned)Q >= (1u << 22)) return false;       // (22 bits of a record)
     G.rcap = (unsigned)Q * P * 4;                       // a sample has a record in every tile it touches (<= 4)
     G.ecap = (unsigned)(((unsigned long long)G.rcap * 2) / G.cap) + 1;   // sum of K over split tiles <= 2 records / cap
     G.iph = G.ntmax + G.L * G.ecap;
@@ -881,7 +877,7 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     T.off_usplit = o; o += align256((size_t)T.units * G.ecap * 16);
     T.off_citems = o; o += align256((size_t)kClasses * G.ccap * 32);
     T.off_dump = o;   o += 2048;                                            // where redirected stores go (never read)
-    T.off_recs = o;   o += align256((size_t)T.units * G.rcap * 32) + 256;   // (+ pad: record 0 of an empty tail item)
+    T.off_recs = o;   o += align256((size_t)T.units * G.rcap * 16) + 256;   // (+ pad: record 0 of an empty tail item)
     if ((unsigned long long)T.units * G.ecap >= (1ull << 24)) return false;   // 24-bit partial-tile index
     T.off_partial = o; o += align256((size_t)T.units * G.ecap * kNPix * 32 * 4);   // (worst case; what is touched is one 16 KB tile per share)
     T.total = o;
