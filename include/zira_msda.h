@@ -73,7 +73,7 @@ int zira_msda_bwd_f32(const float *grad_out, const float *value, const int64_t *
  * see the planned entry points below): without a plan from the forward pass this call plans first, the workspace being
  * the plan buffer.  Other sparse calls keep the round-2 entry sort (per-block counting sort of corner contributions,
  * per-tile row sums).
- * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (87 MB at
+ * `zira_msda_bwd_workspace_bytes` returns the scratch size it needs for these dimensions (75 MB at
  * B=2,S=22223,M=8,D=32,L=4,Q=900,P=4 -- sized for the worst case, about a fifth is touched; 496 MB at Q=S), or 0 when
  * no workspace path applies (the plain entry point is then the only one).  The workspace is caller-owned DEVICE
  * memory, 16-byte aligned, needs no initialisation and may be reused by later calls on the same stream; with
@@ -100,14 +100,14 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
  *   zira_msda_plan_bytes      size of the plan buffer for these dimensions on the current device (0: no planned path;
  *                             use zira_msda_bwd_f32_ws)
  *   zira_msda_fwd_plan_f32    the forward AND the plan in ONE launch: the first 64 workgroups plan a (head, level) unit
- *                             each, the others run the gather (17 us for both at the north-star shape against 10.6 +
- *                             12.5 us apart: two kernels on two streams do not overlap on this stack, one grid does)
+ *                             each, the others run the gather (14.7 us for both at the north-star shape against 9.9 +
+ *                             9.8 us apart: two kernels on two streams do not overlap on this stack, one grid does)
  *   zira_msda_plan_f32        the plan alone: reads the level tables, sampling_loc and attn_weight
- *   zira_msda_bwd_planned_f32 the backward from a plan: a gather pass like the forward's for grad_sampling_loc /
- *                             grad_attn_weight (a wave per (b, q, m)), the accumulate kernel for grad_value -- with up to
- *                             960 queries a workgroup serves one head and keeps that head's grad_out rows in LDS, so that
- *                             no load of its inner loop depends on another -- and a small launch that adds up the partial
- *                             tiles of split tiles.  `plan` must come from zira_msda_*plan_f32 for the same dimensions,
+ *   zira_msda_bwd_planned_f32 the backward from a plan: ONE launch whose persistent workgroups sum grad_value tile by
+ *                             tile in LDS (the only load that depends on a record is the query's grad_out row) while
+ *                             forward-style waves -- one per (b, q, m) -- gather the value rows again and form
+ *                             grad_sampling_loc / grad_attn_weight, and a small launch that adds up the partial tiles of
+ *                             split tiles.  `plan` must come from zira_msda_*plan_f32 for the same dimensions,
  *                             level tables, sampling_loc AND attn_weight.  Same outputs / contract as
  *                             zira_msda_bwd_f32_ws; deterministic apart from the order of the LDS sums in double (no fp32
  *                             atomics anywhere).
