@@ -308,13 +308,16 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
 
     // pass 1: records per tile (a sample counts in every tile one of its corners falls into; a sample outside the
     // window has no record: its gradients are zero, and msda_bwd_home writes them)
-    unsigned cellv[4], lwv[4], lhv[4], trk[4][4];   // kOnePass: cell word, fractions, rank inside each touched tile
+    unsigned cellv[4], lwv[4], lhv[4];   // kOnePass: cell word, fractions
+    // ... and the rank inside each touched tile: 16 words per thread in LDS, word-major (no bank conflicts), so that the
+    // kernel fits 64 registers and the gather blocks of msda_fwd_plan get two blocks per CU
+    unsigned *trk = hist + G.ntmax + tid;   // trk[(p * 4 + i) * kPlanThreads]
     if (kOnePass) {
 #pragma unroll
         for (unsigned p = 0; p < 4; ++p) {
             cellv[p] = kNoCell;
 #pragma unroll
-            for (unsigned i = 0; i < 4; ++i) trk[p][i] = kNoRank;
+            for (unsigned i = 0; i < 4; ++i) trk[(p * 4 + i) * kPlanThreads] = kNoRank;
         }
     }
     for (unsigned q = tid; q < G.Q; q += kPlanThreads) {
@@ -342,7 +345,7 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                     for_each_touched_tile(c, Lv, [&](unsigned t, unsigned, unsigned, bool) {
                         const unsigned w = atomicAdd(&hist[t], 1u);   // rank inside the tile
                         // (the first call is the home tile; i is a compile-time constant after inlining)
-                        if (i == 0) trk[p][0] = w; else if (i == 1) trk[p][1] = w; else if (i == 2) trk[p][2] = w; else trk[p][3] = w;
+                        trk[(p * 4 + i) * kPlanThreads] = w;
                         ++i;
                     });
                 }
@@ -418,7 +421,7 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
                 c.cx = (int)(cellv[p] & 0xFFFFu);
                 unsigned i = 0;
                 for_each_touched_tile(c, Lv, [&](unsigned t, unsigned ty, unsigned tx, bool) {   // (the same order as in pass 1)
-                    const unsigned rank = i == 0 ? trk[p][0] : (i == 1 ? trk[p][1] : (i == 2 ? trk[p][2] : trk[p][3]));
+                    const unsigned rank = trk[(p * 4 + i) * kPlanThreads];
                     rc[hist[t] + rank] = make_record(tid, ab, (unsigned)c.cy, (unsigned)c.cx, lwv[p], lhv[p], ty, tx);
                     ++i;
                 });
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(kPlanThreads) void msda_plan(const int64_t *__restr
 // the forward's 64 registers (two-pass plan, 84 bytes of scratch per lane) was measured at 24.4 us for the call; with the
 // plan's 100 registers and one forward block per CU 19.0 us.
 #ifndef ZIRA_FUSED_WAVES
-#define ZIRA_FUSED_WAVES 4   // (no register cap below the one-pass plan's 100: spilling it costs 5 us)
+#define ZIRA_FUSED_WAVES 8   // (64 registers: two 1024-thread blocks per CU, i.e. the gather at the plain forward's occupancy)
 #endif
 #ifndef ZIRA_FUSED_ONEPASS
 #define ZIRA_FUSED_ONEPASS 1
@@ -867,8 +870,8 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     if ((unsigned long long)G.hp * L * (kClasses + 1) + 1 > 1024) return false;   // (the deal's prefix table lives in LDS beside the tile)
     G.Mdiv = make_fdiv((unsigned)M);
     G.NBGdiv = make_fdiv(G.nbg);
-    T.lds_plan = (kTLevelWords * kTMaxLevels + 16 + kPlanThreads / 64 + 1 + G.ntmax) * 4;
-    if (T.lds_plan > 64 * 1024) return false;
+    T.lds_plan = (kTLevelWords * kTMaxLevels + 16 + kPlanThreads / 64 + 1 + G.ntmax + 16 * kPlanThreads) * 4;
+    if (T.lds_plan > 78 * 1024) return false;   // (two blocks per CU)
     T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + (((size_t)G.hp * L * (kClasses + 1) + 1 + 3) & ~(size_t)3) * 4;
     T.one_pass = (unsigned)Q <= kPlanThreads && P <= 4;
     size_t o = 0;
