@@ -517,29 +517,30 @@ __global__ __launch_bounds__(kPlanThreads, ZIRA_FUSED_WAVES) void msda_fwd_plan(
 // the first round-4 version let the shares meet through fp32 atomics on pre-zeroed pixels: a share's 4096 atomics sit
 // in the same in-order memory queue as the next item's loads -- with 160-record shares the kernel took 46 instead of 28 us.)
 // kFoldParts blocks per unit.
-constexpr unsigned kFoldParts = 4;
+constexpr unsigned kFoldParts = kNPix * 8 / 256;   // blocks per unit: a thread takes ONE float4 of every split tile of the unit
 __global__ __launch_bounds__(256) void msda_bwd_fold(PlanGeom G, const unsigned *__restrict__ scount, const uint4 *__restrict__ usplit,
                                                      const float *__restrict__ partial, float *__restrict__ grad_value)
 {
     constexpr unsigned D = 32;
     const unsigned unit = blockIdx.x / kFoldParts, part = blockIdx.x % kFoldParts;
+    // (the first entry is requested together with the count: the kernel is nothing but round trips)
+    const uint4 e0 = usplit[(size_t)unit * G.ecap];
     const unsigned ns = scount[unit] < G.ecap ? scount[unit] : G.ecap;
-    for (unsigned s = part; s < ns; s += kFoldParts) {
-        const uint4 e = usplit[(size_t)unit * G.ecap + s];
+    const unsigned i = part * 256 + threadIdx.x;              // this thread's float4 of a tile
+    const unsigned c4 = i % (D / 4), pix = i / (D / 4);
+    for (unsigned s = 0; s < ns; ++s) {
+        const uint4 e = s == 0 ? e0 : usplit[(size_t)unit * G.ecap + s];
         const unsigned ty0 = e.x & 0xFFFFu, tx0 = e.x >> 16, H = e.y & 0xFFFFu, Wd = e.y >> 16;
         const unsigned slot = e.w & 0xFFFFFFu, K = e.w >> 24;
-        const float4 *src = reinterpret_cast<const float4 *>(partial + (size_t)slot * kNPix * D);
-        for (unsigned i = threadIdx.x; i < kNPix * (D / 4); i += 256) {
-            float4 a = src[i];
-            for (unsigned k = 1; k < K; ++k) {
-                const float4 b = src[(size_t)k * kNPix * (D / 4) + i];
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            }
-            const unsigned c4 = i % (D / 4), pix = i / (D / 4);
-            const unsigned y = ty0 + pix / kTW, x = tx0 + pix % kTW;
-            if (y < H && x < Wd)
-                *reinterpret_cast<float4 *>(grad_value + ((size_t)e.z + (size_t)(y * Wd + x) * G.M) * D + c4 * 4) = a;
+        const float4 *src = reinterpret_cast<const float4 *>(partial + (size_t)slot * kNPix * D) + i;
+        float4 a = src[0];
+        for (unsigned k = 1; k < K; ++k) {   // (fixed order: the same sum in every run)
+            const float4 b = src[(size_t)k * kNPix * (D / 4)];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
+        const unsigned y = ty0 + pix / kTW, x = tx0 + pix % kTW;
+        if (y < H && x < Wd)
+            *reinterpret_cast<float4 *>(grad_value + ((size_t)e.z + (size_t)(y * Wd + x) * G.M) * D + c4 * 4) = a;
     }
 }
 
