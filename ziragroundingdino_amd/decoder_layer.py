@@ -72,7 +72,8 @@ class LayerWeights:
                 "out_t": ms.output_proj.weight.t(),
             }
             new["samp_t"] = new["samp_w"].t()
-            if self.key is None:
+            dev = sa.in_proj_weight.device
+            if self.key is None or self.sa_in_t.device != dev:   # first use, or the layer moved (model.to(...))
                 for k, v in new.items():
                     setattr(self, k, v.contiguous().clone())
             else:   # in place: captured graphs read these buffers
@@ -298,7 +299,7 @@ class MLPWeights:
         if key == self.key:
             return
         with torch.no_grad():
-            if self.key is None:
+            if self.key is None or self.w0_t.device != l0.weight.device:   # first use, or the module moved
                 self.w0_t, self.w1_t = l0.weight.t().contiguous().clone(), l1.weight.t().contiguous().clone()
             else:   # in place: captured graphs read these buffers
                 self.w0_t.copy_(l0.weight.t())
