@@ -219,7 +219,7 @@ class _FrozenDecoderLayer(torch.autograd.Function):
             # ---- FFN ----  (LayerNorm gradient, product with W2 and the ReLU gradient in one launch)
             gh, ds4 = rowgemm(g, layer.linear2.weight, w_is_nk=False, mask=h, lnb=(s4, layer.norm3.weight, stats4[0], stats4[1]),
                               lnb_save=True)
-            g3 = torch.addmm(ds4, gh, layer.linear1.weight)
+            g3 = ds4.addmm_(gh, layer.linear1.weight)   # (in place: ds4 is this node's)
             # ---- MSDA cross-attention ----
             go3, ds3 = rowgemm(g3, ms.output_proj.weight, w_is_nk=False, lnb=(s3, layer.norm1.weight, m3, r3), lnb_save=True,
                                batch=B, c_batch_first=True)

@@ -8,7 +8,7 @@ the 45 MB tensor.  ``_SharedSourceProjections`` already lets the second projecti
 here the residual path joins as well: the LayerNorm input gradient ``gs`` is the addend (beta = 1) of the first product,
 
     gs = LNbwd(g);  go = gs Wo;  gv, gloc, gattn = MSDA'(go);  gproj = sampling'(gloc, gattn)
-    gsrc = gs + gv Wv + gproj Wq            (addmm with gs as its addend, then addmm_)
+    gsrc = gs + gv Wv + gproj Wq            (addmm_ into gs, twice)
 
 The forward is the module's own sequence of launches (two projections, sampling locations + softmax, the MSDA op, output
 projection, residual add + LayerNorm in one kernel).  fp32 GPU calls without padding mask only; otherwise the modules run."""
@@ -112,7 +112,8 @@ class _FrozenEncoderAttention(torch.autograd.Function):
             if rc != 0:
                 raise RuntimeError("zira_msda_sampling_bwd_f32 failed with code %d" % rc)
             # the three gradients of src meet in the GEMMs: residual path as the addend, then the two projections
-            gx = torch.addmm(gs2, gv.view(rows, C), ms.value_proj.weight)
+            # (in place: torch.addmm(x, ...) would first COPY x into its result -- a pass of its own; gs is this node's)
+            gx = gs2.addmm_(gv.view(rows, C), ms.value_proj.weight)
             gx.addmm_(gproj, wq)
         return None, gx.view(B, S, C), None, None, None, None
 

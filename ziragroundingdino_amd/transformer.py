@@ -255,7 +255,7 @@ class _FrozenFFNNorm(torch.autograd.Function):
                 rc = lib.zira_gemm_drelu_f32(gs.data_ptr(), w2.data_ptr(), h.data_ptr(), rows, h.shape[1], C, g.data_ptr(), st)
         if rc != 0:
             raise RuntimeError("frozen FFN + LayerNorm backward failed with code %d" % rc)
-        return (torch.addmm(gs, g, w1),) + (None,) * 7
+        return (gs.addmm_(g, w1),) + (None,) * 7   # (in place: torch.addmm(gs, ...) copies gs into its result first)
 
 
 def _frozen_ffn_norm_ok(x, lin1, lin2, norm):
