@@ -72,3 +72,36 @@ def test_level_tables_are_checked():
     with pytest.raises(AssertionError, match="cover"):
         mod(query=g["query"], value=g["value"][:, :-1], reference_points=g["reference_points"],
             spatial_shapes=g["spatial_shapes"], level_start_index=g["level_start_index"])
+
+
+def test_native_nodes_decline_cpu_tensors():
+    """The one-node forms of the decoder layer, the decoder glue and the encoder attention sublayer are GPU paths; on CPU
+    tensors their ``applies()`` says no and the module composition runs (same outputs as the reference's modules)."""
+    import types
+
+    import torch
+
+    from ziragroundingdino_amd import decoder_layer, encoder_layer, transformer
+    from ziragroundingdino_amd.dense import LayerNorm
+    from ziragroundingdino_amd.utils import MLP
+
+    torch.manual_seed(0)
+    dec = transformer.DeformableTransformerDecoderLayer(256, 2048, 0.0, "relu", 4, 8, 4, use_text_cross_attention=True)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    tgt, pos = torch.randn(5, 2, 256), torch.randn(5, 2, 256)
+    ref, text, value = torch.rand(5, 2, 4, 4), torch.randn(2, 3, 256), torch.randn(2, 30, 256)
+    assert not decoder_layer.applies(dec, tgt, pos, ref, text, value, None, None)
+    glue = types.SimpleNamespace(bbox_embed=torch.nn.ModuleList([MLP(256, 256, 4, 3)]), norm=LayerNorm(256),
+                                 ref_point_head=MLP(512, 256, 256, 2), query_scale=None, query_pos_sine_scale=None)
+    for m in (glue.bbox_embed, glue.norm, glue.ref_point_head):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    assert not decoder_layer.refine_applies(glue, 0, tgt, torch.rand(5, 2, 4))
+    assert not decoder_layer.prep_applies(glue, torch.rand(5, 2, 4), torch.ones(2, 4, 2))
+    enc = transformer.DeformableTransformerEncoderLayer(256, 1024, 0.0, "relu", 4, 8, 4)
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    src = torch.randn(2, 30, 256)
+    shapes = torch.tensor([[4, 5], [2, 3], [1, 2], [1, 2]])
+    assert not encoder_layer.applies(enc, src, torch.randn(2, 30, 256), torch.rand(2, 30, 4, 2), shapes, None)
