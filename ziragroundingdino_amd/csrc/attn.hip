@@ -23,6 +23,12 @@
 // one block per key tile for dK and dV; the four waves split the other dimension and add their partial tiles in
 // LDS.  No atomics, no workspace beyond lse and delta ([B, H, L] floats each).
 //
+// Where the time goes (self-attention of 900 queries, 2 images x 8 heads: 464 blocks, two per CU on most CUs): the products
+// alone are 13 / 20 / 26 us of MFMA issue (forward / dQ / dK+dV at 64 flop per cycle and SIMD) against 34.6 / 42.9 / 55.8 us
+// measured -- 38-47 % of the fp32 MFMA rate.  Requesting the next tile's operands a round ahead (register double buffer) was
+// measured and dropped: 33.5 / 47.0 / 74.0 us -- the dK+dV kernel then needs 288 registers, one wave per SIMD, and the CU's
+// second block no longer runs beside the first, which is what had been hiding the loads.
+//
 // Layouts: q / k / v element (l, b, h, c) at ptr[(l * B + b) * ld + h * 32 + c] (ld = row stride in floats: the
 // projections' outputs and slices of fused projections are used as they are); out, dq, dk, dv contiguous [L|S, B, H*32].
 // `kpm`: optional additive key mask [B, S] (0 or -inf).  A query whose keys are all masked gets a zero row.
