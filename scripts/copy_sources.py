@@ -32,7 +32,7 @@ for e in prof.events():
     n = 1
     for d in e.input_shapes[0]:
         n *= d
-    if n < BIG // 8:
+    if n < int(os.environ.get("MIN_ELEMS", BIG // 8)):
         continue
     chain, p = [], e.cpu_parent
     while p is not None and len(chain) < 6:
@@ -44,5 +44,6 @@ for e in prof.events():
     a[0] += 1
     a[1] += t
 print("large aten::copy_ calls of one eager step (shape, enclosing ops):")
-for (sh, ch), (n, t) in sorted(seen.items(), key=lambda kv: -kv[1][1]):
+print("total %.1f us in %d calls" % (sum(v[1] for v in seen.values()), sum(v[0] for v in seen.values())))
+for (sh, ch), (n, t) in sorted(seen.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOP", 60))]:
     print("%8.1f us x%-3d %-24s %s" % (t, n, sh, ch))

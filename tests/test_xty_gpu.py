@@ -17,7 +17,10 @@ def _rel(a, b):
 @pytest.mark.parametrize("B,N,a,b,xt", [(2, 22223, 64, 256, False), (2, 22223, 64, 256, True),
                                         (2, 22223, 256, 64, False), (1, 5000, 36, 256, True),
                                         (3, 4097, 200, 132, False), (2, 2500, 4, 8, True),
-                                        (2, 3000, 320, 260, False)])
+                                        (2, 3000, 320, 260, False),
+                                        # the fusion block's shapes at 4 heads x 32 tokens: the 16-byte-load form (xty_rows128)
+                                        (2, 22223, 128, 256, False), (2, 22223, 256, 128, False), (1, 4096, 128, 256, False),
+                                        (3, 4101, 256, 128, False), (1, 8191, 128, 256, False)])
 def test_xty_matches_float64(B, N, a, b, xt):
     g = torch.Generator().manual_seed(N + a + b)
     X = torch.randn((B, a, N) if xt else (B, N, a), generator=g).to(DEV)

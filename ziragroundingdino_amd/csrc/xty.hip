@@ -13,6 +13,7 @@
 // folds them in a fixed order (deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 
 #include "zira_msda.h"
 
@@ -189,6 +190,138 @@ __global__ __launch_bounds__(kThreads) void xty_partial(const float *__restrict_
         }
 }
 
+// The fusion block's own three products at 4 heads x 32 text tokens -- 128 x 256 (twice) and 256 x 128 outputs -- in a form
+// whose loads are 16 / 8 bytes per lane.  xty_partial issues one 4-byte load per lane and MFMA operand (256 bytes per
+// instruction); the CU's texture addresser takes 16 cycles per wave instruction whatever its width, so that for these two
+// block-per-CU shapes the addresser was as busy as the MFMA pipe (512 cycles each per row pair) and the kernel ran at
+// 40 % of the fp32 MFMA rate (54 us; this form: 36 us).  Here the 128-wide operand is read as one float4 per lane -- lane c holds columns
+// 4 c .. 4 c + 3, which feed four MFMA blocks whose row (column) number c stands for column 4 c + q -- and a 64-column
+// slice of the 256-wide operand as one float2 per lane: 2 load instructions per 8 MFMAs.  A block owns a 128 x 64
+// (64 x 128 with SWAP) slice of the output for 1 / 32 of the rows; its four waves take every fourth row pair and add
+// their tiles through LDS in a fixed order, so a block writes one partial tile (8 MB of partials instead of 34).
+template <bool SWAP>
+__global__ __launch_bounds__(kThreads) void xty_rows128(const float *__restrict__ X, const float *__restrict__ Y, int N,
+                                                        int chunk_rows, float *__restrict__ part)
+{
+    constexpr int a = SWAP ? 256 : 128, b = SWAP ? 128 : 256;
+    constexpr int IA = SWAP ? 2 : 4, JB = SWAP ? 4 : 2;     // MFMA blocks per wave along a / b = floats per lane and load
+    constexpr int RT = SWAP ? 64 : 128, CT = SWAP ? 128 : 64;
+    constexpr int kU = 8;                                     // row pairs per batch of loads
+    extern __shared__ float tile[];   // [4 waves][RT][CT]: 128 KB
+    const int chunk = blockIdx.x, chunks = gridDim.x, cb = blockIdx.y, z = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane >> 5, c = lane & 31;
+    const float *Xz = X + (size_t)z * N * a + (SWAP ? cb * 64 : 0) + IA * c;
+    const float *Yz = Y + (size_t)z * N * b + (SWAP ? 0 : cb * 64) + JB * c;
+    const int n_begin = chunk * chunk_rows;
+    const int n_end = (n_begin + chunk_rows < N) ? n_begin + chunk_rows : N;
+    const int nsteps = n_end > n_begin ? (n_end - n_begin + 7) / 8 : 0;   // a step = 8 rows: a pair per wave
+
+    v16f acc[IA][JB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Batch {
+        float xa[kU][IA];
+        float yb[kU][JB];
+    };
+    auto load_x = [&](const float *p, float (&x)[IA]) {
+        if (IA == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            x[0] = v.x; x[1] = v.y; x[IA - 2] = v.z; x[IA - 1] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(p);
+            x[0] = v.x; x[1] = v.y;
+        }
+    };
+    auto load_y = [&](const float *p, float (&y)[JB]) {
+        if (JB == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            y[0] = v.x; y[1] = v.y; y[JB - 2] = v.z; y[JB - 1] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(p);
+            y[0] = v.x; y[1] = v.y;
+        }
+    };
+    // Loads never depend on where the chunk ends (row numbers clamped into the matrix, no branch): the rows past the end are
+    // cleared when they are multiplied.  (Cleared right after the load, every tail batch waited for ALL loads in flight.)
+    auto fetch = [&](Batch &t, int s0) {   // steps s0 .. s0 + kU - 1
+        const int n0 = n_begin + 8 * s0 + 2 * wave + k;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int n = n0 + 8 * u;
+            const size_t nc = (size_t)(n < N ? n : N - 1);
+            load_x(Xz + nc * a, t.xa[u]);
+            load_y(Yz + nc * b, t.yb[u]);
+        }
+    };
+    auto multiply = [&](const Batch &t, int s0) {   // (one form for every batch: a branch here and the compiler re-rolls the ring)
+        const int n0 = n_begin + 8 * s0 + 2 * wave + k;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            float xa[IA], yb[JB];
+            const unsigned m = n0 + 8 * u < n_end ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) xa[i] = __uint_as_float(__float_as_uint(t.xa[u][i]) & m);
+#pragma unroll
+            for (int j = 0; j < JB; ++j) yb[j] = __uint_as_float(__float_as_uint(t.yb[u][j]) & m);
+#pragma unroll
+            for (int i = 0; i < IA; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // two batches alternate: one is on its way while the other one is multiplied (one wave per SIMD: nothing else hides the
+    // loads).  A ring of three measured the same (38.2 / 36.5 us against 37.2 / 35.3): the loads are hidden, what is left above
+    // the 24 us of MFMA issue (12 batches x 64 x 64 cycles) is the launch, the first batch, the LDS exchange and the tile's store.
+    const int nb = (nsteps + kU - 1) / kU;
+    Batch ping, pong;
+    fetch(ping, 0);
+    for (int bi = 0; bi < nb; bi += 2) {
+        fetch(pong, (bi + 1) * kU);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(ping, bi * kU);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(ping, (bi + 2) * kU);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(pong, (bi + 1) * kU);   // (unconditional: under `if` the compiler sinks pong's loads into the branch, next to their uses)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the four waves' tiles side by side in LDS, added in wave order on the way out; register r of lane l is the element
+    // (8 (r / 4) + 4 k + r % 4, c) of its 32 x 32 block, and number n of block q along a stands for column IA n + q (JB n + q along b)
+    {
+        float *mine = tile + wave * (RT * CT);
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = IA * (8 * (r / 4) + 4 * k + (r % 4)) + i;
+                float *dst = mine + row * CT + JB * c;
+                if (JB == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][JB - 2][r], acc[i][JB - 1][r]);
+                else *reinterpret_cast<float2 *>(dst) = make_float2(acc[i][0][r], acc[i][1][r]);
+            }
+    }
+    __syncthreads();
+    float *pz = part + ((size_t)z * chunks + chunk) * a * b + (SWAP ? (size_t)cb * 64 * b : (size_t)cb * 64);
+#pragma unroll
+    for (int t = 0; t < RT * CT / 4 / kThreads; ++t) {
+        const int idx = threadIdx.x + t * kThreads, row = idx / (CT / 4), c4 = idx % (CT / 4);
+        const float *src = tile + row * CT + c4 * 4;
+        float4 o = *reinterpret_cast<const float4 *>(src);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + w * (RT * CT));
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(pz + (size_t)row * b + c4 * 4) = o;
+    }
+}
+constexpr size_t kRowsLds = 4 * 128 * 64 * sizeof(float);
+constexpr int kRowsChunks = 32;   // 32 chunks x 4 slices x 2 images = one block per CU at the bench shape
+
 // out = sum over chunks of the partial tiles.  A block folds 16 float4 of the output: 16 chunk
 // groups (thread / 16) each add every 16th partial, LDS joins them in a fixed order.
 __global__ __launch_bounds__(kThreads) void xty_fold(const float *__restrict__ part, int chunks,
@@ -242,6 +375,22 @@ int zira_xty_f32(const float *X, const float *Y, int B, int N, int a, int b, int
     if (!X || !Y || !out || !workspace || B <= 0 || N <= 0 || a <= 0 || b <= 0 || (a & 3) || (b & 3))
         return ZIRA_MSDA_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t tile = (size_t)a * b, total4 = (size_t)B * tile / 4;
+    if (!x_transposed && N >= 128 * kRowsChunks && ((a == 128 && b == 256) || (a == 256 && b == 128)) &&
+        !(((uintptr_t)X | (uintptr_t)Y | (uintptr_t)workspace) & 15)) {
+        // (xty_chunks(N) = 128 here: the workspace the caller sized covers the 32 chunks)
+        const int chunk_rows = (((N + kRowsChunks - 1) / kRowsChunks) + 7) & ~7;
+        const dim3 grid(kRowsChunks, 4, B);
+        const void *fn = a == 128 ? reinterpret_cast<const void *>(&xty_rows128<false>) : reinterpret_cast<const void *>(&xty_rows128<true>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLds) != hipSuccess) return ZIRA_MSDA_EINVAL;
+        if (a == 128) hipLaunchKernelGGL((xty_rows128<false>), grid, dim3(kThreads), kRowsLds, st, X, Y, N, chunk_rows, workspace);
+        else hipLaunchKernelGGL((xty_rows128<true>), grid, dim3(kThreads), kRowsLds, st, X, Y, N, chunk_rows, workspace);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(xty_fold, dim3((unsigned)((total4 + 15) / 16)), dim3(kThreads), 0, st, workspace, kRowsChunks, tile,
+                           total4, out);
+        return (int)hipGetLastError();
+    }
     const int chunks = xty_chunks(N);
     const int chunk_rows = (N + chunks - 1) / chunks;
     if (a <= b) {  // wide tile along b
@@ -265,7 +414,6 @@ int zira_xty_f32(const float *X, const float *Y, int B, int N, int a, int b, int
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const size_t tile = (size_t)a * b, total4 = (size_t)B * tile / 4;
     hipLaunchKernelGGL(xty_fold, dim3((unsigned)((total4 + 15) / 16)), dim3(kThreads), 0, st,
                        workspace, chunks, tile, total4, out);
     return (int)hipGetLastError();
