@@ -80,7 +80,7 @@ def conv_module_as_gemm(conv: torch.nn.Conv2d, x):
 # Tall-reduction products (csrc/xty.hip): out[z] = X[z]^T @ Y[z] with a reduction over tens of
 # thousands of image tokens and a small output -- the shape BiMultiHeadAttention's re-bracketed
 # image side produces (transformer.py).  rocBLAS gives them one or two tiles (109 / 85 us at
-# N = 22223, 64 x 256); the split-reduction kernel takes ~15 us.
+# N = 22223, 64 x 256); the split-reduction kernel takes ~15 us (128 x 256 / 256 x 128, the bench's shapes: 36 us, xty_rows128).
 # ---------------------------------------------------------------------------------------------
 _XTY_WS = {}
 
