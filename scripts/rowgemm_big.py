@@ -55,3 +55,31 @@ timeit(lambda: rowgemm(x384, w[384], w_is_nk=False, res=res), "rowgemm res K=384
 timeit(lambda: res.clone().addmm_(x384, w[384]), "lib clone + addmm_ K=384")
 timeit(lambda: rowgemm(x, wt[256], w_is_nk=False, lnb=(x, gam, mean, rstd), lnb_save=True), "rowgemm LNbwd + dgrad N=256")
 timeit(lambda: x.clone(), "clone (for scale)")
+# the fusion block's image-side output: v_n + gamma * (P R + b) per image, K = H * T = 128
+M1 = 22223
+P = torch.rand(2, M1, 128, device=dev)
+R = torch.randn(2, 128, 256, device=dev) / 11
+vn = torch.randn(2, M1, 256, device=dev)
+gamma = torch.rand(256, device=dev)
+bo = torch.randn(256, device=dev)
+
+
+def lib_path():
+    d = torch.empty_like(vn)
+    for i in range(2):
+        torch.addmm(bo, P[i], R[i], out=d[i])
+    return torch.addcmul(vn, d, gamma)
+
+
+def fused_path():
+    Rs = R * gamma
+    bs = bo * gamma
+    out = torch.empty_like(vn)
+    for i in range(2):
+        rowgemm(P[i], Rs[i], w_is_nk=False, bias=bs, res=vn[i], out=out[i])
+    return out
+
+
+print("max diff", (lib_path() - fused_path()).abs().max().item())
+timeit(lib_path, "fusion out_v: 2 addmm + addcmul")
+timeit(fused_path, "fusion out_v: 2 rowgemm (gamma folded, res)")

@@ -84,3 +84,42 @@ def test_fused_bi_softmax_matches_unfused_attention(T, with_masks):
     for n, a, b in zip(names, res[True], res[False]):
         err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
         assert err < 1e-4, (n, err)    # fp32 re-association over ~3000-term sums
+
+
+@pytest.mark.parametrize("drop_path", [0.0, 0.4])
+def test_fusion_block_residual_in_gemm_matches_addcmul(drop_path):
+    """v + drop_path(gamma_v * delta_v) inside the attention's last GEMM (dense._WideMatmulResidual: layer scale folded into
+    the small operands, residual rows added by the row-GEMM epilogue) against the addcmul pass behind the GEMM: same RNG
+    draws, values and gradients to fp32 re-association."""
+    from ziragroundingdino_amd import transformer
+    torch.manual_seed(0)
+    blk = transformer.BiAttentionBlock(v_dim=256, l_dim=256, embed_dim=1024, num_heads=4, dropout=0.0, drop_path=drop_path,
+                                       init_values=0.2).to(DEV).train()
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    v = torch.randn(2, 5003, 256, device=DEV, requires_grad=True)
+    l = torch.randn(2, 32, 256, device=DEV, requires_grad=True)
+    mask_l = torch.zeros(2, 32, dtype=torch.bool, device=DEV)
+    mask_l[1, 29:] = True
+    gv, gl = torch.randn_like(v), torch.randn_like(l)
+    res = {}
+    calls = []
+    real = dense._WideMatmulResidual.forward
+
+    def spy(ctx, *a):
+        calls.append(1)
+        return real(ctx, *a)
+
+    dense._WideMatmulResidual.forward = staticmethod(spy)
+    try:
+        for flag in (True, False):
+            transformer.BiAttentionBlock.residual_in_gemm = flag
+            torch.manual_seed(11)
+            ov, ol = blk(v, l, attention_mask_v=None, attention_mask_l=mask_l)
+            res[flag] = (ov.detach(), ol.detach()) + torch.autograd.grad([ov, ol], [v, l], [gv, gl])
+    finally:
+        transformer.BiAttentionBlock.residual_in_gemm = True
+        dense._WideMatmulResidual.forward = staticmethod(real)
+    assert len(calls) == 1                                   # the GEMM form ran, and only when switched on
+    for a, b in zip(res[True], res[False]):
+        assert _rel(a, b.double()) < 2e-6

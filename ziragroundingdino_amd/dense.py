@@ -9,6 +9,7 @@ anything else -> im2col (F.unfold) + GEMM.  Same results as F.conv2d up to fp32 
 order; gradients come from autograd of the matmuls (weight gradients are GEMMs as well).
 """
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn.functional as F
 
 
@@ -175,6 +176,57 @@ def tall_reduce(P, V):
 def wide_matmul(L, R, bias=None):
     """(bias +) L [B, N, k] @ R [B, k, m] with autograd; see ``_WideMatmul``."""
     return _WideMatmul.apply(L, R, bias)
+
+
+class _WideMatmulResidual(torch.autograd.Function):
+    """res + scale * (L @ R + bias): the image-side output of the fusion block with its layer-scale residual
+    (reference fuse_modules.py:300-303: ``v + drop_path(gamma_v * delta_v)``) as one row-GEMM launch per image.
+
+    ``scale`` ([m] or [B, 1, m]: the layer scale, times the per-sample stochastic-depth factor) is constant here
+    (frozen), so it is folded into the SMALL operands -- R [B, k, m] and the bias -- and the GEMM's epilogue adds the
+    residual rows: no [B, N, m] product in memory, no scale pass over it in the forward (2 addmm + addcmul 91 us ->
+    64 us at N = 22223, k = 128) and none over its gradient in the backward (the incoming gradient IS the scaled
+    product's; only the small dR is scaled back)."""
+
+    @staticmethod
+    def forward(ctx, L, R, bias, res, scale):
+        from .rowgemm import rowgemm
+        B = L.shape[0]
+        sc = scale if scale.dim() == 3 else scale.view(1, 1, -1)
+        Rs = (R * sc).contiguous()                                    # [B, k, m]
+        bs = (bias.view(1, -1) * sc.reshape(-1, sc.shape[-1])).expand(B, -1).contiguous()   # [B, m]
+        L, res = L.contiguous(), res.contiguous()
+        out = torch.empty_like(res)
+        for i in range(B):
+            rowgemm(L[i], Rs[i], w_is_nk=False, bias=bs[i], res=res[i], out=out[i])
+        ctx.save_for_backward(L, Rs, sc)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        L, Rs, sc = ctx.saved_tensors
+        g = g.contiguous()
+        gL = torch.bmm(g, Rs.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gR = xty(L, g) * sc if ctx.needs_input_grad[1] else None
+        gb = (g * sc).sum((0, 1)) if ctx.needs_input_grad[2] else None
+        return gL, gR, gb, (g if ctx.needs_input_grad[3] else None), None
+
+
+def wide_matmul_residual_supported(L, R, bias, res, scale) -> bool:
+    from . import rowgemm as rg
+    if not (L.is_cuda and L.dim() == 3 and R.dim() == 3 and res.dim() == 3 and bias is not None and bias.dim() == 1):
+        return False
+    if any(t.dtype != torch.float32 for t in (L, R, bias, res, scale)) or torch.is_autocast_enabled("cuda"):
+        return False
+    if scale.requires_grad or L.shape[0] > 4 or res.shape != (L.shape[0], L.shape[1], R.shape[2]):
+        return False
+    return rg.supported(L.shape[1], R.shape[2], L.shape[2])
+
+
+def wide_matmul_residual(L, R, bias, res, scale):
+    """res + scale * (L [B, N, k] @ R [B, k, m] + bias) with autograd; call only when ``wide_matmul_residual_supported``."""
+    return _WideMatmulResidual.apply(L, R, bias, res, scale)
 
 
 class _TallReduceNT(torch.autograd.Function):

@@ -21,7 +21,8 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .dense import LayerNorm, bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul
+from .dense import (LayerNorm, bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul, wide_matmul_residual,
+                    wide_matmul_residual_supported)
 from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
 from .ms_deform_attn import multi_value_projections
 from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
@@ -352,8 +353,10 @@ class BiMultiHeadAttention(nn.Module):
         return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).reshape(
             bsz * self.num_heads, -1, self.head_dim)
 
-    def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
+    def forward(self, v, l, attention_mask_v=None, attention_mask_l=None, residual_v=None):
         """v: image tokens [B, N, v_dim] (N = 22 k), l: text tokens [B, T, l_dim] (T <= 256).
+        ``residual_v``: optional callable returning the scale of the caller's ``v + scale * out_v``; when the fused path can
+        take the residual into its last GEMM it returns ``(v + scale * out_v, out_l, True)`` instead of ``(out_v, out_l)``.
 
         ``reassociate`` (default): the three image-side projections (v_dim -> embed_dim = 1024 on N
         tokens, 70 GFLOP and five 91 MB tensors per layer at the bench shape) are never formed.
@@ -384,7 +387,13 @@ class BiMultiHeadAttention(nn.Module):
                 out_l = out_l + self.values_v_proj.bias.view(H, hd)     # rows of P_l sum to one
                 out_l = self.out_l_proj(out_l.reshape(bsz, src_len, self.embed_dim))
                 z = torch.einsum("bthe,dhe->bhtd", value_l4, self.out_v_proj.weight.view(-1, H, hd))
-                out_v = wide_matmul(pv, z.reshape(bsz, H * src_len, -1), self.out_v_proj.bias)
+                z = z.reshape(bsz, H * src_len, -1)
+                if residual_v is not None:
+                    scale = residual_v()
+                    if wide_matmul_residual_supported(pv, z, self.out_v_proj.bias, v, scale):
+                        return wide_matmul_residual(pv, z, self.out_v_proj.bias, v, scale), out_l, True
+                    return torch.addcmul(v, wide_matmul(pv, z, self.out_v_proj.bias), scale), out_l, True
+                out_v = wide_matmul(pv, z, self.out_v_proj.bias)
                 return out_v, out_l
             attn = wide_matmul(v, a.reshape(bsz, -1, H * src_len)).view(bsz, tgt_len, H, src_len) + c[:, None]
             attn = attn.permute(0, 2, 1, 3).reshape(bsz * H, tgt_len, src_len)  # [bs*heads, n_img, n_text]
@@ -453,24 +462,34 @@ class BiAttentionBlock(nn.Module):
     def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
         v = self.layer_norm_v(v)
         l = self.layer_norm_l(l)
-        delta_v, delta_l = self.attn(v, l, attention_mask_v=attention_mask_v,
-                                     attention_mask_l=attention_mask_l)
         if not self.fused_residual:
+            delta_v, delta_l = self.attn(v, l, attention_mask_v=attention_mask_v, attention_mask_l=attention_mask_l)
             return v + self.drop_path(self.gamma_v * delta_v), l + self.drop_path(self.gamma_l * delta_l)
-        return self._residual(v, self.gamma_v, delta_v), self._residual(l, self.gamma_l, delta_l)
+        # the image-side residual rides in the attention's last GEMM when it can (the scale is drawn when that GEMM is
+        # reached: after everything the attention itself draws, as in the reference's order)
+        in_gemm = (lambda: self._scale(self.gamma_v, v)) if self.residual_in_gemm and not self.gamma_v.requires_grad else None
+        got = self.attn(v, l, attention_mask_v=attention_mask_v, attention_mask_l=attention_mask_l, residual_v=in_gemm)
+        if len(got) == 3:
+            return got[0], self._residual(l, self.gamma_l, got[1])
+        return self._residual(v, self.gamma_v, got[0]), self._residual(l, self.gamma_l, got[1])
 
-    fused_residual = True   # class-level switch for A/B runs
+    fused_residual = True     # class-level switches for A/B runs
+    residual_in_gemm = True
+
+    def _scale(self, gamma, x):
+        """gamma, times the per-sample stochastic-depth factor as a [B, 1, C] tensor when it is drawn."""
+        dp = self.drop_path
+        if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
+            keep = 1 - dp.drop_prob
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep).div_(keep)
+            return gamma * mask
+        return gamma
 
     def _residual(self, x, gamma, delta):
         """x + drop_path(gamma * delta) as one pass: the layer scale and the per-sample stochastic-depth
         factor are folded into a [B, 1, C] scale first (the reference's three elementwise passes over the
         [B, S, 256] image tokens -- scale, mask, add -- move 2.7x the bytes; same draws from the RNG)."""
-        dp = self.drop_path
-        if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
-            keep = 1 - dp.drop_prob
-            mask = delta.new_empty((delta.shape[0],) + (1,) * (delta.ndim - 1)).bernoulli_(keep).div_(keep)
-            return torch.addcmul(x, delta, gamma * mask)
-        return torch.addcmul(x, delta, gamma)
+        return torch.addcmul(x, delta, self._scale(gamma, delta))
 
 
 class TransformerEncoderLayer(nn.Module):
