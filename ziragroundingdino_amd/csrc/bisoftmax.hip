@@ -226,6 +226,76 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd(
     for (int j = threadIdx.x; j < HT; j += kThreads) part_sum[((size_t)b * chunks + chunk) * HT + j] = colacc[j];
 }
 
+// The same for T = 32 text tokens (the ODinW-like captions of the bench; H * T a multiple of 64): a (row, head) is half a
+// wave, so everything stays in registers -- a lane owns column 64 hf + lane of its wave's rows, the softmax reductions are
+// five xor-shuffles inside 32 lanes (in the order of the G-lane groups above: the same p_v bit for bit), the column sums of
+// e are per-lane registers joined through LDS once at the end.  No tile, no barrier inside the loop, four rows of loads
+// in flight per wave: 42 us -> HBM time for the 68 MB.
+template <int HALVES>
+__global__ __launch_bounds__(kThreads) void bis_rows_fwd_t32(
+    const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
+    const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l, const uint8_t *__restrict__ mask_v, int N,
+    int stable, int clamp_lo, int clamp_hi, float *__restrict__ pv, float *__restrict__ e, float *__restrict__ part_sum)
+{
+    constexpr int HT = 64 * HALVES, T = 32, U = 4;
+    __shared__ float red[kThreads / 64][HT];
+    const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = stable ? gmax[0] : 0.f;
+    float cj[HALVES], cm1[HALVES], acc[HALVES];
+    bool live[HALVES];
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) {
+        const int j = 64 * hf + lane;
+        cj[hf] = c[(size_t)b * HT + j];
+        cm1[hf] = clampf(colmax[(size_t)b * HT + j] - g, clamp_lo, clamp_hi);   // max_n x1 (clamp is monotone)
+        live[hf] = !(mask_l && mask_l[b * T + (j & (T - 1))]);
+        acc[hf] = 0.f;
+    }
+    const int nw = (kThreads / 64) * chunks;   // waves per batch element: wave w takes rows w, w + nw, ...
+    const float *xb = xm + (size_t)b * N * HT + lane;
+    for (int r0 = chunk * (kThreads / 64) + wave; r0 < N; r0 += nw * U) {
+        float x[U][HALVES];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * nw < N ? r0 + u * nw : N - 1;   // (clamped: no branch round the loads)
+#pragma unroll
+            for (int hf = 0; hf < HALVES; ++hf) x[u][hf] = xb[(size_t)row * HT + 64 * hf];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = r0 + u * nw;
+            if (row >= N) break;   // wave-uniform
+            const bool dead = mask_v && mask_v[(size_t)b * N + row];
+            const size_t o = ((size_t)b * N + row) * HT + lane;
+#pragma unroll
+            for (int hf = 0; hf < HALVES; ++hf) {
+                const float x1 = clampf(x[u][hf] + cj[hf] - g, clamp_lo, clamp_hi);
+                float m = live[hf] ? x1 : -INFINITY;
+#pragma unroll
+                for (int d = 1; d < T; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+                const float ex = live[hf] ? expf(x1 - m) : 0.f;
+                float sum = ex;
+#pragma unroll
+                for (int d = 1; d < T; d <<= 1) sum += __shfl_xor(sum, d);
+                pv[o + 64 * hf] = live[hf] ? ex * (1.f / sum) : 0.f;
+                const float ev = dead ? 0.f : expf(clampf(x1 - cm1[hf], clamp_lo, clamp_hi));
+                e[o + 64 * hf] = ev;
+                acc[hf] += ev;
+            }
+        }
+    }
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) red[wave][64 * hf + lane] = acc[hf];
+    __syncthreads();
+    for (int j = threadIdx.x; j < HT; j += kThreads) {
+        float t = red[0][j];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) t += red[w][j];
+        part_sum[((size_t)b * chunks + chunk) * HT + j] = t;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
     const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
     const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l, const float *__restrict__ pv,
@@ -373,6 +443,12 @@ int zira_bisoftmax_fwd_f32(const float *xm, const float *c, const uint8_t *mask_
     hipLaunchKernelGGL(bis_global_max, dim3(1), dim3(kThreads), 0, st, colmax, total, gmax);
     const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
     const int vec = (HT % 4 == 0) && !(((uintptr_t)xm | (uintptr_t)c | (uintptr_t)colmax | (uintptr_t)pv | (uintptr_t)e) & 15);
+    if (T == 32 && (HT == 64 || HT == 128 || HT == 256)) {   // a (row, head) = half a wave: the register form
+        const dim3 grid(rchunks, B);
+        if (HT == 64) hipLaunchKernelGGL(bis_rows_fwd_t32<1>, grid, dim3(kThreads), 0, st, xm, c, colmax, gmax, mask_l, mask_v, N, stable, clamp_lo, clamp_hi, pv, e, workspace);
+        else if (HT == 128) hipLaunchKernelGGL(bis_rows_fwd_t32<2>, grid, dim3(kThreads), 0, st, xm, c, colmax, gmax, mask_l, mask_v, N, stable, clamp_lo, clamp_hi, pv, e, workspace);
+        else hipLaunchKernelGGL(bis_rows_fwd_t32<4>, grid, dim3(kThreads), 0, st, xm, c, colmax, gmax, mask_l, mask_v, N, stable, clamp_lo, clamp_hi, pv, e, workspace);
+    } else
     hipLaunchKernelGGL(bis_rows_fwd, dim3(rchunks, B), dim3(kThreads), (((size_t)2 * R + 1) * HT + T) * sizeof(float), st,
                        xm, c, colmax, gmax, mask_l, mask_v, N, H, T, R, stable, clamp_lo, clamp_hi, vec, pv, e, workspace);
     hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, rchunks, HT, 1,
