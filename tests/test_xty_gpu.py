@@ -123,3 +123,45 @@ def test_fusion_block_residual_in_gemm_matches_addcmul(drop_path):
     assert len(calls) == 1                                   # the GEMM form ran, and only when switched on
     for a, b in zip(res[True], res[False]):
         assert _rel(a, b.double()) < 2e-6
+
+
+def test_composed_text_side_matches_two_step_projections():
+    """The text side's double projections through embed_dim (l_proj then the query weights, values_l_proj then the output
+    weights, the value weights then out_l_proj) as one constant matrix each while the six Linears are frozen
+    (BiMultiHeadAttention._composed_text_side) against the two-step form: outputs and input gradients to fp32
+    re-association; a weight changed in place is followed, in the same buffers (captured graphs read them)."""
+    from ziragroundingdino_amd import transformer
+    torch.manual_seed(5)
+    att = transformer.BiMultiHeadAttention(v_dim=256, l_dim=256, embed_dim=1024, num_heads=4, dropout=0.0).to(DEV)
+    for p in att.parameters():
+        p.data.normal_(0, 0.05)
+        p.requires_grad_(False)
+    N, T = 3001, 32
+    v = torch.randn(2, N, 256, device=DEV, requires_grad=True)
+    l = torch.randn(2, T, 256, device=DEV, requires_grad=True)
+    mask_l = torch.zeros(2, T, dtype=torch.bool, device=DEV)
+    mask_l[0, T - 3:] = True
+    gv, gl = torch.randn(2, N, 256, device=DEV), torch.randn(2, T, 256, device=DEV)
+
+    def run(flag):
+        transformer.BiMultiHeadAttention.compose_text_side = flag
+        try:
+            ov, ol = att(v, l, attention_mask_v=None, attention_mask_l=mask_l)
+            return (ov.detach(), ol.detach()) + torch.autograd.grad((ov * gv).sum() + (ol * gl).sum(), [v, l])
+        finally:
+            transformer.BiMultiHeadAttention.compose_text_side = True
+
+    def check():
+        for n, a, b in zip(("out_v", "out_l", "grad_v", "grad_l"), run(True), run(False)):
+            assert _rel(a, b.double()) < 2e-5, n
+
+    assert att._composed_text_side(l) is not None
+    check()
+    ptrs = [t.data_ptr() for t in att._text_side[1]]
+    with torch.no_grad():
+        att.l_proj.weight.mul_(1.5)
+        att.out_l_proj.bias.add_(0.25)
+    check()
+    assert [t.data_ptr() for t in att._text_side[1]] == ptrs
+    att.l_proj.weight.requires_grad_(True)      # a trainable Linear: the two-step form
+    assert att._composed_text_side(l) is None

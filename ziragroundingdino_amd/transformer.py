@@ -353,6 +353,54 @@ class BiMultiHeadAttention(nn.Module):
         return t.view(bsz, -1, self.num_heads, self.head_dim).transpose(1, 2).reshape(
             bsz * self.num_heads, -1, self.head_dim)
 
+    compose_text_side = True   # class-level switch for A/B runs
+
+    def _composed_text_side(self, l):
+        """The text side of the re-bracketed products goes through ``embed_dim`` = 1024 twice in a row -- ``l_proj`` then the
+        query weights, ``values_l_proj`` then the output weights, the value weights then ``out_l_proj`` -- as one Linear on
+        the B x T <= 512 text tokens and one batched product per head: GEMMs of a few MFLOP that take 15-25 us each, and as
+        many again in the backward.  While all six Linears are frozen (every ZiRa task) each pair is ONE constant matrix:
+            a_h  = scale (l Wl_h^T + bl_h) Wq_h         = l A_h + a0_h        A_h = scale Wl_h^T Wq_h        [l_dim, v_dim]
+            c_h  = scale (l Wl_h^T + bl_h) . bq_h       = l C_h + c0_h
+            z_h  = (l Wvl_h^T + bvl_h) Wo_h^T           = l Z_h + z0_h        Z_h = Wvl_h^T Wo_h^T
+            out_l = sum_h (u_h Wvv_h^T + bvv_h) Wol_h^T + bol = [u_0 .. u_H] O + o0,   O_h = Wvv_h^T Wol_h^T
+        (products formed once in float64, rounded to fp32; fp32 re-association as the image side, reference
+        fuse_modules.py:152-163, :213-235).  Rebuilt -- IN PLACE, captured graphs keep reading the buffers -- whenever a
+        weight changes (load_state_dict, .to(), an optimizer that does train them elsewhere).  Returns None when it does
+        not apply."""
+        lins = (self.l_proj, self.v_proj, self.values_l_proj, self.out_v_proj, self.values_v_proj, self.out_l_proj)
+        if not self.compose_text_side or not l.is_cuda or l.dtype != torch.float32 or torch.is_autocast_enabled("cuda"):
+            return None
+        ps = [p for lin in lins for p in (lin.weight, lin.bias)]
+        if any(p is None or p.requires_grad or p.dtype != torch.float32 or p.device != l.device for p in ps):
+            return None
+        key = tuple(x for p in ps for x in (p.data_ptr(), p._version))
+        cached = getattr(self, "_text_side", None)
+        if cached is None or cached[0] != key:
+            H, hd = self.num_heads, self.head_dim
+            with torch.no_grad():
+                f64 = lambda t: t.detach().double()
+                Wl, bl = f64(self.l_proj.weight).view(H, hd, -1), f64(self.l_proj.bias).view(H, hd)
+                Wq, bq = f64(self.v_proj.weight).view(H, hd, -1), f64(self.v_proj.bias).view(H, hd)
+                Wvl, bvl = f64(self.values_l_proj.weight).view(H, hd, -1), f64(self.values_l_proj.bias).view(H, hd)
+                Wo = f64(self.out_v_proj.weight).view(-1, H, hd)
+                Wvv, bvv = f64(self.values_v_proj.weight).view(H, hd, -1), f64(self.values_v_proj.bias).view(H, hd)
+                Wol, bol = f64(self.out_l_proj.weight).view(-1, H, hd), f64(self.out_l_proj.bias)
+                A = self.scale * torch.einsum("hel,hed->lhd", Wl, Wq).flatten(1)          # [l_dim, H * v_dim]
+                C = self.scale * torch.einsum("hel,he->lh", Wl, bq)                       # [l_dim, H]
+                a0 = self.scale * torch.einsum("he,hed->hd", bl, Wq).flatten()
+                c0 = self.scale * (bl * bq).sum(-1)
+                new = [torch.cat([A, C], 1), torch.cat([a0, c0]),
+                       torch.einsum("hel,dhe->lhd", Wvl, Wo).flatten(1), torch.einsum("he,dhe->hd", bvl, Wo).flatten(),
+                       torch.einsum("hed,lhe->hdl", Wvv, Wol).flatten(0, 1), torch.einsum("he,lhe->l", bvv, Wol) + bol]
+                new = [t.float().contiguous() for t in new]
+                if cached is not None and all(o.shape == n.shape and o.device == n.device for o, n in zip(cached[1], new)):
+                    for o, n in zip(cached[1], new):
+                        o.copy_(n)
+                    new = cached[1]
+            cached = self._text_side = (key, new)
+        return cached[1]
+
     def forward(self, v, l, attention_mask_v=None, attention_mask_l=None, residual_v=None):
         """v: image tokens [B, N, v_dim] (N = 22 k), l: text tokens [B, T, l_dim] (T <= 256).
         ``residual_v``: optional callable returning the scale of the caller's ``v + scale * out_v``; when the fused path can
@@ -370,12 +418,22 @@ class BiMultiHeadAttention(nn.Module):
         H, hd = self.num_heads, self.head_dim
         if self.reassociate:
             src_len = l.size(1)
-            k4 = self.l_proj(l).view(bsz, src_len, H, hd)
-            value_l4 = self.values_l_proj(l).view(bsz, src_len, H, hd)
-            wq = self.v_proj.weight.view(H, hd, -1)
-            a = torch.einsum("hed,bthe->bdht", wq, k4) * self.scale             # [B, v_dim, H, T]
-            c = torch.einsum("he,bthe->bht", self.v_proj.bias.view(H, hd), k4) * self.scale
-            if self.fused_softmax and bi_softmax_supported(v, H, src_len, self.training and self.dropout > 0):
+            fused = self.fused_softmax and bi_softmax_supported(v, H, src_len, self.training and self.dropout > 0)
+            composed = self._composed_text_side(l) if fused else None
+            if composed is not None:   # the text side's double projections as one constant matrix each (see there)
+                AC, ac0, Z, z0, O, o0 = composed
+                l2 = l.reshape(bsz * src_len, -1)
+                ac = torch.addmm(ac0, l2, AC).view(bsz, src_len, -1)
+                a = ac[..., :H * self.v_dim].reshape(bsz, src_len, H, self.v_dim).permute(0, 3, 2, 1)   # [B, v_dim, H, T]
+                c = ac[..., H * self.v_dim:].permute(0, 2, 1)                                            # [B, H, T]
+                value_l4 = k4 = None
+            else:
+                k4 = self.l_proj(l).view(bsz, src_len, H, hd)
+                value_l4 = self.values_l_proj(l).view(bsz, src_len, H, hd)
+                wq = self.v_proj.weight.view(H, hd, -1)
+                a = torch.einsum("hed,bthe->bdht", wq, k4) * self.scale             # [B, v_dim, H, T]
+                c = torch.einsum("he,bthe->bht", self.v_proj.bias.view(H, hd), k4) * self.scale
+            if fused:
                 # everything between the score GEMM and the two output GEMMs in one HIP op
                 # (csrc/bisoftmax.hip), tensors staying in the GEMMs' [B, N, H*T] layout
                 xm = wide_matmul(v, a.reshape(bsz, -1, H * src_len))
@@ -383,10 +441,14 @@ class BiMultiHeadAttention(nn.Module):
                                            H, src_len, self.stable_softmax_2d, self.clamp_min_for_underflow,
                                            self.clamp_max_for_overflow)
                 u = (tall_reduce_nt(e, v) / colsum[..., None]).view(bsz, H, src_len, -1)   # P_l v
-                out_l = torch.einsum("bhtd,hed->bthe", u, self.values_v_proj.weight.view(H, hd, -1))
-                out_l = out_l + self.values_v_proj.bias.view(H, hd)     # rows of P_l sum to one
-                out_l = self.out_l_proj(out_l.reshape(bsz, src_len, self.embed_dim))
-                z = torch.einsum("bthe,dhe->bhtd", value_l4, self.out_v_proj.weight.view(-1, H, hd))
+                if composed is not None:
+                    out_l = torch.addmm(o0, u.permute(0, 2, 1, 3).reshape(bsz * src_len, -1), O).view(bsz, src_len, -1)
+                    z = torch.addmm(z0, l2, Z).view(bsz, src_len, H, -1).permute(0, 2, 1, 3)          # [B, H, T, v_dim]
+                else:
+                    out_l = torch.einsum("bhtd,hed->bthe", u, self.values_v_proj.weight.view(H, hd, -1))
+                    out_l = out_l + self.values_v_proj.bias.view(H, hd)     # rows of P_l sum to one
+                    out_l = self.out_l_proj(out_l.reshape(bsz, src_len, self.embed_dim))
+                    z = torch.einsum("bthe,dhe->bhtd", value_l4, self.out_v_proj.weight.view(-1, H, hd))
                 z = z.reshape(bsz, H * src_len, -1)
                 if residual_v is not None:
                     scale = residual_v()
