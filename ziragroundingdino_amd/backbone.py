@@ -164,7 +164,7 @@ class SwinTransformerBlock(nn.Module):
         Hp, Wp = H + pad_b, W + pad_r
         if self.shift_size > 0:
             x = torch.roll(x, shifts=(-self.shift_size, -self.shift_size), dims=(1, 2))
-            attn_mask = mask_matrix
+            attn_mask = mask_matrix() if callable(mask_matrix) else mask_matrix
         else:
             attn_mask = None
         w = self.attn(window_partition(x, ws), mask=attn_mask)
@@ -201,16 +201,25 @@ class BasicLayer(nn.Module):
 
     def forward(self, x, H, W, dp=None):
         ws, ss = self.window_size, self.shift_size
-        Hp, Wp = int(math.ceil(H / ws)) * ws, int(math.ceil(W / ws)) * ws
-        img_mask = torch.zeros((1, Hp, Wp, 1), device=x.device)
-        cnt = 0
-        for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
-            for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
-                img_mask[:, h, w, :] = cnt
-                cnt += 1
-        mw = window_partition(img_mask, ws).view(-1, ws * ws)
-        attn_mask = mw.unsqueeze(1) - mw.unsqueeze(2)
-        attn_mask = attn_mask.masked_fill(attn_mask != 0, -100.0).masked_fill(attn_mask == 0, 0.0)
+        made = []
+
+        def attn_mask():
+            """The shifted windows' [nW, ws*ws, ws*ws] additive mask (reference swin_transformer.py:382-398), built when a
+            block asks for it: the native window attention does the same bookkeeping by index arithmetic inside its kernel,
+            and at the bench size the stage-1 mask is an 11 MB tensor written three times per pass."""
+            if not made:
+                Hp, Wp = int(math.ceil(H / ws)) * ws, int(math.ceil(W / ws)) * ws
+                img_mask = torch.zeros((1, Hp, Wp, 1), device=x.device)
+                cnt = 0
+                for h in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+                    for w in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+                        img_mask[:, h, w, :] = cnt
+                        cnt += 1
+                mw = window_partition(img_mask, ws).view(-1, ws * ws)
+                m = mw.unsqueeze(1) - mw.unsqueeze(2)
+                made.append(m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0))
+            return made[0]
+
         for i, blk in enumerate(self.blocks):
             x = blk(x, H, W, attn_mask, None if dp is None else dp[i])
         if self.downsample is not None:
