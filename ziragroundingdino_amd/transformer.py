@@ -109,6 +109,15 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
             kpm = _additive_mask(kpm, q.dtype)
         if attention.supported(q, k, v, H, kpm):
             return F.linear(attention.fused_attention(q, k, v, H, kpm), mha.out_proj.weight, mha.out_proj.bias)
+    return F.linear(_mha_core(q, k, v, H, key_padding_mask, attn_mask, dropout_p), mha.out_proj.weight, mha.out_proj.bias)
+
+
+def _mha_core(q: Tensor, k: Tensor, v: Tensor, H: int, key_padding_mask, attn_mask, dropout_p: float) -> Tensor:
+    """The attention between the in- and the out-projection of ``lean_mha``: q [L, B, E], k / v [S, B, E] (any strides) ->
+    [L, B, E]; masks as nn.MultiheadAttention takes them."""
+    L, B, E = q.shape
+    S = k.shape[0]
+    hd = E // H
     q = q.reshape(L, B * H, hd).transpose(0, 1).view(B, H, L, hd)
     k = k.reshape(S, B * H, hd).transpose(0, 1).view(B, H, S, hd)
     v = v.reshape(S, B * H, hd).transpose(0, 1).view(B, H, S, hd)
@@ -127,8 +136,7 @@ def lean_mha(mha: nn.MultiheadAttention, query: Tensor, key: Tensor, value: Tens
         out = _attention_small(q, k, v, mask, dropout_p)
     else:
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=dropout_p)
-    out = out.permute(2, 0, 1, 3).reshape(L, B, E)
-    return F.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    return out.permute(2, 0, 1, 3).reshape(L, B, E)
 
 
 SMALL_ATTENTION_SCORES = 1 << 25   # score elements (B*H*L*S) up to which the scores are simply materialised
@@ -584,11 +592,17 @@ class TransformerEncoderLayer(nn.Module):
         # masks of different images are interleaved over heads; kept for output parity.
         if src_mask.dim() == 3 and src_mask.shape[0] == src.shape[1]:
             src_mask = src_mask.repeat(self.nhead, 1, 1)
+        if self.native_projections:
+            from . import text_layer
+            if text_layer.applies(self, src, pos):
+                return text_layer.forward(self, src, pos, src_mask)
         q = k = self.with_pos_embed(src, pos)
         src2 = _mha(self.self_attn, q, k, src, attn_mask=src_mask)
         src = self.norm1(src + self.dropout1(src2))
         src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout2(src2))
+
+    native_projections = True   # class-level switch (tests compare both ways)
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
