@@ -9,6 +9,7 @@ for f in glob.glob("/tmp/im/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     print("  total kernel time %.1f ms" % (sum(float(r["TotalDurationNs"]) for r in rows) / 1e6))
     for r in rows:
-        if re.search(r"msda_(fwd_plan|bwd_tile_accum|bwd_fold\()", r["Name"]) or "zira::msda_bwd_fold" in r["Name"]:
-            print("  %-40s calls %5s avg %8.2f us" % (re.sub(r"\(.*", "", r["Name"])[:40], r["Calls"], float(r["AverageNs"]) / 1e3))
+        import os
+        if re.search(os.environ.get("KPAT", r"msda_(fwd_plan|bwd_tile_accum|bwd_fold\()"), r["Name"]) or "zira::msda_bwd_fold" in r["Name"]:
+            print("  %-60s calls %5s avg %8.2f us  min %7.2f max %8.2f" % (re.sub(r"\(zira_.*|\(float.*", "", r["Name"])[-60:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY

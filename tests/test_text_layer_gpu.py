@@ -37,12 +37,13 @@ def _inputs(T, B, seed):
 
 
 def _run(lay, src, pos, mask, go, native):
+    before = transformer.TransformerEncoderLayer.native_projections
     transformer.TransformerEncoderLayer.native_projections = native
     try:
         out = lay(src, src_mask=mask, src_key_padding_mask=None, pos=pos)
         return out.detach(), torch.autograd.grad([out], [src], [go])[0]
     finally:
-        transformer.TransformerEncoderLayer.native_projections = True
+        transformer.TransformerEncoderLayer.native_projections = before
 
 
 @pytest.mark.parametrize("T,B", [(32, 2), (9, 2), (195, 1), (256, 2)])
