@@ -227,9 +227,13 @@ def test_sampling_locations_one_pass_is_bit_identical():
     assert torch.equal(a, b)
 
 
-def test_transformer_graph_path_matches_eager_and_survives_replays():
-    """Opt-in hipGraph replay of the encoder / decoder layers (graphs.GraphedTransformer): same losses as the
-    eager path step by step (stochastic depth off so that both see the same arithmetic), ten replays."""
+@pytest.mark.parametrize("graph_encoder", [False, True])
+def test_transformer_graph_path_matches_eager_and_survives_replays(graph_encoder, monkeypatch):
+    """hipGraph replay of the decoder piece (the default) and of the encoder pieces as well (graphs.GraphedTransformer): same
+    losses as the eager path step by step (stochastic depth off so that both see the same arithmetic), ten replays."""
+    from ziragroundingdino_amd import graphs as zg
+    monkeypatch.setattr(zg.GraphedTransformer, "graph_encoder", graph_encoder)
+
     def run(use_graph):
         model = small_model().train()            # seeds itself; stochastic depth is off in small_model
         model.use_transformer_graph = use_graph

@@ -190,16 +190,21 @@ class GraphedTransformer:
     graphs (``torch.cuda.make_graphed_callables``): in eager mode the host needs ~31 ms to
     enqueue the ~1500 small kernels of the forward alone, longer than the GPU needs to run them.
 
-    The transformer is cut into seven graphed pieces -- text enhancer + deformable layer of each
+    The transformer is cut into seven pieces that can replay from graphs -- text enhancer + deformable layer of each
     encoder layer, and query selection + decoder -- each with its own pair of graphs and memory
-    pool; the six image<->text fusion blocks between them stay eager.  Two things fault on the second
+    pool (since round 4 only the decoder piece does by default: see ``graph_encoder`` below); the six image<->text fusion blocks between them stay eager.  Two things fault on the second
     replay on ROCm 7.2 / torch 2.10 and are avoided: ``torch.topk`` inside a graph (the graphed query
     selection takes the first k of a stable descending sort instead: same indices unless logits tie)
     and graphs that contain three or more BiAttention blocks (found by bisection in round 2).
     One set of graphs per input signature (image size / caption length); further signatures
     run eagerly after ``max_signatures``."""
 
-    graph_encoder = True   # class-level switches: which pieces are graphed (developer bisection)
+    # Class-level switches: which pieces replay from graphs.  The decoder piece is ~1000 launches of a few microseconds: graphed,
+    # 36.6-36.7 against 39.6-39.9 ms per step launched eagerly.  The six encoder pieces are ~120 launches for ~4 ms of GPU time
+    # each -- the host stays ahead of them on any machine -- and run 0.5 ms per step FASTER launched eagerly (36.57 / 36.75
+    # against 37.13 / 37.27 ms with them graphed; both eager 36.99 / 36.74: scripts/ab_step.py graph_encoder=0|1
+    # graph_decoder=0|1, alternating processes on one box).  graph_encoder = True remains supported and tested.
+    graph_encoder = False
     graph_decoder = True
     graph_fusion = False     # True: each fusion block replays from its own graph pair as well (300-step soak passes; no faster: the step is GPU-bound by then)
     graph_selection = False  # two-stage query selection runs eagerly with torch.topk -- the indices the eager path and the
