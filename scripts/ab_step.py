@@ -36,7 +36,7 @@ for kv in sys.argv[1:]:
         zt.BiMultiHeadAttention.compose_text_side = bool(int(v))
     elif k == "residual_in_gemm":
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
-    elif k in ("graph_encoder", "graph_decoder"):
+    elif k in ("graph_encoder", "graph_decoder", "graph_fusion", "graph_selection"):
         from ziragroundingdino_amd.graphs import GraphedTransformer
         setattr(GraphedTransformer, k, bool(int(v)))
     else:

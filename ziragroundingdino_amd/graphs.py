@@ -206,7 +206,7 @@ class GraphedTransformer:
     # graph_decoder=0|1, alternating processes on one box).  graph_encoder = True remains supported and tested.
     graph_encoder = False
     graph_decoder = True
-    graph_fusion = False     # True: each fusion block replays from its own graph pair as well (300-step soak passes; no faster: the step is GPU-bound by then)
+    graph_fusion = False     # True: each fusion block replays from its own graph pair as well (300-step soak passes; SLOWER: 37.2-37.4 against 36.5-36.7 ms per step)
     graph_selection = False  # two-stage query selection runs eagerly with torch.topk -- the indices the eager path and the
                              # reference pick, ties included; True: inside the decoder's graph, as the first k of a stable sort
 
