@@ -438,6 +438,36 @@ def pmc_traffic():
         return None
 
 
+PROFILE_GROUPS = {   # kernels of a timed group as they are named in profiles/*_bench_kernel_stats.txt
+    "fwd_dec": ("zira::msda_fwd_plan",),
+    "bwd_dec": ("zira::msda_bwd_tile_accum<256u>", "zira::msda_bwd_fold"),
+    "fwd_enc": ("msda_fwd_lean<2>",),
+    "bwd_enc": ("msda_bwd_bin", "msda_bwd_accum<32, 512>", "msda_bwd_fold<32>", "msda_bwd_walk<32, 4>"),
+}
+
+
+def profile_kernel_times():
+    """Average microseconds per kernel name from the newest committed rocprofv3 summary of the bench command
+    (profiles/*_bench_kernel_stats.txt, written by scripts/collect_profiles.sh), so that `roofline.kernels.*.frac_profiles`
+    can be compared with the line's own event timing mechanically.  -> ({name: avg_us}, file) or ({}, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.txt")))
+    if not files:
+        return {}, None
+    avg, on = {}, False
+    for ln in open(files[-1]):
+        if ln.startswith("hand-written kernels"):
+            on = True
+            continue
+        parts = ln.split(None, 4)
+        if on and len(parts) == 5 and parts[0].endswith("%"):
+            try:
+                avg[parts[4].strip()] = float(parts[3])
+            except ValueError:
+                pass
+    return avg, os.path.relpath(files[-1], ROOT)
+
+
 def summarize_timing(records, B_expect):
     """Group the (kind, dims, e0, e1) records of `_C.TIMING` -> {group: (calls, avg seconds, dims)}."""
     groups = {}
@@ -486,6 +516,9 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="with WORLD_SIZE=1 under torch.distributed.run: still create the nccl group and issue every barrier / "
                          "all-reduce of the N > 1 path (a hardware check of that path on a 1-GPU box)")
+    ap.add_argument("--regions", type=int, default=3,
+                    help="timed regions of --steps steps per launch mode; the line reports the MEDIAN region (each region is "
+                         "bracketed by barrier + synchronize on both sides; all of them are listed in config.launch_modes)")
     ap.add_argument("--no-second-mode", action="store_true",
                     help="skip the second timed region in the other launch mode (eager <-> hipGraph replay)")
     args = ap.parse_args()
@@ -563,16 +596,16 @@ def main():
         model.use_transformer_graph = False
         trainer.flat_grad.zero_()
         run_steps(args.warmup)
+    regions = max(1, args.regions)
     _C.TIMING = []
-    elapsed = timed(args.steps)
+    all_regions = {"graph" if args.transformer_graph else "eager": [timed(args.steps) for _ in range(regions)]}
     records, _C.TIMING = _C.TIMING, None
-    modes = {"graph" if args.transformer_graph else "eager": elapsed}
     if not args.no_second_mode and args.dtype == "f32":   # the same steps in the other launch mode (every rank: collectives)
         other = not args.transformer_graph
         model.use_transformer_graph = other
         try:
             run_steps(max(2, args.warmup))
-            modes["graph" if other else "eager"] = timed(args.steps)
+            all_regions["graph" if other else "eager"] = [timed(args.steps) for _ in range(regions)]
         except RuntimeError as e:
             if not other or torch.cuda.is_current_stream_capturing():
                 raise
@@ -599,17 +632,18 @@ def main():
         if rank == 0:
             replay = inmodel_replay(got, dev)
         del got
-    if dist_on:
-        keys = sorted(modes)
-        t = torch.tensor([elapsed] + [modes[k] for k in keys], device=dev, dtype=torch.float64)
+    if dist_on:   # every region: the MAX over ranks
+        keys = sorted(all_regions)
+        t = torch.tensor([x for k in keys for x in all_regions[k]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0].item())
-        modes = {k: float(t[1 + i].item()) for i, k in enumerate(keys)}
-    # Both launch modes ran the SAME K steps between the same barriers (max over ranks each): the line reports the faster
-    # one and says which (`config.launch_mode`); `config.launch_modes` keeps both.  Replayed graphs do not depend on the
-    # host, eager launches win by 2-3 % on a fast one -- a deployment would pick per machine exactly like this.
+        flat = [float(x) for x in t.tolist()]
+        all_regions = {k: flat[i * regions:(i + 1) * regions] for i, k in enumerate(keys)}
+    # Both launch modes ran the SAME K steps, `--regions` times each, every region between the same barriers (max over
+    # ranks).  `value` is the CONFIGURED mode (the trainer's default unless a flag says otherwise), its median region; the
+    # other mode stands beside it in `config.launch_modes` and is never the headline.
+    modes = {k: sorted(v)[len(v) // 2] for k, v in all_regions.items()}
     primary_mode = "graph" if args.transformer_graph else "eager"
-    reported_mode = min(modes, key=modes.get)
+    reported_mode = primary_mode
     elapsed = modes[reported_mode]
 
     if rank == 0:
@@ -624,6 +658,13 @@ def main():
                             "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS,
                             "share_of_step": (calls / timed_steps) * avg_s / (elapsed / args.steps),
                             "dims_BSMDLQP": list(dims)}
+        prof_avg, prof_file = profile_kernel_times()
+        for key, names in PROFILE_GROUPS.items():   # the same groups from the committed rocprofv3 summary of this command
+            if key in kernels and all(n in prof_avg for n in names[:1]):
+                us = sum(prof_avg.get(n, 0.0) for n in names)
+                kernels[key]["avg_us_profiles"] = us
+                kernels[key]["frac_profiles"] = kernels[key]["algorithmic_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                kernels[key]["profiles_source"] = prof_file + ": " + " + ".join(names)
         dominant = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                     "kernels": kernels, "dominant": dominant, "timing_source": timing_source}
@@ -694,8 +735,11 @@ def main():
                 "launch_mode": reported_mode, "launch_mode_default": primary_mode,
                 "frontend_prefetch": bool(args.prefetch), "collectives_forced": bool(dist_on and world == 1),
                 "text_tokens": 2 + 2 * args.categories, "distinct_minibatches": len(batches),
-                "launch_modes": {k: {"images_per_s": images / v, "ms_per_step": v / args.steps * 1e3}
+                "launch_modes": {k: {"images_per_s": images / v, "ms_per_step": v / args.steps * 1e3,
+                                     "regions_ms_per_step": [x / args.steps * 1e3 for x in all_regions[k]]}
                                  for k, v in sorted(modes.items())},
+                "value_is": "median of %d timed regions of %d steps in the configured launch mode (%s)"
+                            % (regions, args.steps, primary_mode),
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "msda_kernel_variant": _lib.variant_f32(32),
             },

@@ -36,15 +36,19 @@ CFG = dict(hidden_dim=256, nheads=8, num_queries=16, enc_layers=1, dec_layers=2,
            channels=[12, 20, 28], dropout=0.0)
 
 
-def build_inputs(g):
+def build_inputs(g, shapes=((8, 10), (4, 5), (2, 3)), image=(64, 80), pad_from=64):
+    """``shapes``: the three backbone levels; ``image``: the padded minibatch size; ``pad_from``: image 1's first padded
+    column (None: no padding -- what bench.py's equal-sized images have)."""
     bs = 2
-    shapes = [(8, 10), (4, 5), (2, 3)]
+    shapes = [tuple(s) for s in shapes]
     feats = [torch.randn(bs, c, h, w, generator=g) for c, (h, w) in zip(CFG["channels"], shapes)]
-    img_mask = torch.zeros(bs, 64, 80, dtype=torch.bool)
-    img_mask[1, :, 64:] = True                                   # image 1 is narrower
+    img_mask = torch.zeros(bs, *image, dtype=torch.bool)
+    if pad_from is not None:
+        img_mask[1, :, pad_from:] = True                         # image 1 is narrower
     masks = [F.interpolate(img_mask[None].float(), size=s).to(torch.bool)[0] for s in shapes]
     poss = [torch.randn(bs, CFG["hidden_dim"], h, w, generator=g) for h, w in shapes]
-    pos_extra = torch.randn(bs, CFG["hidden_dim"], 1, 2, generator=g)   # level 3 = 3x3 s2 conv of level 2
+    h3, w3 = (shapes[-1][0] + 1) // 2, (shapes[-1][1] + 1) // 2   # level 3 = 3x3 s2 conv of level 2
+    pos_extra = torch.randn(bs, CFG["hidden_dim"], h3, w3, generator=g)
     ids = torch.tensor([[101, 3000, 1012, 3001, 3002, 1012, 3003, 1012, 102]] * bs)
     hidden = torch.randn(bs, ids.shape[1], CFG["bert_hidden"], generator=g)
     targets = []
@@ -67,7 +71,8 @@ class Slice:
         tr = T_.Transformer(
             d_model=d, nhead=CFG["nheads"], num_queries=CFG["num_queries"], num_encoder_layers=CFG["enc_layers"],
             num_decoder_layers=CFG["dec_layers"], dim_feedforward=CFG["dim_feedforward"], dropout=0.0,
-            return_intermediate_dec=True, query_dim=4, num_feature_levels=4, enc_n_points=2, dec_n_points=2,
+            return_intermediate_dec=True, query_dim=4, num_feature_levels=4, enc_n_points=CFG["enc_n_points"],
+            dec_n_points=CFG["dec_n_points"],
             learnable_tgt_init=True, two_stage_type="standard", embed_init_tgt=True, use_text_enhancer=True,
             use_fusion_layer=True, use_text_cross_attention=True, text_dropout=0.0, fusion_dropout=0.0,
             fusion_droppath=0.1, use_adapter=False)

@@ -38,7 +38,7 @@ def build_slice_model(g, dev, cls=GroundingDINO, seeded=True):
     c = g["cfg"]
     args = zira_swint_config(hidden_dim=c["hidden_dim"], nheads=c["nheads"], num_queries=c["num_queries"],
                              enc_layers=c["enc_layers"], dec_layers=c["dec_layers"],
-                             dim_feedforward=c["dim_feedforward"], enc_n_points=2, dec_n_points=2,
+                             dim_feedforward=c["dim_feedforward"], enc_n_points=c["enc_n_points"], dec_n_points=c["dec_n_points"],
                              max_text_len=c["max_text_len"],
                              fusion_droppath=0.0)  # stochastic depth off for parity
     tiny_bert = zbert.BertModel(zbert.BertConfig(vocab_size=64, hidden_size=c["bert_hidden"], num_hidden_layers=1,
@@ -257,6 +257,64 @@ def test_two_training_steps_match_reference(msda_backend):
     model.zero_grad(set_to_none=True)       # detaches the gradient views from the bucket ...
     with pytest.raises(RuntimeError, match="left the flat gradient bucket"):
         trainer.run_step(data)              # ... which the trainer refuses to train through
+
+
+@pytest.mark.parametrize("msda_backend", DEVICES, indirect=True)
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graphed"])
+def test_two_training_steps_at_the_native_nodes_size_match_reference(msda_backend, graphed, monkeypatch):
+    """The reference's two optimisation steps at a size this package's frozen-weight nodes accept (tests/golden/
+    gen_step_native_golden.py: d_ffn 128, 4 sampling points, 2 x 5440 unpadded image tokens): on the GPU the one-node
+    decoder layer, the decoder glue node, the encoder's attention node and its frozen FFN + LayerNorm node must have run
+    (counted), launched eagerly and replayed from the transformer's hipGraphs; on the CPU the module composition runs
+    against the same numbers.  Reference transformer_for_adapter.py:910-1073, :809-907."""
+    from gen_step_native_golden import native_inputs
+    from ziragroundingdino_amd import decoder_layer, encoder_layer, transformer
+
+    dev = msda_backend
+    if dev == "cpu" and graphed:
+        pytest.skip("graphs are a GPU launch mode")
+    g = torch.load(os.path.join(GOLDEN, "step_zira_slice_native.pt"), weights_only=False)
+    g["inputs"] = native_inputs()
+    counts = {}
+    for key, cls in (("decoder_layer", decoder_layer._FrozenDecoderLayer), ("decoder_glue", decoder_layer._RefineAndNorm),
+                     ("encoder_attention", encoder_layer._FrozenEncoderAttention), ("encoder_ffn", transformer._FrozenFFNNorm)):
+        real = cls.forward
+
+        def counted(*a, _real=real, _key=key, **k):
+            counts[_key] = counts.get(_key, 0) + 1
+            return _real(*a, **k)
+
+        monkeypatch.setattr(cls, "forward", staticmethod(counted))
+    model = build_slice_model(g, dev)
+    model.use_transformer_graph = graphed
+    trainer = ZiraTrainer(model)
+    assert sorted(trainer.names) == sorted(g["trainable_names"])
+    trainer.model = _SliceWrapper(model)
+    data = slice_inputs(g, model, dev)
+
+    loss_dict = run_slice_step(model, *data)
+    want = g["steps"][0]
+    assert set(loss_dict) == set(want["loss_dict"])
+    for k, v in loss_dict.items():
+        close(v, want["loss_dict"][k], 1e-4, k)   # north_star: 1e-3
+    sum(loss_dict.values()).backward()
+    named = dict(model.named_parameters())
+    for n in g["trainable_names"]:
+        close(named[n].grad, want["grads"][n], 1e-3, "grad " + n)
+    close(torch.linalg.vector_norm(trainer.flat_grad), want["grad_norm"], 1e-4, "grad norm")
+    trainer.flat_grad.zero_()
+    for it in range(2):
+        out = trainer.run_step(data)
+        for k, v in out.items():
+            close(v, g["steps"][it]["loss_dict"][k], 1e-4, "step %d %s" % (it, k))
+    for n in g["trainable_names"]:
+        close(named[n], g["steps"][1]["params_after"][n], 1e-4, "param after 2 steps " + n)
+    if dev == "cpu":
+        assert counts == {}, counts
+    else:     # (a replayed graph re-runs no Python: at least the capture passes count)
+        c = g["cfg"]
+        assert counts.get("decoder_layer", 0) >= c["dec_layers"] and counts.get("decoder_glue", 0) >= c["dec_layers"], counts
+        assert counts.get("encoder_attention", 0) >= c["enc_layers"] and counts.get("encoder_ffn", 0) >= c["enc_layers"], counts
 
 
 def _dp_worker(rank, world, port, path, out):

@@ -47,4 +47,39 @@ __device__ unsigned long long zira_plan_stamps[16 * 2048];
 #define ZIRA_DEV_STAMP_READERS
 #endif
 
+// -DZIRA_DEV_BTIMES=1 (independent of the phase stamps above, which drain the memory queue at every stamp): one start / mark /
+// end time per block and where it ran; the only disturbance is one wait + four stores at the end of a block.
+#ifndef ZIRA_DEV_BTIMES
+#define ZIRA_DEV_BTIMES 0
+#endif
+#if ZIRA_DEV_BTIMES
+#include <hip/hip_runtime.h>
+// absolute block times (100 MHz wall clock): start, a mark, end, kind | XCC id << 8 | HW_ID << 16 -- scripts/tile_timeline.py
+__device__ unsigned long long zira_block_times[4 * 8192];
+#define BTIME_DECL unsigned long long bt_0 = wall_clock64(), bt_1 = 0
+#define BTIME_MARK bt_1 = wall_clock64()
+#define BTIME_FLUSH(kind)                                                                                         \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                              \
+            zira_block_times[blockIdx.x * 4 + 0] = bt_0;                                                          \
+            zira_block_times[blockIdx.x * 4 + 1] = bt_1;                                                          \
+            zira_block_times[blockIdx.x * 4 + 2] = wall_clock64();                                                \
+            zira_block_times[blockIdx.x * 4 + 3] = (unsigned long long)(kind) |                                   \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) |                            \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16);                            \
+        }                                                                                                         \
+    } while (0)
+#define ZIRA_DEV_BTIME_READER                                                                                       \
+    extern "C" int zira_dev_read_block_times(unsigned long long *host, int n)                                       \
+    {                                                                                                               \
+        return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(zira_block_times), sizeof(unsigned long long) * n);        \
+    }
+#else
+#define BTIME_DECL
+#define BTIME_MARK
+#define BTIME_FLUSH(kind)
+#define ZIRA_DEV_BTIME_READER
+#endif
+
 #endif

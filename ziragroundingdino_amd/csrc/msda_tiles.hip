@@ -588,11 +588,13 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
     const uint4 *__restrict__ recs, float *__restrict__ dump, float *__restrict__ partial, float *__restrict__ grad_value,
     const HomeArgs HA)
 {
+    BTIME_DECL;
     if (blockIdx.x >= HA.nacc) {
         const ItemId id = lean_item(HA.nitems, HA.per_xcd, HA.Qdiv, HA.Mdiv, blockIdx.x - HA.nacc, NTHR / 64);
         if (!id.ok) return;  // wave-uniform
         bwd_home_item<2>(grad_out, HA.value, HA.shapes, HA.start, HA.loc, HA.attn, HA.S, HA.Mdiv.d, HA.LP, HA.invP, id,
                          HA.grad_loc, HA.grad_attn);
+        BTIME_FLUSH(2);
         return;
     }
     constexpr unsigned D = 32, LPS = 8, NW = NTHR / 64, NG = 8;
@@ -744,6 +746,7 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
     Raw ra = fetch(it, 0), rb = fetch(it, 1), rc = fetch(it, 2), rd = fetch(it, 3);
     Item nx = make_item(h1);
     __syncthreads();   // (the accumulators are clear)
+    BTIME_MARK;
     TSTAMP(0);
     for (unsigned i = 0;; ++i) {
         const bool more = i + 1 < cnt;
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
         nx = make_item(h2);
     }
     TSTAMP_FLUSH;
+    BTIME_FLUSH(1);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -965,3 +969,4 @@ int tiles_backward_planned_f32(const float *grad_out, const float *value, const 
 }  // namespace zira
 
 ZIRA_DEV_STAMP_READERS
+ZIRA_DEV_BTIME_READER
