@@ -528,6 +528,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU, each on the cores of its GPU's NUMA node -- set BEFORE the first GPU call (the eagerly launched
+    # encoder pieces are host-sensitive, and eight unpinned ranks share and migrate across cores)
+    from ziragroundingdino_amd import placement
+    pinned = placement.pin_this_rank(verbose=(rank == 0 or os.environ.get("ZIRA_VERBOSE_PLACEMENT") == "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # (test hooks: ZIRA_BENCH_DEVICE pins every rank to one GPU and ZIRA_BENCH_BACKEND=gloo carries the collectives through
@@ -549,6 +553,17 @@ def main():
     from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
 
     _lib.load()  # fail loudly if the HIP extension is missing
+    if dist_on:   # the launch mode is a flag, hence the same on every rank -- checked, because ranks in different modes would
+        # still pass every collective and silently time different programs
+        flag = torch.tensor([int(args.transformer_graph)], device=dev)
+        lo, hi = flag.clone(), flag.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if int(lo) != int(hi):
+            raise SystemExit("bench.py: ranks disagree on --transformer-graph")
+    print("[bench] rank %d/%d on cuda:%d, launch mode %s, %s" % (
+        rank, world, dev_index, "graph" if args.transformer_graph else "eager",
+        "pinned to %d cores" % len(pinned) if pinned else "not pinned"), file=sys.stderr, flush=True)
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
     model.use_transformer_graph = args.transformer_graph
@@ -741,6 +756,7 @@ def main():
                 "value_is": "median of %d timed regions of %d steps in the configured launch mode (%s)"
                             % (regions, args.steps, primary_mode),
                 "trainable_values": int(trainer.flat_grad.numel()),
+                "ranks_pinned_to_numa_cores": bool(pinned),
                 "msda_kernel_variant": _lib.variant_f32(32),
             },
             "roofline": roofline,

@@ -112,7 +112,12 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
  *                             zira_msda_bwd_f32_ws; deterministic apart from the order of the LDS sums in double (no fp32
  *                             atomics anywhere).
  * The plan buffer needs no initialisation and 16-byte alignment; the backward uses a region of it as scratch (the partial
- * tiles), so a plan may serve several backward calls one after the other on a stream, not concurrently. */
+ * tiles: hence `plan` is not const there), so a plan may serve several backward calls one after the other on a stream, not
+ * concurrently.  Limits of the planned path (zira_msda_plan_bytes returns 0 beyond them and the callers take
+ * zira_msda_bwd_f32_ws): D = 32, L <= 16, and the plan kernel's LDS tables -- S / 8 + L tile counters beside 64 KB of
+ * per-thread ranks -- within 78 KB, i.e. S up to about 27 000 value rows per image (the decoder shape has 22 223).  Where the
+ * runtime refuses the kernels' dynamic-LDS opt-in, zira_msda_fwd_plan_f32 falls back to zira_msda_fwd_f32 +
+ * zira_msda_plan_f32 and those return ZIRA_MSDA_EINVAL rather than a launch error. */
 size_t zira_msda_plan_bytes(int B, int S, int M, int D, int L, int Q, int P);
 
 int zira_msda_plan_f32(const int64_t *spatial_shapes, const int64_t *level_start_index, const float *sampling_loc,
@@ -127,7 +132,7 @@ int zira_msda_bwd_planned_f32(const float *grad_out, const float *value, const i
                               const int64_t *level_start_index, const float *sampling_loc,
                               const float *attn_weight, int B, int S, int M, int D, int L, int Q, int P,
                               float *grad_value, float *grad_sampling_loc, float *grad_attn_weight,
-                              const void *plan, size_t plan_bytes, void *stream);
+                              void *plan, size_t plan_bytes, void *stream);
 
 /* float64 twins: the reference dispatches AT_DISPATCH_FLOATING_TYPES = {float, double}
  * (ms_deform_attn_cuda.cu:65, :135). */
@@ -391,6 +396,24 @@ int zira_rowgemm_f32(const zira_rowgemm_args *args, void *stream);
  * A = grad of the block's output, B = linear2.weight [d_model, d_ffn], H = relu(linear1(x)) -> C = the gradient in front of
  * the ReLU; replaces autograd's  mm + threshold_backward. */
 int zira_gemm_drelu_f32(const float *A, const float *B, const float *H, int M, int N, int K, float *C, void *stream);
+
+/* ---- fp32-accurate GEMM on the bf16 matrix cores for products with FROZEN weights -------------------
+ * C[M, N] = epilogue(A[M, K] * B^T) for the image-token rows times a frozen weight (reference FFN
+ * transformer_for_adapter.py:877-886, its backward under the freeze of groundingdino_dual_zero_rep_branch.py:722-745;
+ * stands for F.linear / autograd's mm there).  Every fp32 number is exactly a1 + a2 + a3 with a_i bfloat16; the six
+ * product terms a_i b_j with i + j <= 4 reproduce a b to 2^-26 |a b|, each product exact and the sums in fp32 inside
+ * the matrix core (csrc/gemm_bf16x3.hip).
+ *   zira_split_bf16x3_f32: w [rows, cols] fp32 row-major -> planes [3][N][K] bfloat16 (3 * rows * cols * 2 bytes, 16-byte
+ *     aligned) with B[n][k] = w[n][k] (transpose = 0: N = rows, K = cols) or w[k][n] (transpose = 1: N = cols, K = rows).
+ *     Done once per weight version.
+ *   zira_gemm_bf16x3_f32: A [M, K] fp32 row-major, b_planes from the call above, C [M, N] row-major; N % 128 == 0,
+ *     K % 32 == 0, all pointers 16-byte aligned.  epilogue 0: + bias[N];  1: + bias[N], ReLU;  2: where aux[M, N] > 0, else 0
+ *     (the ReLU gradient of the FFN backward, aux = the saved activations);  3: + aux[M, N] (aux may be C itself: the
+ *     gradient that reaches the input through the residual connection).  Non-finite A gives NaN.
+ * Return 0, a hipError_t, or -1 for unsupported arguments.  Device pointers; enqueue only. */
+int zira_split_bf16x3_f32(const float *w, int rows, int cols, int transpose, void *planes, void *stream);
+int zira_gemm_bf16x3_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
+                         const float *aux, float *C, void *stream);
 
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):

@@ -26,11 +26,11 @@ for rep in range(4):
     for (cv, cl, ca, cg), p in zip(copies, plans):
         keep.append(_C.ms_deform_attn_backward(cv, sh, st, cl, ca, cg, 64, plan=p))
 torch.cuda.synchronize()
-n = 4 * 8192
+n = 8 * 8192
 buf = (ctypes.c_ulonglong * n)()
 lib.zira_dev_read_block_times.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.zira_dev_read_block_times(buf, n) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
 a = a[a[:, 2] > 0]
 kind, xcc = a[:, 3] & 255, (a[:, 3] >> 8) & 15
 t0 = a[:, 0].min()
@@ -45,6 +45,18 @@ print("accumulate: busy       ", pct((acc[:, 2] - acc[:, 0]) / 100.0))
 print("gather:     start      ", pct(us(gat[:, 0])))
 print("gather:     end        ", pct(us(gat[:, 2])))
 print("gather:     duration   ", pct((gat[:, 2] - gat[:, 0]) / 100.0))
+if len(acc):   # what an accumulate block's time is made of: least squares over the blocks
+    items, empty = (acc[:, 4] & 0xFFFFFFFF).astype(float), (acc[:, 4] >> 32).astype(float)
+    steps, shares = (acc[:, 5] & 0xFFFFFFFF).astype(float), (acc[:, 5] >> 32).astype(float)
+    busy = (acc[:, 2] - acc[:, 1]) / 100.0      # first step -> end
+    X = np.stack([np.ones_like(items), items - empty, empty, steps, shares], 1)
+    coef, *_ = np.linalg.lstsq(X, busy, rcond=None)
+    print("busy after the prologue ~ %.2f + %.2f per non-empty item + %.2f per empty tile + %.2f per block step + %.2f per share  (rms residual %.2f us)"
+          % (*coef, float(np.sqrt(np.mean((X @ coef - busy) ** 2)))))
+    print("items per block:", pct(items), " steps per block:", pct(steps))
+    order = np.argsort(-busy)
+    for i in list(order[:5]) + list(order[-5:]):
+        print("   busy %5.1f  items %3d (empty %3d)  steps %3d  shares %d" % (busy[i], items[i], empty[i], steps[i], shares[i]))
 edges = np.arange(0, us(a[:, 2].max()) + 2.0, 2.0)
 print("per 2 us: gather blocks started / accumulate blocks ended")
 hs, _ = np.histogram(us(gat[:, 0]), edges)

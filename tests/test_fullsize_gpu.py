@@ -55,14 +55,21 @@ def count_forward_calls(monkeypatch, fn_class, counts, key):
     monkeypatch.setattr(fn_class, "forward", staticmethod(counted))
 
 
-@pytest.mark.parametrize("frozen", [False, True], ids=["trainable", "frozen"])
-def test_full_size_transformer_matches_reference(monkeypatch, frozen):
+@pytest.mark.parametrize("frozen,arith", [(False, "f32"), (True, "f32"), (True, "bf16x3")], ids=["trainable", "frozen", "frozen_bf16x3"])
+def test_full_size_transformer_matches_reference(monkeypatch, frozen, arith):
     """``frozen``: every parameter with requires_grad = False, as in every ZiRa task (reference
     groundingdino_dual_zero_rep_branch.py:722-745) and in bench.py -- the layers then run as the package's one-node forms
     (decoder_layer.py, encoder_layer.py, the frozen FFN + LayerNorm node, the decoder glue node); with trainable weights those
     nodes decline and the module composition runs.  The fixture's gradients are with respect to the inputs only, so both
-    variants are held to the same reference outputs (transformer_for_adapter.py:910-1073, :809-907)."""
-    from ziragroundingdino_amd import decoder_layer, encoder_layer
+    variants are held to the same reference outputs (transformer_for_adapter.py:910-1073, :809-907).
+    ``arith`` = "bf16x3": the encoder FFN's four products per layer on the bf16 matrix cores in split-bf16 arithmetic
+    (csrc/gemm_bf16x3.hip) -- same bars."""
+    from ziragroundingdino_amd import decoder_layer, encoder_layer, gemm_bf16x3
+
+    monkeypatch.setattr(transformer.Switches, "gemm_arith", arith)
+    real_gemm = gemm_bf16x3.gemm
+    split_gemms = []
+    monkeypatch.setattr(gemm_bf16x3, "gemm", lambda *a, **k: (split_gemms.append(1), real_gemm(*a, **k))[1])
 
     g = torch.load(os.path.join(HERE, "golden", "full_transformer.pt"), weights_only=False)
     tr = attach_heads(transformer.Transformer(**g["kwargs"]), utils.MLP, utils.ContrastiveEmbed)
@@ -132,6 +139,7 @@ def test_full_size_transformer_matches_reference(monkeypatch, frozen):
 
     monkeypatch.setattr(torch, "topk", topk_like_reference)
     counts.clear()
+    del split_gemms[:]
     (hs, refs, hs_enc, ref_enc, init_box, _), text_dict = run()
     assert torch.equal(tr.last_topk_proposals.cpu(), want_all)
     close(text_dict["encoded_text"], g["memory_text"], TOL, "memory_text")
@@ -158,6 +166,7 @@ def test_full_size_transformer_matches_reference(monkeypatch, frozen):
         assert counts == {"decoder_layer": 6, "decoder_glue": 6, "encoder_attention": 6, "encoder_ffn": 6}, counts
     else:
         assert counts == {}, counts
+    assert len(split_gemms) == (24 if arith == "bf16x3" else 0)     # four products per encoder FFN, forward + backward
 
 
 def test_swin_b_bf16_training_steps_full_size():

@@ -523,10 +523,17 @@ def test_add_layer_norm_equals_add_then_norm():
     assert torch.equal(LayerNorm(256).cuda().add_norm(small, small), LayerNorm(256).cuda()(small + small))
 
 
-def test_state_dict_loaded_after_capture_reaches_the_graphs():
+@pytest.mark.parametrize("graph_all", [False, True], ids=["default_pieces", "encoder_and_fusion_graphed"])
+def test_state_dict_loaded_after_capture_reaches_the_graphs(graph_all, monkeypatch):
     """A replayed hipGraph re-runs no Python: buffers derived from parameters (the MSDA modules' concatenated query
-    projection) must follow a ``load_state_dict`` into a live model whose graphs exist already.  Two models, A stepped
-    (graphs captured), then B's weights loaded into A: A's next loss must be the one B computes eagerly."""
+    projection, the decoder layers' transposed weights, the fusion blocks' composed text-side matrices) must follow a
+    ``load_state_dict`` into a live model whose graphs exist already.  Two models, A stepped (graphs captured), then B's
+    weights loaded into A: A's next loss must be the one B computes eagerly.  ``graph_all``: with the encoder pieces and the
+    fusion blocks replayed too (supported switches; the composed text side then has no Python key check per step)."""
+    from ziragroundingdino_amd.graphs import GraphedTransformer
+    if graph_all:
+        monkeypatch.setattr(GraphedTransformer, "graph_encoder", True)
+        monkeypatch.setattr(GraphedTransformer, "graph_fusion", True)
     a, b = small_model().train(), small_model().train()
     with torch.no_grad():
         for p in b.transformer.parameters():     # B: every transformer weight moved (incl. sampling_offsets / attention_weights)

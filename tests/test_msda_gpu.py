@@ -661,3 +661,25 @@ def test_fused_forward_plan_and_planned_backward_other_shapes(oracle, name, B, Q
     _close(v.grad, want[0], 2e-5, "grad_value")
     _close(lo.grad.cpu().numpy() * ok[..., None], want[1] * ok[..., None], 2e-5, "grad_loc")
     _close(at.grad, want[2], 2e-5, "grad_attn")
+
+
+def test_a_plan_serves_only_the_tensors_it_was_made_from():
+    """The plan holds every sample's tile and every record's attention weight: `ms_deform_attn_backward(plan=...)` refuses a
+    plan made for other sampling locations / attention weights of the same shape, and one whose tensors were modified in
+    place since (the autograd Function's saved tensors are version-checked by autograd; the plan rides beside them)."""
+    from ziragroundingdino_amd import _C
+
+    B, Q, M, D, shapes, P = 2, 64, 8, 32, [(12, 17), (6, 9), (3, 5), (2, 3)], 4
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=41)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn, tgo = map(t, (value, sh, start, loc, attn, go))
+    if not _C.plan_applies(v, tsh, tst, tloc, 64):
+        pytest.skip("no planned path for this call")
+    out, plan = _C.ms_deform_attn_forward_plan(v, tsh, tst, tloc, tattn, 64)
+    _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo, 64, plan=plan)            # its own tensors: fine
+    other = tloc.clone()
+    with pytest.raises(RuntimeError, match="plan was made for other"):
+        _C.ms_deform_attn_backward(v, tsh, tst, other, tattn, tgo, 64, plan=plan)
+    tattn.mul_(0.5)                                                                       # in place: the records hold the old weights
+    with pytest.raises(RuntimeError, match="plan was made for other"):
+        _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo, 64, plan=plan)

@@ -307,8 +307,11 @@ def test_two_training_steps_at_the_native_nodes_size_match_reference(msda_backen
         out = trainer.run_step(data)
         for k, v in out.items():
             close(v, g["steps"][it]["loss_dict"][k], 1e-4, "step %d %s" % (it, k))
+    # (AdamW's first steps move every element by ~ lr * g / |g|: an element whose gradient is at rounding level -- the 5440-token
+    #  reductions of this fixture are summed in different orders on the two sides -- can move by a visibly different fraction of
+    #  lr = 1e-3; north_star's 1e-3, where the small fixture holds 1e-4)
     for n in g["trainable_names"]:
-        close(named[n], g["steps"][1]["params_after"][n], 1e-4, "param after 2 steps " + n)
+        close(named[n], g["steps"][1]["params_after"][n], 1e-4 if dev == "cpu" else 1e-3, "param after 2 steps " + n)
     if dev == "cpu":
         assert counts == {}, counts
     else:     # (a replayed graph re-runs no Python: at least the capture passes count)

@@ -137,6 +137,13 @@ def _plan_dims(value, spatial_shapes, level_start_index, sampling_loc, im2col_st
     return (dims, nbytes) if nbytes else None
 
 
+def _plan_key(sampling_loc, attn_weight):
+    """What a plan was made from: it holds the tile of every sample and the attention weight of every record, so it serves the
+    backward of exactly these two tensors in exactly this state."""
+    return (sampling_loc.data_ptr(), sampling_loc._version, tuple(sampling_loc.shape),
+            attn_weight.data_ptr(), attn_weight._version)
+
+
 def plan_applies(value, spatial_shapes, level_start_index, sampling_loc, im2col_step):
     """True where ``ms_deform_attn_forward_plan`` / ``ms_deform_attn_plan`` return a plan: sparse float32 calls on the
     GPU (decoder cross-attention) with D = 32; False for CPU tensors, dense calls, other dtypes / widths."""
@@ -161,6 +168,7 @@ def ms_deform_attn_plan(value, spatial_shapes, level_start_index, sampling_loc, 
         rc = lib.zira_msda_plan_f32(spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                                     attn_weight.data_ptr(), *dims, plan.data_ptr(), nbytes, _stream())
     _raise_on(rc, "ms_deform_attn_plan")
+    plan.zira_plan_key = _plan_key(sampling_loc, attn_weight)
     return plan
 
 
@@ -182,6 +190,7 @@ def ms_deform_attn_forward_plan(value, spatial_shapes, level_start_index, sampli
                                         sampling_loc.data_ptr(), attn_weight.data_ptr(), *dims, out.data_ptr(),
                                         plan.data_ptr(), nbytes, _stream())
     _raise_on(rc, "ms_deform_attn_forward_plan")
+    plan.zira_plan_key = _plan_key(sampling_loc, attn_weight)
     return out, plan
 
 
@@ -206,6 +215,10 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         if value.dtype != torch.float32 or plan.dtype != torch.uint8 or not plan.is_cuda \
                 or plan.numel() < _plan_bytes(lib, B, S, M, D, L, Q, P) or not _plan_bytes(lib, B, S, M, D, L, Q, P):
             raise RuntimeError("ms_deform_attn_backward: plan does not belong to this call")
+        key = getattr(plan, "zira_plan_key", None)   # (a plan made through this module; a raw buffer filled through the C ABI has none)
+        if key is not None and key != _plan_key(sampling_loc, attn_weight):
+            raise RuntimeError("ms_deform_attn_backward: the plan was made for other sampling locations / attention weights "
+                               "(or they were modified in place since): its tiles and record weights do not fit this call")
         with torch.cuda.device(value.device), _Timed("bwd", (B, S, M, D, L, Q, P)):
             rc = lib.zira_msda_bwd_planned_f32(*args, plan.data_ptr(), plan.numel(), _stream())
         _raise_on(rc, "ms_deform_attn_backward")

@@ -23,6 +23,7 @@ SYMBOLS = (
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32", "zira_window_attn_bf16",
     "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_ld_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32", "zira_gemm_drelu_f32",
     "zira_rowgemm_f32", "zira_box_refine_fwd_f32", "zira_box_refine_bwd_f32", "zira_decoder_prep_f32",
+    "zira_split_bf16x3_f32", "zira_gemm_bf16x3_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
 
@@ -147,6 +148,10 @@ def load():
     lib.zira_msda_sampling_bwd_f32.restype = i
     lib.zira_gemm_drelu_f32.argtypes = [vp, vp, vp, i, i, i, vp, vp]
     lib.zira_gemm_drelu_f32.restype = i
+    lib.zira_split_bf16x3_f32.argtypes = [vp, i, i, i, vp, vp]
+    lib.zira_split_bf16x3_f32.restype = i
+    lib.zira_gemm_bf16x3_f32.argtypes = [vp, vp, i, i, i, i, vp, vp, vp, vp]
+    lib.zira_gemm_bf16x3_f32.restype = i
     lib.zira_sine_embed_f32.argtypes = [vp, vp, ll, i, i, f32, vp, vp]
     lib.zira_sine_embed_f32.restype = i
     lib.zira_msda_version.restype = ctypes.c_char_p

@@ -55,17 +55,20 @@ __device__ unsigned long long zira_plan_stamps[16 * 2048];
 #if ZIRA_DEV_BTIMES
 #include <hip/hip_runtime.h>
 // absolute block times (100 MHz wall clock): start, a mark, end, kind | XCC id << 8 | HW_ID << 16 -- scripts/tile_timeline.py
-__device__ unsigned long long zira_block_times[4 * 8192];
-#define BTIME_DECL unsigned long long bt_0 = wall_clock64(), bt_1 = 0
+__device__ unsigned long long zira_block_times[8 * 8192];
+#define BTIME_DECL unsigned long long bt_0 = wall_clock64(), bt_1 = 0, bt_x = 0, bt_y = 0
+#define BTIME_NOTE(x, y) do { bt_x += (x); bt_y += (y); } while (0)
 #define BTIME_MARK bt_1 = wall_clock64()
 #define BTIME_FLUSH(kind)                                                                                         \
     do {                                                                                                          \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
         if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                              \
-            zira_block_times[blockIdx.x * 4 + 0] = bt_0;                                                          \
-            zira_block_times[blockIdx.x * 4 + 1] = bt_1;                                                          \
-            zira_block_times[blockIdx.x * 4 + 2] = wall_clock64();                                                \
-            zira_block_times[blockIdx.x * 4 + 3] = (unsigned long long)(kind) |                                   \
+            zira_block_times[blockIdx.x * 8 + 0] = bt_0;                                                          \
+            zira_block_times[blockIdx.x * 8 + 1] = bt_1;                                                          \
+            zira_block_times[blockIdx.x * 8 + 2] = wall_clock64();                                                \
+            zira_block_times[blockIdx.x * 8 + 4] = bt_x;                                                          \
+            zira_block_times[blockIdx.x * 8 + 5] = bt_y;                                                          \
+            zira_block_times[blockIdx.x * 8 + 3] = (unsigned long long)(kind) |                                   \
                 ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) |                            \
                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16);                            \
         }                                                                                                         \
@@ -78,6 +81,7 @@ __device__ unsigned long long zira_block_times[4 * 8192];
 #else
 #define BTIME_DECL
 #define BTIME_MARK
+#define BTIME_NOTE(x, y)
 #define BTIME_FLUSH(kind)
 #define ZIRA_DEV_BTIME_READER
 #endif

@@ -1542,7 +1542,7 @@ namespace {
 // (b, q, m); every sample, also those outside the window, whose gradients are zero), grad_value from the plan's tiles -- one launch.
 int planned_backward(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start, const float *loc,
                      const float *attn, int B, int S, int M, int D, int L, int Q, int P, float *gv, float *gl, float *ga,
-                     const void *plan, size_t plan_bytes, hipStream_t st)
+                     void *plan, size_t plan_bytes, hipStream_t st)
 {
     if (D != 32 || !lean_ok(B, S, M, D, L, Q, P)) return -1;
     return zira::tiles_backward_planned_f32(grad_out, value, shapes, start, loc, attn, B, S, M, D, L, Q, P, gv, gl, ga, plan,
@@ -1708,7 +1708,7 @@ int zira_msda_fwd_plan_f32(const float *value, const int64_t *shapes, const int6
 
 int zira_msda_bwd_planned_f32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
                               const float *loc, const float *attn, int B, int S, int M, int D, int L, int Q, int P,
-                              float *gv, float *gl, float *ga, const void *plan, size_t plan_bytes, void *stream)
+                              float *gv, float *gl, float *ga, void *plan, size_t plan_bytes, void *stream)
 {
     if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !grad_out || !gv || !gl || !ga || !plan)
         return ZIRA_MSDA_EINVAL;

@@ -271,6 +271,61 @@ __device__ __forceinline__ void bwd_home_item(const float *__restrict__ grad_out
     }
 }
 
+// Two items by one wave, their loads interleaved: the item is a chain of two dependent round trips (locations / weights, then
+// the corner rows), and inside msda_bwd_tile_accum the gather waves run at four waves per SIMD beside the accumulate blocks --
+// too few to hide it (scripts/tile_timeline.py: a gather block took 3.6 us with cold operands, 2.2 warm).  Both items' sixteen
+// row gathers are in flight together (128 bytes per lane).  id0.ok; id1.ok may be false (wave-uniform): then item 0 alone.
+template <int CQR>
+__device__ __forceinline__ void bwd_home_item2(const float *__restrict__ grad_out, const float *__restrict__ value,
+                                               const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                               const float *__restrict__ loc, const float *__restrict__ attn, unsigned S, unsigned M,
+                                               unsigned LP, float invP, const ItemId id0, const ItemId id1,
+                                               float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+{
+    constexpr unsigned D = 16 * CQR, CQ = 4 * CQR, SLOTS = 64 / CQ, NI = CQ;
+    if (!id1.ok) {
+        bwd_home_item<CQR>(grad_out, value, shapes, start, loc, attn, S, M, LP, invP, id0, grad_loc, grad_attn);
+        return;
+    }
+    const unsigned lane = threadIdx.x & 63;
+    const float *vb0 = value + (size_t)id0.b * S * M * D, *vb1 = value + (size_t)id1.b * S * M * D;
+    const float4 g0 = *reinterpret_cast<const float4 *>(grad_out + (size_t)id0.item * D + (lane % CQ) * 4);
+    const float4 g1 = *reinterpret_cast<const float4 *>(grad_out + (size_t)id1.item * D + (lane % CQ) * 4);
+    const unsigned slot = lane / CQ, cq = lane % CQ;
+    const int bp = (int)(slot * 4), back = (int)((lane % SLOTS) * CQ * 4);
+    for (unsigned s0 = 0; s0 < LP; s0 += 16) {
+        const unsigned s = s0 + (lane >> 2);
+        const Entry k0 = entry_setup<true>(shapes, start, loc + (size_t)id0.item * LP * 2, attn + (size_t)id0.item * LP, s,
+                                           lane & 3, LP, invP, M, D, id0.m);
+        const Entry k1 = entry_setup<true>(shapes, start, loc + (size_t)id1.item * LP * 2, attn + (size_t)id1.item * LP, s,
+                                           lane & 3, LP, invP, M, D, id1.m);
+        float4 v0[NI], v1[NI];
+#pragma unroll
+        for (unsigned j = 0; j < NI; ++j) {
+            const unsigned o0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)(j * SLOTS * 4), (int)k0.offb);
+            const unsigned o1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp + (int)(j * SLOTS * 4), (int)k1.offb);
+            v0[j] = load_row16(vb0, o0 + cq * 16);
+            v1[j] = load_row16(vb1, o1 + cq * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (unsigned j = 0; j < NI; ++j) {
+            float d0 = v0[j].x * g0.x, d1 = v1[j].x * g1.x;
+            d0 = fmaf(v0[j].y, g0.y, d0); d1 = fmaf(v1[j].y, g1.y, d1);
+            d0 = fmaf(v0[j].z, g0.z, d0); d1 = fmaf(v1[j].z, g1.z, d1);
+            d0 = fmaf(v0[j].w, g0.w, d0); d1 = fmaf(v1[j].w, g1.w, d1);
+            d0 = sum_over_row_lanes<CQ>(d0);
+            d1 = sum_over_row_lanes<CQ>(d1);
+            const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d0)));
+            const float t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_int(d1)));
+            if (lane / SLOTS == j) { m0 = t0; m1 = t1; }
+        }
+        store_sample_grads(k0, k0.inb ? m0 : 0.f, lane, s, LP, grad_loc + (size_t)id0.item * LP * 2, grad_attn + (size_t)id0.item * LP);
+        store_sample_grads(k1, k1.inb ? m1 : 0.f, lane, s, LP, grad_loc + (size_t)id1.item * LP * 2, grad_attn + (size_t)id1.item * LP);
+    }
+}
+
 }  // namespace
 
 #endif

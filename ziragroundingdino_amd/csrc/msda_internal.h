@@ -33,7 +33,7 @@ int tiles_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t 
 // all three gradients: the gather half (grad_sampling_loc / grad_attn_weight) rides in the accumulate launch
 int tiles_backward_planned_f32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
                                const float *loc, const float *attn, int B, int S, int M, int D, int L, int Q, int P,
-                               float *grad_value, float *grad_loc, float *grad_attn, const void *plan, size_t plan_bytes,
+                               float *grad_value, float *grad_loc, float *grad_attn, void *plan, size_t plan_bytes,
                                hipStream_t st);
 
 }  // namespace zira

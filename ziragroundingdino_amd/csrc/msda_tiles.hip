@@ -72,6 +72,12 @@
 #ifndef ZIRA_TILE_SLOTS_PER_CU
 #define ZIRA_TILE_SLOTS_PER_CU 4    // ... of the four that fit (LDS, registers): the fourth is where the gather blocks pass through
 #endif
+#ifndef ZIRA_HOME_ITEMS_PER_WAVE
+#define ZIRA_HOME_ITEMS_PER_WAVE 1   // (b, q, m) items a gather wave of msda_bwd_tile_accum takes (1; 2: their loads interleaved)
+#endif
+#ifndef ZIRA_TILE_MIX_ORDER
+#define ZIRA_TILE_MIX_ORDER 1        // every other accumulate block walks its items light-first (see msda_bwd_tile_accum)
+#endif
 #ifndef ZIRA_TILE_ROWS
 #define ZIRA_TILE_ROWS 16      // pixel rows of a tile (x 8 columns)
 #endif
@@ -590,10 +596,20 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
 {
     BTIME_DECL;
     if (blockIdx.x >= HA.nacc) {
-        const ItemId id = lean_item(HA.nitems, HA.per_xcd, HA.Qdiv, HA.Mdiv, blockIdx.x - HA.nacc, NTHR / 64);
+        // (ZIRA_HOME_ITEMS_PER_WAVE = 2: a wave takes two neighbouring queries of a head and interleaves their loads,
+        //  csrc/msda_fwd_lean.h bwd_home_item2 -- measured equal to one item per wave)
+        constexpr unsigned IPW = ZIRA_HOME_ITEMS_PER_WAVE, WPB = NTHR / 64;
+        const unsigned w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (IPW - 1);   // wave w -> slots IPW w, IPW w + 1
+        const ItemId id = lean_item(HA.nitems, HA.per_xcd, HA.Qdiv, HA.Mdiv, blockIdx.x - HA.nacc, WPB * IPW, w0);
         if (!id.ok) return;  // wave-uniform
-        bwd_home_item<2>(grad_out, HA.value, HA.shapes, HA.start, HA.loc, HA.attn, HA.S, HA.Mdiv.d, HA.LP, HA.invP, id,
-                         HA.grad_loc, HA.grad_attn);
+        if (IPW == 2) {
+            const ItemId id1 = lean_item(HA.nitems, HA.per_xcd, HA.Qdiv, HA.Mdiv, blockIdx.x - HA.nacc, WPB * IPW, w0 + 1);
+            bwd_home_item2<2>(grad_out, HA.value, HA.shapes, HA.start, HA.loc, HA.attn, HA.S, HA.Mdiv.d, HA.LP, HA.invP, id, id1,
+                              HA.grad_loc, HA.grad_attn);
+        } else {
+            bwd_home_item<2>(grad_out, HA.value, HA.shapes, HA.start, HA.loc, HA.attn, HA.S, HA.Mdiv.d, HA.LP, HA.invP, id,
+                             HA.grad_loc, HA.grad_attn);
+        }
         BTIME_FLUSH(2);
         return;
     }
@@ -659,7 +675,13 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
 #pragma unroll
     for (unsigned kk = 0; kk < 4; ++kk) lbk[kk] = lb + (odd ? kAccWord[kk ^ kSwap] : kAccWord[kk]) * 8u;
 
-    auto load_hdr = [&](unsigned i) {   // item i of this block: ring position k + i nbg -> (class, unit, position in the unit's class items)
+    // Every block's list runs from heavy items (many block steps, LDS-bound) to light ones (a step or none: 16 KB of stores
+    // each, bound by the chip's write bandwidth -- scripts/tile_timeline.py: ~3 us per item whatever its size, 0.5 us per
+    // step); with all blocks walking it the same way the stores of a launch pile up in its second half.  Every other block
+    // of a group walks its list backwards.
+    const bool backwards = ZIRA_TILE_MIX_ORDER && (k & 1u);
+    auto load_hdr = [&](unsigned ii) {   // the ii-th item this block takes: ring position k + i nbg -> (class, unit, position in the unit's class items)
+        const unsigned i = backwards ? cnt - 1u - ii : ii;
         const unsigned r = i * G.nbg + ((i & 1u) ? G.nbg - 1u - k : k);
         unsigned e;
         if (ne <= 64) {
@@ -754,6 +776,7 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
         const Raw na = fetch(nx, 0), nb = fetch(nx, 1), nc = fetch(nx, 2), nd = fetch(nx, 3);
         // (wave w holds records 8 w .. 8 w + 7 of every SPB: a wave without records at a step skips it)
         const unsigned nsteps = it.n > wave * NG ? (it.n - wave * NG + SPB - 1) / SPB : 0u;
+        BTIME_NOTE(1u | ((it.n ? 0ull : 1ull) << 32), (it.n + SPB - 1) / SPB | ((unsigned long long)(it.share ? 1u : 0u) << 32));
         float4 g0 = row_of(it, ra), g1 = row_of(it, rb);
         for (unsigned s = 0; s < nsteps; s += 2) {   // (two copies of the body per round)
             const float4 g2 = row_of(it, rc);
@@ -892,6 +915,20 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     return true;
 }
 
+// Dynamic LDS above 48 KB is an opt-in on runtimes that enforce the default limit (the plan kernels take up to 78 KB, 77 KB
+// at the decoder shape): declared once per kernel; a refusal turns the planned path off (-1: the callers fall back).
+template <typename K>
+inline bool allow_lds(K kernel, size_t bytes, bool &done)
+{
+    if (done || bytes <= 48 * 1024) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    done = true;
+    return true;
+}
+
 inline PlanPtrs plan_ptrs(const TilesLayout &T, void *plan)
 {
     char *w = reinterpret_cast<char *>(plan);
@@ -920,6 +957,8 @@ int tiles_plan_f32(const int64_t *shapes, const int64_t *start, const float *loc
     TilesLayout T;
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
     const PlanPtrs W = plan_ptrs(T, plan);
+    static bool lds_one = false, lds_two = false;   // (one device per process)
+    if (!(T.one_pass ? allow_lds(msda_plan<true>, 78 * 1024, lds_one) : allow_lds(msda_plan<false>, 78 * 1024, lds_two))) return -1;
     if (T.one_pass)
         hipLaunchKernelGGL(msda_plan<true>, dim3(T.units), dim3(kPlanThreads), T.lds_plan, st, shapes, start, loc, attn, T.G, W);
     else
@@ -934,6 +973,8 @@ int tiles_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t 
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
     if ((unsigned long long)B * Q * M >= (1ull << 31) || L * P > 64) return -1;
     const PlanPtrs W = plan_ptrs(T, plan);
+    static bool lds_ok = false;
+    if (!allow_lds(msda_fwd_plan, 78 * 1024, lds_ok)) return -1;
     const unsigned nitems = (unsigned)B * Q * M, per = (nitems + 7) >> 3, wpb = kPlanThreads / 64;
     const unsigned units8 = (T.units + 7) & ~7u;
     const unsigned grid = units8 + 8 * ((per + wpb - 1) / wpb);
@@ -945,19 +986,19 @@ int tiles_fwd_plan_f32(const float *value, const int64_t *shapes, const int64_t 
 
 int tiles_backward_planned_f32(const float *grad_out, const float *value, const int64_t *shapes, const int64_t *start,
                                const float *loc, const float *attn, int B, int S, int M, int D, int L, int Q, int P, float *gv,
-                               float *gl, float *ga, const void *plan, size_t plan_bytes, hipStream_t st)
+                               float *gl, float *ga, void *plan, size_t plan_bytes, hipStream_t st)
 {
     TilesLayout T;
     if (!make_tiles_layout(B, S, M, D, L, Q, P, T) || !plan || plan_bytes < T.total || ((uintptr_t)plan & 15)) return -1;
-    const PlanPtrs W = plan_ptrs(T, const_cast<void *>(plan));
-    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<void *>(plan)) + T.off_dump);
+    const PlanPtrs W = plan_ptrs(T, plan);
+    float *dump = reinterpret_cast<float *>(reinterpret_cast<char *>(plan) + T.off_dump);
     if ((unsigned long long)B * Q * M >= (1ull << 31) || L * P > 64) return -1;
     HomeArgs HA;
     HA.value = value; HA.loc = loc; HA.attn = attn; HA.shapes = shapes; HA.start = start; HA.grad_loc = gl; HA.grad_attn = ga;
     HA.S = (unsigned)S; HA.LP = (unsigned)(L * P); HA.nitems = (unsigned)B * Q * M; HA.per_xcd = (HA.nitems + 7) >> 3;
     HA.nacc = T.grid; HA.invP = 1.0f / (float)P; HA.Mdiv = make_fast_div((unsigned)M); HA.Qdiv = make_fast_div((unsigned)Q);
     if (T.grid & 7u) return -1;   // (the gather blocks' XCD interleave starts at a multiple of 8)
-    const unsigned wpb = kAccThreads / 64;
+    const unsigned wpb = kAccThreads / 64 * ZIRA_HOME_ITEMS_PER_WAVE;   // items a gather block takes
     hipLaunchKernelGGL((msda_bwd_tile_accum<kAccThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kAccThreads),
                        T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
     hipError_t e = hipGetLastError();

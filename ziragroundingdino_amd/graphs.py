@@ -221,10 +221,11 @@ class GraphedTransformer:
         """A replay re-runs no Python, so buffers DERIVED from parameters (the MSDA modules' concatenated query
         projection) must follow in-place changes of those parameters (``copy_``, ``load_state_dict`` into a live model)
         here: cheap version check per call, refresh in place when anything moved."""
-        params = getattr(self, "_params", None)
-        if params is None:
-            params = self._params = list(self.transformer.parameters())
-        ver = sum(p._version for p in params)
+        # (the parameters are listed afresh every call: load_state_dict(assign=True) and module surgery REPLACE parameter
+        #  objects, whose versions a cached list would never see; the walk costs ~0.1 ms for the transformer's 400 tensors)
+        ver = 0
+        for p in self.transformer.parameters():
+            ver += p._version + (p.data_ptr() & 0xFFFFF)
         if ver != self._versions:
             if self._versions is not None:
                 for m in self.transformer.modules():

@@ -169,6 +169,9 @@ class Switches:
     fused_attention = True   # lean_mha: csrc/attn.hip for fp32 heads of width 32 without attention mask / dropout (the decoder's)
     fused_ffn_backward = True  # frozen FFNs: (gy @ W2) * (h > 0) in one native GEMM (csrc/gemm_drelu.hip) instead of mm + threshold_backward
     sort_for_topk = False    # select_queries: stable sort instead of torch.topk everywhere (developer switch)
+    # arithmetic of the frozen FFN products on the image-token rows: "f32" = the library's fp32 GEMMs (+ csrc/gemm_drelu.hip);
+    # "bf16x3" = fp32-accurate split-bf16 products on the bf16 matrix cores (csrc/gemm_bf16x3.hip, gemm_bf16x3.py)
+    gemm_arith = "f32"
 
 
 def _mha(mha, query, key, value, key_padding_mask=None, attn_mask=None):
@@ -199,6 +202,34 @@ class _LinearReLU(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _FFNSplit:
+    """The bf16 planes of a frozen FFN's two weights in the two orientations its forward and backward read them in
+    (gemm_bf16x3.SplitWeight: made once, refreshed in place when a parameter changes)."""
+
+    def __init__(self):
+        from .gemm_bf16x3 import SplitWeight
+        self.w1, self.w2, self.w2t, self.w1t = SplitWeight(False), SplitWeight(False), SplitWeight(True), SplitWeight(True)
+
+    def refresh(self, lin1, lin2):
+        for sw, w in ((self.w1, lin1.weight), (self.w1t, lin1.weight), (self.w2, lin2.weight), (self.w2t, lin2.weight)):
+            sw.planes(w)
+
+
+def _ffn_split(layer, x2):
+    """The layer's split weights when ``Switches.gemm_arith`` asks for the bf16x3 products and the shapes allow them, else None."""
+    if Switches.gemm_arith != "bf16x3":
+        return None
+    from . import gemm_bf16x3 as g3
+    lin1, lin2 = layer.linear1, layer.linear2
+    if not (g3.supported(x2, lin1.out_features, lin1.in_features) and lin2.out_features % 128 == 0 and lin2.in_features % 32 == 0
+            and x2.shape[0] >= 1024):
+        return None
+    sp = getattr(layer, "_ffn_split_weights", None)
+    if sp is None:
+        sp = layer._ffn_split_weights = _FFNSplit()
+    return sp
+
+
 class _FrozenFFN(torch.autograd.Function):
     """linear2(relu(linear1(x))) with FROZEN weights (every ZiRa task): bias + ReLU in the first GEMM's epilogue, and in the
     backward the product  gy @ W2  masked by  h > 0  in ONE native kernel (csrc/gemm_drelu.hip) -- the separate
@@ -206,7 +237,13 @@ class _FrozenFFN(torch.autograd.Function):
     x [N, K], W1 [F, K], W2 [K2, F]."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, split=None):
+        ctx.split = split
+        if split is not None:
+            from . import gemm_bf16x3 as g3
+            h = g3.gemm(x, split.w1.planes(w1), g3.EPI_BIAS_RELU, bias=b1)
+            ctx.save_for_backward(w1, w2, h)
+            return g3.gemm(h, split.w2.planes(w2), g3.EPI_BIAS, bias=b2)
         h = torch._addmm_activation(b1, x, w1.t())
         ctx.save_for_backward(w1, w2, h)
         return torch.addmm(b2, h, w2.t())
@@ -216,13 +253,18 @@ class _FrozenFFN(torch.autograd.Function):
         from . import _lib
         w1, w2, h = ctx.saved_tensors
         gy = gy.contiguous()
+        if ctx.split is not None:
+            from . import gemm_bf16x3 as g3
+            g = g3.gemm(gy, ctx.split.w2t.planes(w2), g3.EPI_MASK, aux=h)
+            gx = g3.gemm(g, ctx.split.w1t.planes(w1), g3.EPI_BIAS, bias=torch.zeros(w1.shape[1], device=g.device))
+            return gx, None, None, None, None, None
         g = torch.empty_like(h)
         with torch.cuda.device(h.device):
             rc = _lib.load().zira_gemm_drelu_f32(gy.data_ptr(), w2.data_ptr(), h.data_ptr(), h.shape[0], h.shape[1], gy.shape[1],
                                                  g.data_ptr(), torch.cuda.current_stream(h.device).cuda_stream)
         if rc != 0:
             raise RuntimeError("zira_gemm_drelu_f32 failed with code %d" % rc)
-        return g @ w1, None, None, None, None
+        return g @ w1, None, None, None, None, None
 
 
 class _FrozenFFNNorm(torch.autograd.Function):
@@ -232,10 +274,16 @@ class _FrozenFFNNorm(torch.autograd.Function):
     (45 MB per tensor at the encoder shape).  x [N, K]."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, eps):
+    def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, eps, split=None):
         from . import _lib
-        h = torch._addmm_activation(b1, x, w1.t())
-        y = torch.addmm(b2, h, w2.t())
+        ctx.split = split
+        if split is not None:
+            from . import gemm_bf16x3 as g3
+            h = g3.gemm(x, split.w1.planes(w1), g3.EPI_BIAS_RELU, bias=b1)
+            y = g3.gemm(h, split.w2.planes(w2), g3.EPI_BIAS, bias=b2)
+        else:
+            h = torch._addmm_activation(b1, x, w1.t())
+            y = torch.addmm(b2, h, w2.t())
         rows, C = x.shape
         out, s = torch.empty_like(x), torch.empty_like(x)
         stats = torch.empty((2, rows), device=x.device, dtype=torch.float32)
@@ -260,11 +308,15 @@ class _FrozenFFNNorm(torch.autograd.Function):
             st = torch.cuda.current_stream(s.device).cuda_stream
             rc = lib.zira_layernorm_bwd_f32(gout.data_ptr(), s.data_ptr(), ln_w.data_ptr(), stats[0].data_ptr(),
                                             stats[1].data_ptr(), rows, C, gs.data_ptr(), st)
-            if rc == 0:   # gs: the gradient of x + ffn(x), i.e. of the FFN output and of x through the residual connection
+            if rc == 0 and ctx.split is None:   # gs: the gradient of x + ffn(x), i.e. of the FFN output and of x through the residual connection
                 rc = lib.zira_gemm_drelu_f32(gs.data_ptr(), w2.data_ptr(), h.data_ptr(), rows, h.shape[1], C, g.data_ptr(), st)
         if rc != 0:
             raise RuntimeError("frozen FFN + LayerNorm backward failed with code %d" % rc)
-        return (gs.addmm_(g, w1),) + (None,) * 7   # (in place: torch.addmm(gs, ...) copies gs into its result first)
+        if ctx.split is not None:   # the same two products on the bf16 matrix cores: ReLU mask and the residual sum in their epilogues
+            from . import gemm_bf16x3 as g3
+            g3.gemm(gs, ctx.split.w2t.planes(w2), g3.EPI_MASK, aux=h, out=g)
+            return (g3.gemm(g, ctx.split.w1t.planes(w1), g3.EPI_ADD, aux=gs, out=gs),) + (None,) * 8
+        return (gs.addmm_(g, w1),) + (None,) * 8   # (in place: torch.addmm(gs, ...) copies gs into its result first)
 
 
 def _frozen_ffn_norm_ok(x, lin1, lin2, norm):
@@ -408,6 +460,14 @@ class BiMultiHeadAttention(nn.Module):
                     new = cached[1]
             cached = self._text_side = (key, new)
         return cached[1]
+
+    def refresh_fused_projection(self, *unused):
+        """The composed text-side matrices follow the six Linears in place (GraphedTransformer calls this when a parameter
+        changed: with ``graph_fusion`` a replayed block re-runs no Python, so the key check of ``_composed_text_side`` would
+        never see a weight loaded into a live model)."""
+        cached = getattr(self, "_text_side", None)
+        if cached is not None:
+            self._composed_text_side(cached[1][0])   # (any fp32 tensor on the right device re-runs the key check)
 
     def forward(self, v, l, attention_mask_v=None, attention_mask_l=None, residual_v=None):
         """v: image tokens [B, N, v_dim] (N = 22 k), l: text tokens [B, T, l_dim] (T <= 256).
@@ -634,6 +694,12 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
+    def refresh_fused_projection(self, *unused):
+        """The bf16 planes of the FFN weights (``Switches.gemm_arith`` = "bf16x3") follow the parameters in place."""
+        sp = getattr(self, "_ffn_split_weights", None)
+        if sp is not None:
+            sp.refresh(self.linear1, self.linear2)
+
     fuse_bias_relu = True   # bias + ReLU in the GEMM epilogue: -117 us per layer (scripts/enclayer_profile.py)
     native_attention = True   # frozen fp32 GPU calls without padding: the attention sublayer as one autograd node (encoder_layer.py)
 
@@ -643,10 +709,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
             x2 = src.reshape(-1, src.shape[-1])
             if self.dropout3.p == 0.0 and _frozen_ffn_norm_ok(x2, self.linear1, self.linear2, self.norm2):
                 return _FrozenFFNNorm.apply(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                                            self.norm2.weight, self.norm2.bias, self.norm2.eps).view_as(src), src.new_zeros(1)
+                                            self.norm2.weight, self.norm2.bias, self.norm2.eps,
+                                            _ffn_split(self, x2)).view_as(src), src.new_zeros(1)
             if _frozen_ffn_ok(x2, self.linear1, self.linear2):
                 src2 = _FrozenFFN.apply(x2, self.linear1.weight, self.linear1.bias, self.linear2.weight,
-                                        self.linear2.bias).view(*src.shape[:-1], -1)
+                                        self.linear2.bias, _ffn_split(self, x2)).view(*src.shape[:-1], -1)
             else:
                 h = _LinearReLU.apply(x2, self.linear1.weight, self.linear1.bias)
                 src2 = self.linear2(h.view(*src.shape[:-1], -1))
