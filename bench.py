@@ -519,6 +519,9 @@ def main():
     ap.add_argument("--regions", type=int, default=3,
                     help="timed regions of --steps steps per launch mode; the line reports the MEDIAN region (each region is "
                          "bracketed by barrier + synchronize on both sides; all of them are listed in config.launch_modes)")
+    ap.add_argument("--no-gemm-arith-mode", action="store_true",
+                    help="skip the extra timed regions with the frozen FFN products in split-bf16 arithmetic on the bf16 matrix "
+                         "cores (csrc/gemm_bf16x3.hip); `value` is always the plain fp32 arithmetic")
     ap.add_argument("--no-second-mode", action="store_true",
                     help="skip the second timed region in the other launch mode (eager <-> hipGraph replay)")
     args = ap.parse_args()
@@ -626,6 +629,18 @@ def main():
                 raise
             print("[bench] second mode skipped (%s)" % (str(e).splitlines()[0] if str(e) else repr(e)), file=sys.stderr, flush=True)
         model.use_transformer_graph = args.transformer_graph
+    # The same steps once more with the encoder FFN's frozen products in split-bf16 (bf16x3) arithmetic: fp32-accurate by the
+    # gate of tests/test_gemm_bf16x3_gpu.py, reported BESIDE the headline (config.gemm_arith), never as `value`.
+    arith_regions = None
+    if not args.no_gemm_arith_mode and args.dtype == "f32" and args.backbone == "swin_T_224_1k":
+        from ziragroundingdino_amd import transformer as _tr
+        _tr.Switches.gemm_arith = "bf16x3"
+        try:
+            run_steps(max(2, args.warmup))
+            arith_regions = [timed(args.steps) for _ in range(regions)]
+        finally:
+            _tr.Switches.gemm_arith = "f32"
+        run_steps(1)
     timing_source = "HIP events around every native MSDA call of the timed steps"
     if args.transformer_graph and args.kernel_timing_steps > 0:   # (every rank: the steps hold collectives)
         # graph replays hide the launches from event timing: the same step, launched eagerly, right after
@@ -647,6 +662,10 @@ def main():
         if rank == 0:
             replay = inmodel_replay(got, dev)
         del got
+    if dist_on and arith_regions is not None:
+        t = torch.tensor(arith_regions, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        arith_regions = [float(x) for x in t.tolist()]
     if dist_on:   # every region: the MAX over ranks
         keys = sorted(all_regions)
         t = torch.tensor([x for k in keys for x in all_regions[k]], device=dev, dtype=torch.float64)
@@ -755,6 +774,15 @@ def main():
                                  for k, v in sorted(modes.items())},
                 "value_is": "median of %d timed regions of %d steps in the configured launch mode (%s)"
                             % (regions, args.steps, primary_mode),
+                "gemm_arith": {"f32": {"images_per_s": images / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                                       "note": "the library's fp32 GEMMs: `value`"},
+                               **({"bf16x3": {"images_per_s": images / sorted(arith_regions)[len(arith_regions) // 2],
+                                              "ms_per_step": sorted(arith_regions)[len(arith_regions) // 2] / args.steps * 1e3,
+                                              "regions_ms_per_step": [x / args.steps * 1e3 for x in arith_regions],
+                                              "note": "encoder FFN products (4 per layer) as split-bf16 sums on the bf16 matrix "
+                                                      "cores, fp32-accurate against fp64 (tests/test_gemm_bf16x3_gpu.py); same "
+                                                      "launch mode as `value`; not the headline"}}
+                                  if arith_regions else {})},
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "ranks_pinned_to_numa_cores": bool(pinned),
                 "msda_kernel_variant": _lib.variant_f32(32),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev: same-box A/B of class-level switches on the replayed training step.  `python scripts/ab_step.py NAME=0|1 ...` with
-NAME in {shared_source, batch_value, native_layer, native_glue, native_attention, overlap_text, text_native, compose_text, residual_in_gemm, graph_encoder, graph_decoder}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
+NAME in {gemm_arith (f32|bf16x3), shared_source, batch_value, native_layer, native_glue, native_attention, overlap_text, text_native, compose_text, residual_in_gemm, graph_encoder, graph_decoder}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
 prints ms per step.  Run the variants alternately in ONE gpurun call, several times each: processes on one box differ by up to
 0.5 ms; two trainers in one process do not work as an A/B (the second one built is 3 ms slower whatever its switches)."""
 import os
@@ -16,9 +16,12 @@ from ziragroundingdino_amd.groundingdino import build_model  # noqa: E402
 from ziragroundingdino_amd.ms_deform_attn import MultiScaleDeformableAttention as M  # noqa: E402
 from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch  # noqa: E402
 
+n_categories = 15
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
-    if k == "shared_source":
+    if k == "categories":      # text tokens = 2 + 2 * categories (15 -> 32 ODinW-like, 96 -> 194 COCO-like)
+        n_categories = int(v)
+    elif k == "shared_source":
         M.fuse_shared_source = bool(int(v))
     elif k == "batch_value":
         zt.TransformerDecoder.batch_value_projections = bool(int(v))
@@ -36,6 +39,8 @@ for kv in sys.argv[1:]:
         zt.BiMultiHeadAttention.compose_text_side = bool(int(v))
     elif k == "residual_in_gemm":
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
+    elif k == "gemm_arith":
+        zt.Switches.gemm_arith = v
     elif k in ("graph_encoder", "graph_decoder", "graph_fusion", "graph_selection"):
         from ziragroundingdino_amd.graphs import GraphedTransformer
         setattr(GraphedTransformer, k, bool(int(v)))
@@ -45,7 +50,7 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()
 trainer = ZiraTrainer(model)
-batches = [synthetic_batch(2, 800, 1333, n_categories=15, seed=i, device=dev) for i in range(4)]
+batches = [synthetic_batch(2, 800, 1333, n_categories=n_categories, seed=i, device=dev) for i in range(4)]
 for i in range(8):
     trainer.run_step(batches[i % 4], next_data=batches[(i + 1) % 4])
 torch.cuda.synchronize()

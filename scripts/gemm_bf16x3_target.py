@@ -50,10 +50,26 @@ cases = [
     ("gs += g @ W1            [M,2048]x[2048,256]", 256, 2048, lambda: out_x.addmm_(g, w1),
      lambda: g3.gemm(g, p_w1t, g3.EPI_ADD, aux=out_x, out=out_x)),
 ]
+# the 256-wide projections of the deformable layer (value / output projections, the 384-wide query projection, their input gradients)
+wv, bv = torch.randn(256, 256, device=dev) * 0.06, torch.randn(256, device=dev)
+wq, bq = torch.randn(384, 256, device=dev) * 0.06, torch.randn(384, device=dev)
+gproj = torch.randn(M, 384, device=dev)
+p_wv, p_wvt, p_wq, p_wqt = g3.split_planes(wv, False), g3.split_planes(wv, True), g3.split_planes(wq, False), g3.split_planes(wq, True)
+out_v, out_q, acc = torch.empty(M, 256, device=dev), torch.empty(M, 384, device=dev), torch.randn(M, 256, device=dev)
+cases += [
+    ("value_proj + bias       [M,256]x[256,256]", 256, 256, lambda: torch.addmm(bv, x, wv.t()),
+     lambda: g3.gemm(x, p_wv, g3.EPI_BIAS, bias=bv, out=out_v)),
+    ("query proj + bias       [M,256]x[256,384]", 384, 256, lambda: torch.addmm(bq, x, wq.t()),
+     lambda: g3.gemm(x, p_wq, g3.EPI_BIAS, bias=bq, out=out_q)),
+    ("gx += gv @ Wv           [M,256]x[256,256]", 256, 256, lambda: acc.addmm_(gs, wv),
+     lambda: g3.gemm(gs, p_wvt, g3.EPI_ADD, aux=acc, out=acc)),
+    ("gx += gproj @ Wq        [M,384]x[384,256]", 256, 384, lambda: acc.addmm_(gproj, wq),
+     lambda: g3.gemm(gproj, p_wqt, g3.EPI_ADD, aux=acc, out=acc)),
+]
 tot = [0.0, 0.0]
 for name, N, K, ref, ours in cases:
     tr, to = timeit(ref), timeit(ours)
     tot[0] += tr; tot[1] += to
     fl = 2.0 * M * N * K
     print("%-46s library %7.1f us (%5.1f TF/s)   bf16x3 %7.1f us (%5.1f TF/s)   x%.2f" % (name, tr, fl / tr / 1e6, to, fl / to / 1e6, tr / to), flush=True)
-print("FFN forward + backward products: library %.1f us, bf16x3 %.1f us" % tuple(tot))
+print("all products: library %.1f us, bf16x3 %.1f us" % tuple(tot))

@@ -4,6 +4,9 @@
 # into gpurun_out/pmc_<tag>.txt
 tag=$1; pat=$2; shift; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
+script=$1; shift
+case "$script" in /*) ;; *) script=$root/$script ;; esac
+set -- "$script" "$@"
 out=/tmp/pmc_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

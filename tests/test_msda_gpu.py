@@ -683,3 +683,34 @@ def test_a_plan_serves_only_the_tensors_it_was_made_from():
     tattn.mul_(0.5)                                                                       # in place: the records hold the old weights
     with pytest.raises(RuntimeError, match="plan was made for other"):
         _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo, 64, plan=plan)
+
+
+@pytest.mark.parametrize("name,kw", [("inmodel", dict(inmodel=True)), ("pinpoint", dict(hot=2)), ("hot", dict(hot=True))])
+def test_shares_of_split_tiles_combine_inside_the_launch_under_load(oracle, name, kw):
+    """Heavy tiles are cut into shares whose partial tiles meet INSIDE the accumulate launch: write-through stores, an
+    agent-scope counter, the last arriver sums them (csrc/msda_tiles.hip; no fold launch since round 5).  A hand-off of this
+    kind fails -- if it fails -- rarely, under uneven load, and through STALE copies of lines an earlier call left in a cache:
+    so the same plan serves many backward calls that alternate between two gradients (a stale partial tile of the previous
+    call would carry the other gradient's sums), while a second stream keeps the memory system busy, and every grad_value
+    is compared with the oracle's, element by element."""
+    from ziragroundingdino_amd import _C
+
+    B, Q, M, D, shapes, P = 2, 900, 8, 32, NORTH_STAR_SHAPES, 4
+    value, sh, start, loc, attn, go = _random_case(B, Q, M, D, shapes, P, seed=53, **kw)
+    go2 = np.random.default_rng(54).standard_normal(go.shape).astype(np.float32) * 3.0
+    want = [oracle.msda_backward(g, value, sh, start, loc, attn)[0] for g in (go, go2)]
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    v, tsh, tst, tloc, tattn = map(t, (value, sh, start, loc, attn))
+    tgo = [t(go), t(go2)]
+    out, plan = _C.ms_deform_attn_forward_plan(v, tsh, tst, tloc, tattn, 64)
+    side = torch.cuda.Stream()
+    big = torch.empty(64 * 1024 * 1024, device=DEV)          # 256 MB: the copies below evict L2 and the Infinity Cache
+    scale = [max(1.0, float(np.abs(w).max())) for w in want]
+    for it in range(24):
+        if it % 3 != 2:                                       # two calls in three run beside a streaming copy
+            with torch.cuda.stream(side):
+                big.copy_(big.flip(0) if it % 2 else big + 1.0)
+        gv = _C.ms_deform_attn_backward(v, tsh, tst, tloc, tattn, tgo[it & 1], 64, plan=plan)[0]
+        err = float((gv - t(want[it & 1])).abs().max()) / scale[it & 1]
+        assert err < 2e-5, (name, it, err)
+    torch.cuda.synchronize()

@@ -311,7 +311,12 @@ def test_two_training_steps_at_the_native_nodes_size_match_reference(msda_backen
     #  reductions of this fixture are summed in different orders on the two sides -- can move by a visibly different fraction of
     #  lr = 1e-3; north_star's 1e-3, where the small fixture holds 1e-4)
     for n in g["trainable_names"]:
-        close(named[n], g["steps"][1]["params_after"][n], 1e-4 if dev == "cpu" else 1e-3, "param after 2 steps " + n)
+        got, want_p = named[n].detach().float().cpu(), g["steps"][1]["params_after"][n].float()
+        if dev == "cpu":
+            close(got, want_p, 1e-4, "param after 2 steps " + n)
+        else:   # 99.9 % of the elements as on the CPU; an element whose gradient is rounding noise may step the other way (2 x lr)
+            err = (got - want_p).abs() / max(1.0, float(want_p.abs().max()))
+            assert float((err <= 1e-4).float().mean()) >= 0.999 and float(err.max()) <= 2.5e-3, (n, float(err.max()))
     if dev == "cpu":
         assert counts == {}, counts
     else:     # (a replayed graph re-runs no Python: at least the capture passes count)

@@ -26,11 +26,15 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "zira_msda.h"
 
 #ifndef ZIRA_G3_CHUNK
 #define ZIRA_G3_CHUNK 32   // K depth the matrix core sums from zero before the vector unit adds it to the running sum (32, 16; 0: never)
+#endif
+#ifndef ZIRA_G3_BM192_MARGIN
+#define ZIRA_G3_BM192_MARGIN 0.05   // the 192-row tile is taken where it wastes this much less of the last round of block slots
 #endif
 #ifndef ZIRA_G3_STAGGER
 #define ZIRA_G3_STAGGER 0   // s_sleep argument (x 64 cycles) by which the block in a CU's second wave slot starts late
@@ -67,6 +71,44 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &p1, uint2 &p2, uin
     p2.y = pk_bf16(rz, rw);
     p3.x = pk_bf16(rx - bf_lo(p2.x), ry - bf_hi(p2.x));   // (the differences are exact, and fit bf16 exactly)
     p3.y = pk_bf16(rz - bf_lo(p2.y), rw - bf_hi(p2.y));
+}
+
+// The epilogue: accumulator register 4 g + i of block (ni, mi) is C[m][n], m = row (lane & 31) of the block, n = 8 g + 4 (lane >> 5) + i
+template <int MI, int NI, int EPI>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][MI], const float *__restrict__ bias, const float *aux, float *C,
+                                           int M, int N, int mbase, int nbase, int lane)
+{
+    const int lm = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mbase + mi * 32 + lm;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + ni * 32 + 8 * g + 4 * lh;
+                const f32x16 &c = acc[ni][mi];
+                float4 o = make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+                const size_t at = (size_t)m * N + n;
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
+                    o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+                    if (EPI == EPI_BIAS_RELU) {
+                        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                    }
+                } else {
+                    const float4 h = *reinterpret_cast<const float4 *>(aux + at);
+                    if (EPI == EPI_MASK) {
+                        o.x = h.x > 0.f ? o.x : 0.f; o.y = h.y > 0.f ? o.y : 0.f;
+                        o.z = h.z > 0.f ? o.z : 0.f; o.w = h.w > 0.f ? o.w : 0.f;
+                    } else {
+                        o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
+                    }
+                }
+                *reinterpret_cast<float4 *>(C + at) = o;
+            }
+    }
 }
 
 template <int BM, int EPI>
@@ -235,38 +277,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16x3_kernel(const float *_
     }
 
 #undef ZIRA_GLOAD
-    // epilogue: accumulator register 4 g + i of block (ni, mi) is C[m][n], m = row (lane & 31) of the block, n = 8 g + 4 (lane >> 5) + i
-    const int lm = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * WM + mi * 32 + lm;
-        if (m >= M) continue;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * lh;
-                const f32x16 &c = acc[ni][mi];
-                float4 o = make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
-                const size_t at = (size_t)m * N + n;
-                if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
-                    o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
-                    if (EPI == EPI_BIAS_RELU) {
-                        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-                    }
-                } else {
-                    const float4 h = *reinterpret_cast<const float4 *>(aux + at);
-                    if (EPI == EPI_MASK) {
-                        o.x = h.x > 0.f ? o.x : 0.f; o.y = h.y > 0.f ? o.y : 0.f;
-                        o.z = h.z > 0.f ? o.z : 0.f; o.w = h.w > 0.f ? o.w : 0.f;
-                    } else {
-                        o.x += h.x; o.y += h.y; o.z += h.z; o.w += h.w;
-                    }
-                }
-                *reinterpret_cast<float4 *>(C + at) = o;
-            }
-    }
+    store_tile<MI, NI, EPI>(acc, bias, aux, C, M, N, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
 // W [rows][cols] fp32 -> planes [3][N][K] bf16 with B[n][k] = W[n][k] (transpose = 0: N = rows, K = cols) or W[k][n]
@@ -293,16 +304,15 @@ template <int BM, int EPI>
 int launch(const float *a, const unsigned short *bp, const float *bias, const float *aux, float *c, int M, int N, int K, hipStream_t st)
 {
     static bool attr_set = false;   // one device per process
+    const int rt = (M + BM - 1) / BM, ct = N / kBN, per = (rt + 7) / 8;
     const size_t lds = (size_t)3 * (BM + kBN) * kRow;
+    auto kernel = gemm_bf16x3_kernel<BM, EPI>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_kernel<BM, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int rt = (M + BM - 1) / BM, ct = N / kBN, per = (rt + 7) / 8;
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, EPI>), dim3(8 * per * ct), dim3(kThreads), lds, st, a, bp, bias, aux, c, M, N, K, rt,
-                       ct, per);
+    hipLaunchKernelGGL(kernel, dim3(8 * per * ct), dim3(kThreads), lds, st, a, bp, bias, aux, c, M, N, K, rt, ct, per);
     return (int)hipGetLastError();
 }
 
@@ -346,6 +356,8 @@ extern "C" int zira_gemm_bf16x3_f32(const float *a, const void *b_planes, int M,
         const long long tiles = (long long)((M + bm - 1) / bm) * (N / kBN), rounds = (tiles + 511) / 512;
         return (double)(rounds * 512 - tiles) / (double)(rounds * 512) + (bm == 192 ? 0.0 : 0.0);
     };
-    if (waste(192) + 0.05 < waste(128)) return launch_epi<192>(epilogue, a, bp, bias, aux, c, M, N, K, stream);
+    static const int force_bm = [] { const char *e = getenv("ZIRA_G3_BM"); return e ? atoi(e) : 0; }();   // developer override
+    if (force_bm == 192 || (force_bm != 128 && waste(192) + ZIRA_G3_BM192_MARGIN < waste(128)))
+        return launch_epi<192>(epilogue, a, bp, bias, aux, c, M, N, K, stream);
     return launch_epi<128>(epilogue, a, bp, bias, aux, c, M, N, K, stream);
 }

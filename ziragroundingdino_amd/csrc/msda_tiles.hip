@@ -47,7 +47,7 @@
 //          the LDS adds -- 13 us of steps per block for 9.3 us of `ds_add_f64` issue per CU -- and the launch takes 27.8 us
 //          for both halves.)  Flush: every pixel of an unsplit tile once with 16-byte
 //          stores (no zero-fill of grad_value anywhere), each thread clearing the accumulator words it read; empty
-//          tiles are written as zeros without touching LDS; shares of split tiles store their sums to partial tiles that a small second launch (msda_bwd_fold) adds up.
+//          tiles are written as zeros without touching LDS; shares of split tiles store their sums to partial tiles (write-through stores) and count themselves in; the share that arrives last adds the partial tiles up in a fixed order and writes the tile (no second launch since round 5).
 //
 // The sums are formed in double from exact products of fp32 factors (w and attn * g rounded to fp32 as in
 // the reference, cuh:117-147) and rounded to fp32 once: at least as close to the reference as an fp32
@@ -104,7 +104,8 @@ __host__ __device__ constexpr unsigned size_class(unsigned n)
 }
 constexpr unsigned kUcnt = 16;          // words a unit publishes: kClasses counts, its first item slot, spare
 constexpr unsigned kNoCell = 0xFFFFFFFFu, kNoRank = 0xFFFFFFFFu;
-constexpr unsigned kItemShare = 1u << 16;    // item flag: a share of a split tile (its sums go to a partial tile of the workspace)
+constexpr unsigned kItemShare = 1u << 16;    // item flag: a share of a split tile (its sums go to a partial tile of the workspace);
+                                             // a share's word b.z also holds (shares of the tile - 1) << 17 and its own number << 24
 struct FastDivT {
     unsigned mul, shift, d;
 };
@@ -139,8 +140,8 @@ struct PlanGeom {
 // The plan buffer (device memory, caller-owned):
 struct PlanPtrs {
     unsigned *ucnt;     // [units][kUcnt] items of a unit per size class, and the unit's first item slot
-    unsigned *scount;   // [units] split tiles of a unit
-    uint4 *usplit;      // [units * ecap]       {origin, H | W << 16, value row of pixel 0, first partial tile | shares << 24} of every split tile
+    unsigned *tcnt;     // [units * ecap]       shares of a split tile that have stored their partial tile (indexed by the tile's first
+                        //                      partial tile; zero between launches: the plan clears them, the last arriver resets its own)
     float *partial;     // [units * ecap][kNPix * 32]  sums of the shares of split tiles (written by the accumulate kernel)
     uint4 *citems;      // [kClasses][ccap][2]  items by size class, a unit's at its own slots
     uint4 *recs;        // [units * rcap]       16-byte records, sorted by tile inside a unit
@@ -302,7 +303,6 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
     const unsigned NT = tile_levels(shapes, start, G.L, lv, misc);
     if (NT > G.ntmax) {   // (a level table that does not tile [0, S): no items, nothing is accumulated)
         if (tid < kUcnt) W.ucnt[unit * kUcnt + tid] = 0;
-        if (tid == 0) W.scount[unit] = 0;
         return;
     }
     const TLevel Lv = lv[l];
@@ -375,7 +375,7 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
     IC.hq = b * G.Q * G.M + m;
     IC.lP = l * G.P;
     IC.unit = unit;
-    uint4 *us = W.usplit + (size_t)unit * G.ecap;
+    for (unsigned i = tid; i < G.ecap; i += kPlanThreads) W.tcnt[(size_t)unit * G.ecap + i] = 0;
     const unsigned rbase = unit * G.rcap;   // this unit's record region
     unsigned mine[4];   // the counts of up to 4 tiles per thread survive the scan (ntl <= 4 * kPlanThreads)
 #pragma unroll
@@ -394,11 +394,9 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
         const unsigned cls = size_class((n + K - 1) / K);   // (a share's size for split tiles)
         ioff[r] = rbase + hist[t];
         ipos[r] = atomicAdd(&misc[5 + cls], K) | (cls << 28) | (K << 20);
-        if (K > 1) {   // split: the shares' sums go to K partial tiles of the workspace, msda_bwd_fold adds them up
-            const unsigned tyy = t / Lv.ntx, txx = t - tyy * Lv.ntx;
-            const unsigned sp = atomicAdd(&misc[3], 1u), sl = atomicAdd(&misc[4], K);
+        if (K > 1) {   // split: the shares' sums go to K partial tiles of the workspace; the last share to finish adds them up
+            const unsigned sl = atomicAdd(&misc[4], K);
             islot[r] = unit * G.ecap + sl;
-            if (sp < G.ecap) us[sp] = make_uint4((tyy * kTH) | ((txx * kTW) << 16), IC.HW, IC.vrow, islot[r] | (K << 24));
         }
     }
     __syncthreads();
@@ -450,7 +448,6 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
         }
     }
     TSTAMP(3);
-    if (tid == 0) W.scount[unit] = misc[3] < G.ecap ? misc[3] : G.ecap;
     const unsigned ubase = h * G.iph + Lv.tbase + l * G.ecap;   // this unit's item slots (in each class array)
     if (tid < kClasses) W.ucnt[unit * kUcnt + tid] = misc[5 + tid];
     if (tid == kClasses) W.ucnt[unit * kUcnt + kClasses] = ubase;
@@ -469,7 +466,7 @@ __device__ __forceinline__ void plan_unit(const int64_t *__restrict__ shapes, co
             uint4 *dst = W.citems + ((size_t)cls * G.ccap + rr) * 2;
             const unsigned e0 = (unsigned)(((unsigned long long)n * k) / K), e1 = (unsigned)(((unsigned long long)n * (k + 1)) / K);
             IC.unit = K > 1 ? islot[r] + k : 0u;   // (word b.w of a share: its partial tile)
-            store_item(dst, ioff[r] + e0, e1 - e0, org, IC, K > 1 ? kItemShare : 0u);
+            store_item(dst, ioff[r] + e0, e1 - e0, org, IC, K > 1 ? (kItemShare | ((K - 1u) << 17) | (k << 24)) : 0u);
         }
     }
     TSTAMP(5);
@@ -518,38 +515,6 @@ __global__ __launch_bounds__(kPlanThreads, ZIRA_FUSED_WAVES) void msda_fwd_plan(
     fwd_lean_item<2>(value, shapes, start, loc, attn, S, Mdiv.d, LP, invP, id, out);
 }
 
-// The shares of a split tile leave their sums in partial tiles of the workspace (plain stores); this adds them up in
-// a fixed order and writes the tile's pixels -- no atomics, no zero-fill, the same result in every run.  (Round 3 and
-// the first round-4 version let the shares meet through fp32 atomics on pre-zeroed pixels: a share's 4096 atomics sit
-// in the same in-order memory queue as the next item's loads -- with 160-record shares the kernel took 46 instead of 28 us.)
-// kFoldParts blocks per unit.
-constexpr unsigned kFoldParts = kNPix * 8 / 256;   // blocks per unit: a thread takes ONE float4 of every split tile of the unit
-__global__ __launch_bounds__(256) void msda_bwd_fold(PlanGeom G, const unsigned *__restrict__ scount, const uint4 *__restrict__ usplit,
-                                                     const float *__restrict__ partial, float *__restrict__ grad_value)
-{
-    constexpr unsigned D = 32;
-    const unsigned unit = blockIdx.x / kFoldParts, part = blockIdx.x % kFoldParts;
-    // (the first entry is requested together with the count: the kernel is nothing but round trips)
-    const uint4 e0 = usplit[(size_t)unit * G.ecap];
-    const unsigned ns = scount[unit] < G.ecap ? scount[unit] : G.ecap;
-    const unsigned i = part * 256 + threadIdx.x;              // this thread's float4 of a tile
-    const unsigned c4 = i % (D / 4), pix = i / (D / 4);
-    for (unsigned s = 0; s < ns; ++s) {
-        const uint4 e = s == 0 ? e0 : usplit[(size_t)unit * G.ecap + s];
-        const unsigned ty0 = e.x & 0xFFFFu, tx0 = e.x >> 16, H = e.y & 0xFFFFu, Wd = e.y >> 16;
-        const unsigned slot = e.w & 0xFFFFFFu, K = e.w >> 24;
-        const float4 *src = reinterpret_cast<const float4 *>(partial + (size_t)slot * kNPix * D) + i;
-        float4 a = src[0];
-        for (unsigned k = 1; k < K; ++k) {   // (fixed order: the same sum in every run)
-            const float4 b = src[(size_t)k * kNPix * (D / 4)];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        const unsigned y = ty0 + pix / kTW, x = tx0 + pix % kTW;
-        if (y < H && x < Wd)
-            *reinterpret_cast<float4 *>(grad_value + ((size_t)e.z + (size_t)(y * Wd + x) * G.M) * D + c4 * 4) = a;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // accumulate
 // ------------------------------------------------------------------------------------------
@@ -559,6 +524,7 @@ __device__ __forceinline__ unsigned uni(unsigned x) { return __builtin_amdgcn_re
 struct Item {
     unsigned n, ty0, tx0, the, twe, H, W;
     unsigned share, slot; // a share of a split tile: its sums go to partial tile `slot` of the workspace
+    unsigned nshare, kshare;   // ... of `nshare` shares, this one number `kshare` (the tile's first partial tile is slot - kshare)
     unsigned hq;          // item index of query 0 of the head: b * Q * M + m
     size_t voff;          // float offset of the level's pixel 0, this head, in grad_value
     size_t roff;          // first record
@@ -591,7 +557,7 @@ struct HomeArgs {
 template <unsigned NTHR>
 __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_accum(
     const float *__restrict__ grad_out, PlanGeom G, const unsigned *__restrict__ ucnt, const uint4 *__restrict__ citems,
-    const uint4 *__restrict__ recs, float *__restrict__ dump, float *__restrict__ partial, float *__restrict__ grad_value,
+    const uint4 *__restrict__ recs, float *__restrict__ dump, float *partial, unsigned *tcnt, float *__restrict__ grad_value,
     const HomeArgs HA)
 {
     BTIME_DECL;
@@ -626,7 +592,7 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
     const unsigned g = blockIdx.x % G.ng, k = blockIdx.x / G.ng;
     // The units of the group (nug of them) publish their class counts; laid end to end -- class-major, so heavy items
     // first -- they form one ring, and block k takes positions k, k + nbg, ...
-    unsigned *tab = reinterpret_cast<unsigned *>(acc + (kNPix + 1) * D);   // [kClasses nug] prefix, then [nug] first item slot of the unit
+    unsigned *tab = reinterpret_cast<unsigned *>(acc + (kNPix + 1) * D);   // [kClasses nug] prefix, then [nug] first item slot of the unit, [1] items, [1] flag
     const unsigned h0 = g * G.hp;
     if (h0 >= G.heads) return;
     const unsigned nug = (G.heads - h0 < G.hp ? G.heads - h0 : G.hp) * G.L, ne = kClasses * nug;
@@ -655,6 +621,7 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
     // The ring is dealt in rounds of nbg positions, every other round backwards (block k: position k of the even rounds,
     // nbg - 1 - k of the odd ones): the block that drew the heaviest item of a round draws the lightest of the next.
     const unsigned total = uni(tab[ne + nug]);
+    unsigned *flag = tab + ne + nug + 1;   // what the share counter returned, for the whole block
     const unsigned full = fdiv(total, G.NBGdiv), rem = total - full * G.nbg;
     const unsigned cnt = full + (((full & 1u) ? G.nbg - 1u - k : k) < rem ? 1u : 0u);
     if (cnt == 0) return;
@@ -707,6 +674,8 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
         it.n = uni(hd.a.y);
         it.hq = uni(hd.b.y);
         it.share = uni(hd.b.z) & kItemShare;
+        it.nshare = ((uni(hd.b.z) >> 17) & 127u) + 1u;
+        it.kshare = uni(hd.b.z) >> 24;
         it.slot = uni(hd.b.w);
         it.ty0 = org & 0xFFFFu;
         it.tx0 = org >> 16;
@@ -822,10 +791,47 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
                     float *dst = (colin && (PPR / kTW) * ii + pr0 < it.the) ? gbase + ii * rstep : dump + 192 + 4 * lane;   // (pixels of an edge tile outside the map)
                     *reinterpret_cast<float4 *>(dst) = o;
                 }
-            } else {            // a share of a split tile: the whole tile, as it is, to its partial tile (msda_bwd_fold adds the shares up)
-                float *pb = partial + (size_t)it.slot * kNPix * D + (size_t)p0 * D + c4 * 4;
+            } else {
+                // A share of a split tile: the whole tile, as it is, to its partial tile -- WRITE-THROUGH (agent-scope 8-byte
+                // stores: they leave this XCD's L2 for memory), every wave drains its stores, the block's one lane counts the
+                // share in (agent-scope atomic), and the share that finds all the others counted adds the partial tiles up
+                // in their fixed order 0 .. K - 1 (read with agent-scope loads: past this CU's L1) and writes the tile's
+                // pixels: the same sum in every run, whoever arrives last.  cdna_hip_programming.md section 5 ("in-launch
+                // split-K reduction", write-through form) / Guideline 16 R1.  No other block waits: nothing can deadlock.
+                typedef unsigned long long u64;
+                const size_t toff = (size_t)p0 * D + c4 * 4;          // this thread's float4 of a tile, round 0
+                u64 *pb = reinterpret_cast<u64 *>(partial + (size_t)it.slot * kNPix * D + toff);
 #pragma unroll
-                for (unsigned ii = 0; ii < NR; ++ii) *reinterpret_cast<float4 *>(pb + (size_t)ii * PPR * D) = take4(ii);
+                for (unsigned ii = 0; ii < NR; ++ii) {
+                    const float4 o = take4(ii);
+                    u64 *q = pb + (size_t)ii * PPR * D / 2;
+                    __hip_atomic_store(q, ((u64)__float_as_uint(o.y) << 32) | __float_as_uint(o.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 1, ((u64)__float_as_uint(o.w) << 32) | __float_as_uint(o.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its partial tile has left
+                __syncthreads();
+                unsigned *tc = tcnt + (it.slot - it.kshare);
+                if (tid == 0) *flag = __hip_atomic_fetch_add(tc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (uni(*flag) == it.nshare - 1u) {                   // every share of the tile is in memory
+                    const u64 *p0k = reinterpret_cast<const u64 *>(partial + (size_t)(it.slot - it.kshare) * kNPix * D + toff);
+#pragma unroll
+                    for (unsigned ii = 0; ii < NR; ++ii) {
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (unsigned kk = 0; kk < it.nshare; ++kk) {   // (fixed order: the same sum in every run)
+                            const u64 *q = p0k + (size_t)kk * kNPix * D / 2 + (size_t)ii * PPR * D / 2;
+                            const u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const float4 b = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                                                         __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+                            if (kk == 0) a = b;
+                            else { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+                        }
+                        float *dst = (colin && (PPR / kTW) * ii + pr0 < it.the) ? gbase + ii * rstep : dump + 192 + 4 * lane;
+                        *reinterpret_cast<float4 *>(dst) = a;
+                    }
+                    if (tid == 0) __hip_atomic_store(tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the plan may serve another backward)
+                }
             }
         }
         if (it.n) __syncthreads();   // the tile is clear again before the next item adds to it
@@ -843,7 +849,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TilesLayout {
     PlanGeom G;
-    size_t ctl_bytes, off_usplit, off_citems, off_dump, off_recs, off_partial, total;
+    size_t ctl_bytes, off_tcnt, off_citems, off_dump, off_recs, off_partial, total;
     bool one_pass;
     size_t lds_plan, lds_acc;
     unsigned units, grid;
@@ -900,12 +906,12 @@ inline bool make_tiles_layout(int B, int S, int M, int D, int L, int Q, int P, T
     G.NBGdiv = make_fdiv(G.nbg);
     T.lds_plan = (kTLevelWords * kTMaxLevels + 16 + kPlanThreads / 64 + 1 + G.ntmax + 16 * kPlanThreads) * 4;
     if (T.lds_plan > 78 * 1024) return false;   // (two blocks per CU)
-    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + (((size_t)G.hp * L * (kClasses + 1) + 1 + 3) & ~(size_t)3) * 4;
+    T.lds_acc = (size_t)(kNPix + 1) * 32 * 8 + (((size_t)G.hp * L * (kClasses + 1) + 2 + 3) & ~(size_t)3) * 4;
     T.one_pass = (unsigned)Q <= kPlanThreads && P <= 4;
     size_t o = 0;
-    T.ctl_bytes = align256((size_t)T.units * (kUcnt + 1) * 4);   // ucnt[units][kUcnt], scount[units]
+    T.ctl_bytes = align256((size_t)T.units * kUcnt * 4);   // ucnt[units][kUcnt]
     o += T.ctl_bytes;
-    T.off_usplit = o; o += align256((size_t)T.units * G.ecap * 16);
+    T.off_tcnt = o; o += align256((size_t)T.units * G.ecap * 4);
     T.off_citems = o; o += align256((size_t)kClasses * G.ccap * 32);
     T.off_dump = o;   o += 2048;                                            // where redirected stores go (never read)
     T.off_recs = o;   o += align256((size_t)T.units * G.rcap * 16) + 256;   // (+ pad: record 0 of an empty tail item)
@@ -934,8 +940,7 @@ inline PlanPtrs plan_ptrs(const TilesLayout &T, void *plan)
     char *w = reinterpret_cast<char *>(plan);
     PlanPtrs W;
     W.ucnt = reinterpret_cast<unsigned *>(w);
-    W.scount = W.ucnt + (size_t)T.units * kUcnt;
-    W.usplit = reinterpret_cast<uint4 *>(w + T.off_usplit);
+    W.tcnt = reinterpret_cast<unsigned *>(w + T.off_tcnt);
     W.partial = reinterpret_cast<float *>(w + T.off_partial);
     W.citems = reinterpret_cast<uint4 *>(w + T.off_citems);
     W.recs = reinterpret_cast<uint4 *>(w + T.off_recs);
@@ -1000,10 +1005,7 @@ int tiles_backward_planned_f32(const float *grad_out, const float *value, const 
     if (T.grid & 7u) return -1;   // (the gather blocks' XCD interleave starts at a multiple of 8)
     const unsigned wpb = kAccThreads / 64 * ZIRA_HOME_ITEMS_PER_WAVE;   // items a gather block takes
     hipLaunchKernelGGL((msda_bwd_tile_accum<kAccThreads>), dim3(T.grid + 8 * ((HA.per_xcd + wpb - 1) / wpb)), dim3(kAccThreads),
-                       T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, gv, HA);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(msda_bwd_fold, dim3(T.units * kFoldParts), dim3(256), 0, st, T.G, W.scount, W.usplit, W.partial, gv);
+                       T.lds_acc, st, grad_out, T.G, W.ucnt, W.citems, W.recs, dump, W.partial, W.tcnt, gv, HA);
     return (int)hipGetLastError();
 }
 

@@ -16,6 +16,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _C, _lib
+from . import gemm_bf16x3 as g3
 
 
 def applies(layer, src, pos, reference_points, spatial_shapes, key_padding_mask) -> bool:
@@ -63,8 +64,14 @@ class _FrozenEncoderAttention(torch.autograd.Function):
         s2 = src.view(rows, C)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            value = torch.addmm(bv, s2, wv.t()).view(B, S, M, C // M)
-            proj = torch.addmm(bq, (src + pos).view(rows, C), wq.t())
+            sp = (src + pos).view(rows, C)
+            arith = g3.enabled() and g3.supported(s2, C, C) and g3.supported(sp, wq.shape[0], C)
+            if arith:   # the 256-wide products on the bf16 matrix cores in split-bf16 arithmetic (gemm_bf16x3.py)
+                value = g3.linear(ms, "value", s2, wv, bv).view(B, S, M, C // M)
+                proj = g3.linear(ms, "query", sp, wq, bq)
+            else:
+                value = torch.addmm(bv, s2, wv.t()).view(B, S, M, C // M)
+                proj = torch.addmm(bq, sp, wq.t())
             nproj = proj.shape[1]
             loc = torch.empty((B, S, M, L, P, 2), **f32)
             attn = torch.empty((B, S, M, L, P), **f32)
@@ -73,7 +80,7 @@ class _FrozenEncoderAttention(torch.autograd.Function):
             if rc != 0:
                 raise RuntimeError("zira_msda_sampling_fwd_f32 failed with code %d" % rc)
             o = _C.ms_deform_attn_forward(value, shapes, level_start, loc, attn, ms.im2col_step)
-            y = torch.addmm(bo, o.view(rows, C), wo.t())
+            y = g3.linear(ms, "output", o.view(rows, C), wo, bo) if arith else torch.addmm(bo, o.view(rows, C), wo.t())
             out, s = torch.empty_like(src), torch.empty_like(src)
             stats = torch.empty((2, rows), **f32)
             rc = lib.zira_add_layernorm_fwd_f32(s2.data_ptr(), y.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), rows, C,
@@ -83,6 +90,7 @@ class _FrozenEncoderAttention(torch.autograd.Function):
                 raise RuntimeError("zira_add_layernorm_fwd_f32 failed with code %d" % rc)
         ctx.layer = layer
         ctx.dims = (B, S, C, M, L, P, R, nproj)
+        ctx.arith = arith
         ctx.save_for_backward(value, loc, attn, ref, s, stats, shapes, level_start, wq)
         return out
 
@@ -104,7 +112,10 @@ class _FrozenEncoderAttention(torch.autograd.Function):
             if rc != 0:
                 raise RuntimeError("zira_layernorm_bwd_f32 failed with code %d" % rc)
             gs2 = gs.view(rows, C)
-            go = (gs2 @ ms.output_proj.weight).view(B, S, C)
+            if ctx.arith:
+                go = g3.linear_input_grad(ms, "output", gs2, ms.output_proj.weight).view(B, S, C)
+            else:
+                go = (gs2 @ ms.output_proj.weight).view(B, S, C)
             gv, gloc, gattn = _C.ms_deform_attn_backward(value, shapes, level_start, loc, attn, go, ms.im2col_step)
             gproj = torch.empty((rows, nproj), dtype=torch.float32, device=dev)
             rc = lib.zira_msda_sampling_bwd_f32(gloc.data_ptr(), gattn.data_ptr(), attn.data_ptr(), ref.data_ptr(), R,
@@ -113,8 +124,12 @@ class _FrozenEncoderAttention(torch.autograd.Function):
                 raise RuntimeError("zira_msda_sampling_bwd_f32 failed with code %d" % rc)
             # the three gradients of src meet in the GEMMs: residual path as the addend, then the two projections
             # (in place: torch.addmm(x, ...) would first COPY x into its result -- a pass of its own; gs is this node's)
-            gx = gs2.addmm_(gv.view(rows, C), ms.value_proj.weight)
-            gx.addmm_(gproj, wq)
+            if ctx.arith:
+                gx = g3.linear_input_grad(ms, "value", gv.view(rows, C), ms.value_proj.weight, accumulate_into=gs2)
+                g3.linear_input_grad(ms, "query", gproj, wq, accumulate_into=gx)
+            else:
+                gx = gs2.addmm_(gv.view(rows, C), ms.value_proj.weight)
+                gx.addmm_(gproj, wq)
         return None, gx.view(B, S, C), None, None, None, None
 
 

@@ -75,3 +75,56 @@ def gemm(a: torch.Tensor, planes: torch.Tensor, epilogue: int, bias: torch.Tenso
     if rc != 0:
         raise RuntimeError("zira_gemm_bf16x3_f32 failed with code %d (M=%d N=%d K=%d epilogue=%d)" % (rc, M, N, K, epilogue))
     return out
+
+
+# ---- cached split weights of modules -----------------------------------------------------------------------------------------
+
+def enabled() -> bool:
+    """Whether the callers should take the split-bf16 products (``transformer.Switches.gemm_arith`` = "bf16x3")."""
+    from .transformer import Switches
+    return Switches.gemm_arith == "bf16x3"
+
+
+def _cache(owner, name, transpose):
+    store = owner.__dict__.setdefault("_bf16x3_split", {})
+    sw = store.get((name, transpose))
+    if sw is None:
+        sw = store[(name, transpose)] = SplitWeight(transpose)
+    return sw
+
+
+def linear(owner, name, x2, weight, bias=None, out=None):
+    """``x2 @ weight.T (+ bias)`` for a frozen ``weight`` [N, K]; the planes are cached on ``owner`` under ``name``."""
+    N = weight.shape[0]
+    planes = _cache(owner, name, False).planes(weight)
+    if bias is None:
+        bias = _zeros(N, x2.device)
+    return gemm(x2, planes, EPI_BIAS, bias=bias, out=out)
+
+
+def linear_input_grad(owner, name, g2, weight, accumulate_into=None):
+    """``g2 @ weight`` for a frozen ``weight`` [N_out, K_in] (the input gradient of ``F.linear``): [M, N_out] -> [M, K_in];
+    ``accumulate_into`` [M, K_in]: added to IN PLACE (the gradient that meets this one) and returned."""
+    planes = _cache(owner, name, True).planes(weight)          # B[n][k] = weight[k][n]
+    if accumulate_into is not None:
+        return gemm(g2, planes, EPI_ADD, aux=accumulate_into, out=accumulate_into)
+    return gemm(g2, planes, EPI_BIAS, bias=_zeros(weight.shape[1], g2.device))
+
+
+_ZEROS = {}
+
+
+def _zeros(n, device):
+    z = _ZEROS.get((n, device))
+    if z is None:
+        z = _ZEROS[(n, device)] = torch.zeros(n, device=device, dtype=torch.float32)
+    return z
+
+
+def refresh(owner, weights):
+    """Bring every cached plane set of ``owner`` up to date (``weights``: name -> tensor), in place; for
+    ``refresh_fused_projection`` hooks (a replayed hipGraph re-runs no Python)."""
+    for (name, _), sw in owner.__dict__.get("_bf16x3_split", {}).items():
+        w = weights.get(name)
+        if w is not None:
+            sw.planes(w)

@@ -151,10 +151,17 @@ class _MultiValueProjections(Function):
 
     @staticmethod
     def forward(ctx, x, n, *wb):
+        from . import gemm_bf16x3 as g3
         ws, bs = wb[:n], wb[n:]
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(*ws)
         ctx.x_shape = x.shape
+        # (split-bf16 products on the bf16 matrix cores where asked for: gemm_bf16x3.py; the planes are cached on the weights' own
+        #  parameters -- a Function has no module -- and follow them in place)
+        ctx.arith = (g3.enabled() and x2.shape[0] >= 1024 and x2.is_contiguous()
+                     and all(g3.supported(x2, w.shape[0], w.shape[1]) for w in ws))
+        if ctx.arith:
+            return tuple(g3.linear(w, "self", x2, w, b).view(*x.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
         return tuple(torch.addmm(b, x2, w.t()).view(*x.shape[:-1], w.shape[0]) for w, b in zip(ws, bs))
 
     @staticmethod
@@ -166,7 +173,11 @@ class _MultiValueProjections(Function):
             if g is None:
                 continue
             g2 = g.reshape(-1, g.shape[-1])
-            gx = g2 @ w if gx is None else gx.addmm_(g2, w)
+            if ctx.arith and g2.is_contiguous():
+                from . import gemm_bf16x3 as g3
+                gx = g3.linear_input_grad(w, "self", g2, w, accumulate_into=gx)
+            else:
+                gx = g2 @ w if gx is None else gx.addmm_(g2, w)
         return (None if gx is None else gx.view(ctx.x_shape), None) + (None,) * (2 * len(ws))
 
 
@@ -358,6 +369,11 @@ class MultiScaleDeformableAttention(nn.Module):
         version changed, because a graph replay skips the Python code that would notice."""
         if getattr(self, "_fused_qp", None) is not None:
             self._fused_query_projection()
+        if "_bf16x3_split" in self.__dict__:   # the bf16 planes of the projections (gemm_bf16x3.py) follow too
+            from . import gemm_bf16x3 as g3
+            fq = self._fused_query_projection()
+            g3.refresh(self, {"value": self.value_proj.weight, "output": self.output_proj.weight,
+                              **({"query": fq[0]} if fq is not None else {})})
 
     fuse_query_projections = True   # class-level switch (tests compare both ways)
     fuse_sampling_plan = True       # ... softmax + sampling locations in one native launch each way (needs the fused projection)
