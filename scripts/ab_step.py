@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev: same-box A/B of class-level switches on the replayed training step.  `python scripts/ab_step.py NAME=0|1 ...` with
-NAME in {gemm_arith (f32|bf16x3), shared_source, batch_value, native_layer, native_glue, native_attention, overlap_text, text_native, compose_text, residual_in_gemm, graph_encoder, graph_decoder}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
+NAME in {gemm_arith (f32|bf16x3), shared_source, batch_value, native_layer, native_glue, native_attention, overlap_text, compose_text, residual_in_gemm, graph_encoder, graph_decoder}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
 prints ms per step.  Run the variants alternately in ONE gpurun call, several times each: processes on one box differ by up to
 0.5 ms; two trainers in one process do not work as an A/B (the second one built is 3 ms slower whatever its switches)."""
 import os
@@ -33,8 +33,6 @@ for kv in sys.argv[1:]:
         zt.DeformableTransformerEncoderLayer.native_attention = bool(int(v))
     elif k == "overlap_text":
         zt.TransformerEncoder.overlap_text_layer = bool(int(v))
-    elif k == "text_native":
-        zt.TransformerEncoderLayer.native_projections = bool(int(v))
     elif k == "compose_text":
         zt.BiMultiHeadAttention.compose_text_side = bool(int(v))
     elif k == "residual_in_gemm":

@@ -166,7 +166,9 @@ def test_full_size_transformer_matches_reference(monkeypatch, frozen, arith):
         assert counts == {"decoder_layer": 6, "decoder_glue": 6, "encoder_attention": 6, "encoder_ffn": 6}, counts
     else:
         assert counts == {}, counts
-    assert len(split_gemms) == (24 if arith == "bf16x3" else 0)     # four products per encoder FFN, forward + backward
+    # per encoder layer four FFN products and six 256-wide projections of the deformable attention, forward + backward; the six
+    # decoder layers' value projections of the memory and their input gradients
+    assert len(split_gemms) == (6 * 4 + 6 * 6 + 12 if arith == "bf16x3" else 0)
 
 
 def test_swin_b_bf16_training_steps_full_size():

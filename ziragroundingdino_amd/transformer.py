@@ -652,21 +652,15 @@ class TransformerEncoderLayer(nn.Module):
         # masks of different images are interleaved over heads; kept for output parity.
         if src_mask.dim() == 3 and src_mask.shape[0] == src.shape[1]:
             src_mask = src_mask.repeat(self.nhead, 1, 1)
-        if self.native_projections:
-            from . import text_layer
-            if text_layer.applies(self, src, pos):
-                return text_layer.forward(self, src, pos, src_mask)
         q = k = self.with_pos_embed(src, pos)
         src2 = _mha(self.self_attn, q, k, src, attn_mask=src_mask)
         src = self.norm1(src + self.dropout1(src2))
         src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout2(src2))
 
-    # Class-level switch, OFF: by kernel time the row-GEMM form is shorter (267 -> 206 us per layer, scripts/textlayer_profile.py),
-    # but in the step the text layer runs on a side branch of the captured graph beside the deformable encoder layer and is not
-    # on the critical path -- 37.36 / 37.41 ms per step without it, 37.45 / 37.63 with it (scripts/ab_step.py text_native=0|1,
-    # alternating processes on one box).  Kept for configurations without that overlap; tests/test_text_layer_gpu.py pins it.
-    native_projections = False
+    # (A row-GEMM form of this layer -- three autograd nodes round the attention core, 43 -> 31 launches, 267 -> 206 us by kernel
+    #  time -- was built in round 4 and REMOVED in round 5: the layer runs beside the deformable image layer, off the critical
+    #  path, and the step did not change with 32 text tokens (37.4 ms either way) nor with 194 (67.1-67.4 against 66.7-67.4 ms).)
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
