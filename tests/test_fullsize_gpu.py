@@ -259,3 +259,26 @@ def test_swin_b_bf16_step_tracks_fp32_step():
         off += p.numel()
         if float(x.norm()) > 1e-4 * total:      # (the `scaling` gradients of zero-initialised branches are ~1e-12)
             assert cos(x, y) >= 0.98, (n, cos(x, y))
+
+
+def test_first_no_grad_forward_of_fresh_frozen_models_selects_the_reference_proposals():
+    """Regression (round 5): inside an encoder layer the text enhancer runs on a second stream beside the deformable image
+    layer.  Without gradients nothing kept its INPUT alive -- allocated on the main stream, read on the side stream -- and the
+    main stream's allocator handed the block to the image layer: 5 of 12 fresh frozen models selected garbage proposals
+    (scripts/repro_frozen_nograd.py).  Eight fresh models, first forward each: the reference's 900 proposals as a set."""
+    g = torch.load(os.path.join(HERE, "golden", "full_transformer.pt"), weights_only=False)
+    srcs, poss, masks, text, tmask, pid, may, _ = make_inputs()
+    dev = lambda x: [t.cuda() for t in x] if isinstance(x, list) else x.cuda()
+    srcs, poss, masks, text, tmask, pid, may = map(dev, (srcs, poss, masks, text, tmask, pid, may))
+    for trial in range(8):
+        tr = attach_heads(transformer.Transformer(**g["kwargs"]), utils.MLP, utils.ContrastiveEmbed)
+        fill_by_name_(tr, g["salt"], g["scale"], g["scales"])
+        layernorm_weights_plus_one_(tr)
+        tr.to("cuda").eval()
+        for p in tr.parameters():
+            p.requires_grad_(False)
+        with torch.no_grad():
+            tr(srcs, masks, None, poss, None, None, {"encoded_text": text, "text_token_mask": tmask, "position_ids": pid,
+                                                     "text_self_attention_masks": may}, no_padding=True)
+        for b in range(2):
+            assert torch.equal(tr.last_topk_proposals[b].cpu().sort()[0], g["topk_proposals"][b].sort()[0]), (trial, b)

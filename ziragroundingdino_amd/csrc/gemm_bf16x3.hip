@@ -36,6 +36,9 @@
 #ifndef ZIRA_G3_BM192_MARGIN
 #define ZIRA_G3_BM192_MARGIN 0.05   // the 192-row tile is taken where it wastes this much less of the last round of block slots
 #endif
+#ifndef ZIRA_G3_DEV_NOLOAD
+#define ZIRA_G3_DEV_NOLOAD 0
+#endif
 #ifndef ZIRA_G3_STAGGER
 #define ZIRA_G3_STAGGER 0   // s_sleep argument (x 64 cycles) by which the block in a CU's second wave slot starts late
 #endif
@@ -200,7 +203,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16x3_kernel(const float *_
         *reinterpret_cast<uint4 *>(wb + 2 * kBN * kRow) = rb20;
         *reinterpret_cast<uint4 *>(wb + 2 * kBN * kRow + 64 * kRow) = rb21;
         __syncthreads();
+#if !ZIRA_G3_DEV_NOLOAD   // (developer ablation: the K loop without its global loads -- wrong results, what the loads cost)
         if (k0 + kBK < K) ZIRA_GLOAD(k0 + kBK);
+#endif
         if constexpr (CH == 32) {
         // Six terms per 16-deep slice, the small ones first; matrix-core A operand = weight fragment (rows n), B operand =
         // activation fragment (rows m): the accumulator block is C^T [n][m].  The twelve terms of a K step are summed inside

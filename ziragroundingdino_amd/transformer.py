@@ -936,6 +936,11 @@ class TransformerEncoder(nn.Module):
                 cur = torch.cuda.current_stream(output.device)
                 side = self._text_stream(output.device)
                 side.wait_stream(cur)
+                # The text tokens were allocated on `cur` and are read on `side`: without gradients (eval, or a no-grad pass)
+                # nothing keeps them alive once `memory_text` is rebound below, and the allocator of `cur` would hand their
+                # block to the image layer running beside -- found in round 5 as an intermittently wrong two-stage selection
+                # of the frozen full-size transformer (scripts/repro_frozen_nograd.py: 5 of 12 fresh models, 0 of 12 since).
+                memory_text.record_stream(side)
                 with torch.cuda.stream(side):
                     memory_text = text_layer(memory_text)
             else:
