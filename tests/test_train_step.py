@@ -63,21 +63,22 @@ def slice_inputs(g, model, dev):
     return inp, feats, poss, am, pid, c2t
 
 
-def run_slice_step(model, inp, feats, poss, am, pid, c2t):
+def run_slice_step(model, inp, feats, poss, am, pid, c2t, no_padding=False):
     text_dict, loss_lin = model.project_text(inp["bert_hidden"], torch.ones_like(inp["input_ids"]).bool(), pid, am)
-    return model.forward_features(feats, poss, inp["img_mask"], text_dict, c2t, loss_lin, inp["targets"])
+    return model.forward_features(feats, poss, inp["img_mask"], text_dict, c2t, loss_lin, inp["targets"], no_padding=no_padding)
 
 
 class _SliceWrapper(nn.Module):
     """trainer.run_step calls model(data): the slice model behind the interface the trainer uses."""
     training = True
 
-    def __init__(self, model):
+    def __init__(self, model, no_padding=False):
         super().__init__()
         object.__setattr__(self, "_m", model)
+        object.__setattr__(self, "_no_padding", no_padding)
 
     def __call__(self, data):
-        return run_slice_step(self._m, *data)
+        return run_slice_step(self._m, *data, no_padding=self._no_padding)
 
     def add_cls_prompt(self, names):
         self._m.add_cls_prompt(names)
@@ -289,10 +290,12 @@ def test_two_training_steps_at_the_native_nodes_size_match_reference(msda_backen
     model.use_transformer_graph = graphed
     trainer = ZiraTrainer(model)
     assert sorted(trainer.names) == sorted(g["trainable_names"])
-    trainer.model = _SliceWrapper(model)
+    # (the fixture's images are unpadded and the caller knows it, as bench.py's do: GroundingDINO.forward derives the flag from the
+    #  image sizes on the host -- with a mask tensor in hand the encoder's attention node stands down)
+    trainer.model = _SliceWrapper(model, no_padding=True)
     data = slice_inputs(g, model, dev)
 
-    loss_dict = run_slice_step(model, *data)
+    loss_dict = run_slice_step(model, *data, no_padding=True)
     want = g["steps"][0]
     assert set(loss_dict) == set(want["loss_dict"])
     for k, v in loss_dict.items():

@@ -285,6 +285,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16x3_kernel(const float *_
     store_tile<MI, NI, EPI>(acc, bias, aux, C, M, N, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
+// (Measured and dropped in round 5: a wave-specialised form -- eight waves per block, a producer and a consumer wave on every
+// SIMD, two LDS stages, one barrier per K step, one block per CU.  Correct, and slower: 1821-1831 us for the model's eight
+// products against 1567-1584 us for the kernel above, with the loads one or two K steps ahead alike; the tile's epilogue and
+// prologue overlap with nothing when a CU holds one block, which the K = 256 products pay most.)
+
 // W [rows][cols] fp32 -> planes [3][N][K] bf16 with B[n][k] = W[n][k] (transpose = 0: N = rows, K = cols) or W[k][n]
 // (transpose = 1: N = cols, K = rows)
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ w, int rows, int cols, int transpose,
@@ -308,16 +313,16 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
 template <int BM, int EPI>
 int launch(const float *a, const unsigned short *bp, const float *bias, const float *aux, float *c, int M, int N, int K, hipStream_t st)
 {
-    static bool attr_set = false;   // one device per process
     const int rt = (M + BM - 1) / BM, ct = N / kBN, per = (rt + 7) / 8;
+    static bool attr_set = false;
     const size_t lds = (size_t)3 * (BM + kBN) * kRow;
-    auto kernel = gemm_bf16x3_kernel<BM, EPI>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_kernel<BM, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(8 * per * ct), dim3(kThreads), lds, st, a, bp, bias, aux, c, M, N, K, rt, ct, per);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, EPI>), dim3(8 * per * ct), dim3(kThreads), lds, st, a, bp, bias, aux, c, M, N, K, rt, ct, per);
     return (int)hipGetLastError();
 }
 
@@ -358,8 +363,9 @@ extern "C" int zira_gemm_bf16x3_f32(const float *a, const void *b_planes, int M,
     const unsigned short *bp = reinterpret_cast<const unsigned short *>(b_planes);
     // tile height: the one that wastes fewer of the chip's 512 block slots in its last round
     auto waste = [&](int bm) {
-        const long long tiles = (long long)((M + bm - 1) / bm) * (N / kBN), rounds = (tiles + 511) / 512;
-        return (double)(rounds * 512 - tiles) / (double)(rounds * 512) + (bm == 192 ? 0.0 : 0.0);
+        const long long slots = 512;   // blocks the chip holds at a time
+        const long long tiles = (long long)((M + bm - 1) / bm) * (N / kBN), rounds = (tiles + slots - 1) / slots;
+        return (double)(rounds * slots - tiles) / (double)(rounds * slots);
     };
     static const int force_bm = [] { const char *e = getenv("ZIRA_G3_BM"); return e ? atoi(e) : 0; }();   // developer override
     if (force_bm == 192 || (force_bm != 128 && waste(192) + ZIRA_G3_BM192_MARGIN < waste(128)))
