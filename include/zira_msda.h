@@ -443,6 +443,26 @@ int zira_box_refine_bwd_f32(const float *g_new, const float *new_ref, const floa
                             float *g_h, void *stream);
 
 
+/* Level geometry from the padding mask (three op chains of the reference, ~150 launch-bound ATen kernels per training step):
+ *   mask [B, S] bytes (non-zero = padded), shapes [L, 2] / start [L] int64 on the device (the levels tile [0, S)).
+ * zira_level_valid_ratios_f32 (get_valid_ratio, transformer_for_adapter.py:226-233, per level and stacked at :260):
+ *   counts [B, L, 2] = (unpadded columns of the level's first row, unpadded rows of its first column) as floats,
+ *   ratios [B, L, 2] = counts * (1 / (W, H)) (how ATen divides by a host scalar); either output may be null.
+ * zira_encoder_ref_points_f32 (get_reference_points, transformer_for_adapter.py:482-497): ratios [B, L, 2] ->
+ *   ref_points [B, S, L, 2] = ((x + 0.5) / (ratio_x W), (y + 0.5) / (ratio_y H)) of the pixel's own level, times the ratios of level j.
+ * zira_encoder_proposals_f32 (gen_encoder_output_proposals, utils.py:56-116, learnedwh = None): odds [B, S, 4] = p / (1 - p)
+ *   for p = ((x + 0.5) / valid columns, (y + 0.5) / valid rows, 0.05 2^l, 0.05 2^l), +inf where the pixel is padded or any p is
+ *   outside (0.01, 0.99); drop [B, S] bytes = 1 there (the rows of `memory` the reference zeroes).  The caller takes the log
+ *   (ATen's log and libm's logf differ in the last bit).  counts_scratch: B * L * 2 floats.
+ * The same separately rounded fp32 operations as the op chains: bit-identical.  Return 0 or a hipError_t; enqueue only. */
+int zira_level_valid_ratios_f32(const void *mask, const int64_t *shapes, const int64_t *start, int B, long long S, int L,
+                                float *counts, float *ratios, void *stream);
+int zira_encoder_ref_points_f32(const float *ratios, const int64_t *shapes, const int64_t *start, int B, long long S, int L,
+                                float *ref_points, void *stream);
+int zira_encoder_proposals_f32(const void *mask, const int64_t *shapes, const int64_t *start, int B, long long S, int L,
+                               float *counts_scratch, float *odds, void *drop, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

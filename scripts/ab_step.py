@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev: same-box A/B of class-level switches on the replayed training step.  `python scripts/ab_step.py NAME=0|1 ...` with
-NAME in {gemm_arith (f32|bf16x3), shared_source, batch_value, native_layer, native_glue, native_attention, overlap_text, compose_text, residual_in_gemm, graph_encoder, graph_decoder}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
+NAME in {dummy_launches (N tiny adds per fusion block), gemm_arith (f32|bf16x3), shared_source, batch_value, native_layer, native_glue, native_attention, overlap_text, compose_text, residual_in_gemm, graph_encoder, graph_decoder}: sets the switch, times 40 steps after 8 warm-up steps (graph replay, 4 rotating minibatches),
 prints ms per step.  Run the variants alternately in ONE gpurun call, several times each: processes on one box differ by up to
 0.5 ms; two trainers in one process do not work as an A/B (the second one built is 3 ms slower whatever its switches)."""
 import os
@@ -39,6 +39,19 @@ for kv in sys.argv[1:]:
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
     elif k == "gemm_arith":
         zt.Switches.gemm_arith = v
+    elif hasattr(zt.Switches, k):      # any boolean of transformer.Switches (native_geometry, fused_attention, ...)
+        setattr(zt.Switches, k, bool(int(v)))
+    elif k == "dummy_launches":   # what a tiny launch costs the step: N extra [64, 256] adds per fusion block forward
+        _n, _orig = int(v), zt.BiAttentionBlock.forward
+
+        def _with_dummies(self, *a, _n=_n, _orig=_orig, **kw):
+            scratch = self.__dict__.get("_scratch")
+            if scratch is None:
+                scratch = self.__dict__["_scratch"] = torch.zeros(64, 256, device="cuda")
+            for _ in range(_n):
+                scratch.add_(1.0)
+            return _orig(self, *a, **kw)
+        zt.BiAttentionBlock.forward = _with_dummies
     elif k in ("graph_encoder", "graph_decoder", "graph_fusion", "graph_selection"):
         from ziragroundingdino_amd.graphs import GraphedTransformer
         setattr(GraphedTransformer, k, bool(int(v)))

@@ -13,6 +13,9 @@ from ziragroundingdino_amd.groundingdino import build_model  # noqa: E402
 from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if os.environ.get("GEMM_ARITH"):      # f32 | bf16x3
+    from ziragroundingdino_amd import transformer as _zt
+    _zt.Switches.gemm_arith = os.environ["GEMM_ARITH"]
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()

@@ -102,6 +102,9 @@
 #ifndef ZIRA_ACC_MINW
 #define ZIRA_ACC_MINW 4    // accumulate: waves per SIMD the register allocation must allow
 #endif
+#ifndef ZIRA_ACC_SKIP_TRASH
+#define ZIRA_ACC_SKIP_TRASH 0   // accumulate: 1 = the lanes of a corner that belongs to a neighbouring tile sit the adds out (exec mask)
+#endif
 #ifndef ZIRA_ACC_DR
 #define ZIRA_ACC_DR 3      // accumulate: grad_out rows requested this many records ahead (DR + 1 divides 8)
 #endif
@@ -1268,6 +1271,9 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
                 // accumulator row layout: slot k * LPS + j holds channel 4 j + k, so that the lanes of a record
                 // add to consecutive 8-byte words (32-byte lane strides run at half the rate)
                 unsigned long long *ap = acc + (ad[c] + j);
+#if ZIRA_ACC_SKIP_TRASH
+                if (ad[c] != trash)
+#endif
 #pragma unroll
                 for (unsigned k = 0; k < 4; ++k) {
                     const double dd = fma(wc[c], tt[k], kMagic);   // (the product of two floats is exact in double)

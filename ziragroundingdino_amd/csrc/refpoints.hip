@@ -126,6 +126,99 @@ __global__ __launch_bounds__(256) void box_refine_bwd_kernel(const float *__rest
     }
 }
 
+// ---- level geometry from the padding mask: valid ratios, the encoder's reference points, the two-stage proposals ----
+// Three op chains of the reference that depend on nothing but the padding mask and the level table and that PyTorch runs as
+// ~150 launch-bound kernels per step (3 us each on the critical path):
+//   valid ratios      transformer_for_adapter.py:226-233   [B, L, 2] = (valid columns / W, valid rows / H) of every level
+//   reference points  transformer_for_adapter.py:482-497   [B, S, L, 2] = pixel centre / (ratio * extent) of its level, * ratio of level j
+//   proposals         utils.py:56-116                      [B, S, 4] = (pixel centre / valid extent, 0.05 * 2^level), as p / (1 - p)
+//                                                          with +inf where padded or outside (0.01, 0.99) -- the caller's ATen
+//                                                          log finishes it (ATen's log and libm's logf differ in the last bit)
+// Same fp32 operations in the same order as the op chains (separately rounded: contraction is off), so the results are
+// bit-identical: linspace(0.5, H - 0.5, H)[i] is exactly i + 0.5 (its step is exactly 1).
+__device__ __forceinline__ int level_of(const int64_t *__restrict__ start, int L, long long s)
+{
+    int l = 0;
+    for (int i = 1; i < L; ++i) l = s >= start[i] ? i : l;
+    return l;
+}
+
+// counts[b, l] = (valid columns, valid rows) as floats; a block per (b, l)
+__global__ __launch_bounds__(256) void level_counts_kernel(const unsigned char *__restrict__ mask, const int64_t *__restrict__ shapes,
+                                                           const int64_t *__restrict__ start, long long S, int L,
+                                                           float *__restrict__ counts, float *__restrict__ ratios)
+{
+#pragma clang fp contract(off)
+    __shared__ unsigned cnt[2];
+    const int b = blockIdx.x / L, l = blockIdx.x % L;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const unsigned char *m = mask + (long long)b * S + start[l];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned cw = 0, ch = 0;
+    for (int x = threadIdx.x; x < W; x += 256) cw += m[x] ? 0u : 1u;
+    for (int y = threadIdx.x; y < H; y += 256) ch += m[(long long)y * W] ? 0u : 1u;
+    if (cw) atomicAdd(&cnt[0], cw);
+    if (ch) atomicAdd(&cnt[1], ch);
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float c = (float)cnt[threadIdx.x];
+        if (counts) counts[((long long)b * L + l) * 2 + threadIdx.x] = c;
+        // (ATen divides a tensor by a host scalar as a multiplication by the scalar's fp32 reciprocal)
+        if (ratios) ratios[((long long)b * L + l) * 2 + threadIdx.x] = __fmul_rn(c, __fdiv_rn(1.f, (float)(threadIdx.x ? H : W)));
+    }
+}
+
+__global__ __launch_bounds__(256) void encoder_ref_points_kernel(const float *__restrict__ ratios, const int64_t *__restrict__ shapes,
+                                                                 const int64_t *__restrict__ start, int B, long long S, int L,
+                                                                 float *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * S) return;
+    const long long s = idx % S;
+    const int b = (int)(idx / S);
+    const int l = level_of(start, L, s);
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const long long r = s - start[l];
+    const int y = (int)(r / W), x = (int)(r - (long long)y * W);
+    const float *vr = ratios + (long long)b * L * 2;
+    const float rx = __fdiv_rn((float)x + 0.5f, __fmul_rn(vr[2 * l], (float)W));
+    const float ry = __fdiv_rn((float)y + 0.5f, __fmul_rn(vr[2 * l + 1], (float)H));
+    float2 *o = reinterpret_cast<float2 *>(out) + idx * L;
+    for (int j = 0; j < L; ++j) o[j] = make_float2(__fmul_rn(rx, vr[2 * j]), __fmul_rn(ry, vr[2 * j + 1]));
+}
+
+__global__ __launch_bounds__(256) void encoder_proposals_kernel(const unsigned char *__restrict__ mask, const float *__restrict__ counts,
+                                                                const int64_t *__restrict__ shapes, const int64_t *__restrict__ start,
+                                                                int B, long long S, int L, float *__restrict__ odds,
+                                                                unsigned char *__restrict__ drop)
+{
+#pragma clang fp contract(off)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * S) return;
+    const long long s = idx % S;
+    const int b = (int)(idx / S);
+    const int l = level_of(start, L, s);
+    const int W = (int)shapes[2 * l + 1];
+    const long long r = s - start[l];
+    const int y = (int)(r / W), x = (int)(r - (long long)y * W);
+    const float *c = counts + ((long long)b * L + l) * 2;
+    const float wh = __fmul_rn(0.05f, (float)(1u << l));
+    const float p[4] = {__fdiv_rn((float)x + 0.5f, c[0]), __fdiv_rn((float)y + 0.5f, c[1]), wh, wh};
+    bool bad = mask[idx] != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bad = bad || !(p[k] > 0.01f && p[k] < 0.99f);
+    const float inf = __uint_as_float(0x7f800000u);
+    float4 o;
+    o.x = bad ? inf : __fdiv_rn(p[0], 1.f - p[0]);
+    o.y = bad ? inf : __fdiv_rn(p[1], 1.f - p[1]);
+    o.z = bad ? inf : __fdiv_rn(p[2], 1.f - p[2]);
+    o.w = bad ? inf : __fdiv_rn(p[3], 1.f - p[3]);
+    reinterpret_cast<float4 *>(odds)[idx] = o;
+    drop[idx] = bad ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" int zira_box_refine_fwd_f32(const float *h, const float *w, const float *b, const float *ref, long long rows, int K,
@@ -169,5 +262,40 @@ extern "C" int zira_sine_embed_f32(const float *pos, const float *dim_t, long lo
     if (n == 0) return 0;
     hipLaunchKernelGGL(sine_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos, dim_t,
                        rows, C, T, scale, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_level_valid_ratios_f32(const void *mask, const int64_t *shapes, const int64_t *start, int B, long long S, int L,
+                                           float *counts, float *ratios, void *stream)
+{
+    if (!mask || !shapes || !start || B <= 0 || S <= 0 || L <= 0 || L > 30 || (!counts && !ratios)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(level_counts_kernel, dim3((unsigned)(B * L)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned char *>(mask), shapes, start, S, L, counts, ratios);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_encoder_ref_points_f32(const float *ratios, const int64_t *shapes, const int64_t *start, int B, long long S, int L,
+                                           float *ref_points, void *stream)
+{
+    if (!ratios || !shapes || !start || !ref_points || B <= 0 || S <= 0 || L <= 0 || L > 30) return (int)hipErrorInvalidValue;
+    if ((uintptr_t)ref_points & 7) return (int)hipErrorInvalidValue;
+    const long long n = (long long)B * S;
+    hipLaunchKernelGGL(encoder_ref_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ratios, shapes,
+                       start, B, S, L, ref_points);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_encoder_proposals_f32(const void *mask, const int64_t *shapes, const int64_t *start, int B, long long S, int L,
+                                          float *counts_scratch, float *odds, void *drop, void *stream)
+{
+    if (!mask || !shapes || !start || !counts_scratch || !odds || !drop || B <= 0 || S <= 0 || L <= 0 || L > 30)
+        return (int)hipErrorInvalidValue;
+    if ((uintptr_t)odds & 15) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(level_counts_kernel, dim3((unsigned)(B * L)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned char *>(mask), shapes, start, S, L, counts_scratch, (float *)nullptr);
+    const long long n = (long long)B * S;
+    hipLaunchKernelGGL(encoder_proposals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned char *>(mask), counts_scratch, shapes, start, B, S, L, odds,
+                       reinterpret_cast<unsigned char *>(drop));
     return (int)hipGetLastError();
 }

@@ -166,6 +166,7 @@ class Switches:
     """Module-level implementation switches (True = the leaner equivalent path)."""
     lean_mha = True
     small_attention = True   # lean_mha: materialised scores instead of the fused SDPA kernel for small problems
+    native_geometry = True   # valid ratios / encoder reference points / two-stage proposals from the padding mask in one launch each (geometry.py)
     fused_attention = True   # lean_mha: csrc/attn.hip for fp32 heads of width 32 without attention mask / dropout (the decoder's)
     fused_ffn_backward = True  # frozen FFNs: (gy @ W2) * (h > 0) in one native GEMM (csrc/gemm_drelu.hip) instead of mm + threshold_backward
     sort_for_topk = False    # select_queries: stable sort instead of torch.topk everywhere (developer switch)
@@ -868,6 +869,10 @@ class TransformerEncoder(nn.Module):
         """Pixel centres of every level, normalised by the valid extent and replicated over the
         levels: [bs, S, L, 2] (reference :482-497).  ``spatial_shapes``: list of (H, W) or tensor."""
         shapes = spatial_shapes.tolist() if torch.is_tensor(spatial_shapes) else spatial_shapes
+        if (Switches.native_geometry and valid_ratios.is_cuda and valid_ratios.dtype == torch.float32
+                and not valid_ratios.requires_grad and 0 < len(shapes) <= 30):
+            from . import geometry   # one launch instead of 38 (csrc/refpoints.hip), bit-identical
+            return geometry.encoder_reference_points(valid_ratios.contiguous(), shapes)
         refs = []
         for lvl, (H_, W_) in enumerate(shapes):
             H_, W_ = int(H_), int(W_)
@@ -1150,15 +1155,8 @@ class Transformer(nn.Module):
         """Device copies of spatial_shapes / level_start_index, built once per level geometry
         (the reference uploads them on every forward; a cached tensor also keeps the forward
         capturable into a hipGraph)."""
-        cache = self.__dict__.setdefault("_level_table_cache", {})
-        key = (shapes, str(device))
-        if key not in cache:
-            sh = torch.as_tensor(shapes, dtype=torch.long, device=device)
-            start = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
-            if len(cache) > 64:
-                cache.clear()
-            cache[key] = (sh, start)
-        return cache[key]
+        from . import geometry
+        return geometry.level_tables(shapes, device)
 
     def prepare_inputs(self, srcs, masks, pos_embeds):
         """Flatten the levels: (src [B,S,C], mask [B,S], pos+level_embed [B,S,C], shapes list,
@@ -1179,7 +1177,11 @@ class Transformer(nn.Module):
         # the op wants the level table on the device (int64); the host copy `shapes` is kept for
         # everything that only needs Python ints, so nothing reads the device tensor back
         spatial_shapes, level_start_index = self._level_tables(tuple(shapes), src_flatten.device)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        from . import geometry
+        if Switches.native_geometry and geometry.supported(mask_flatten, shapes):
+            valid_ratios = geometry.valid_ratios(mask_flatten, shapes)   # one launch instead of 36, bit-identical
+        else:
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         return (src_flatten, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes,
                 level_start_index, valid_ratios)
 

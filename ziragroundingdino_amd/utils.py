@@ -134,6 +134,13 @@ def gen_encoder_output_proposals(memory: Tensor, memory_padding_mask: Tensor, sp
     N, S, C = memory.shape
     shapes = [(int(h), int(w)) for h, w in (spatial_shapes.tolist() if torch.is_tensor(spatial_shapes)
                                             else spatial_shapes)]
+    if learnedwh is None and memory.is_cuda:
+        from . import geometry
+        from .transformer import Switches
+        if Switches.native_geometry and geometry.supported(memory_padding_mask, shapes):
+            # two launches and ATen's log instead of ~60 launch-bound kernels (csrc/refpoints.hip), bit-identical
+            output_proposals, drop = geometry.encoder_proposals(memory_padding_mask, shapes)
+            return memory.masked_fill(drop.unsqueeze(-1), 0.0), output_proposals
     proposals = []
     cur = 0
     for lvl, (H, W) in enumerate(shapes):
