@@ -463,6 +463,25 @@ int zira_encoder_proposals_f32(const void *mask, const int64_t *shapes, const in
                                float *counts_scratch, float *odds, void *drop, void *stream);
 
 
+/* The set-prediction losses of all S prediction sets of a step at once (SetCriterion.loss_labels / loss_boxes,
+ * criterion/criterion.py:104-181, with sigmoid_focal_loss :31-59 and generalized_box_iou util/box_ops.py:39-66):
+ *   logits [S, B, Q, C], boxes [S, B, Q, 4] (cx, cy, w, h);  matches q_idx / t_idx [S, M] int64 with image_of [M] int64: set s
+ *   matches query q_idx[s, k] of image image_of[k] with target t_idx[s, k] of the concatenated targets (labels [T] int64,
+ *   boxes_all [T, 4]); num_boxes: one float on the device.
+ *   out [3, S] = (focal loss summed over the set / num_boxes, sum of the pairs' L1 / num_boxes, sum of (1 - GIoU) / num_boxes).
+ * _bwd: g_out [3, S] -> g_logits [S, B, Q, C] and g_boxes [S, B, Q, 4] (either may be null), every element written.
+ * scratch: zira_stacked_losses_scratch_bytes(S, B, Q, M).  fp32 in the op chain's order, the focal sum reduced in double;
+ * gradients follow autograd's conventions at the kinks.  Return 0 or a hipError_t; enqueue only. */
+size_t zira_stacked_losses_scratch_bytes(int S, int B, int Q, int M);
+int zira_stacked_losses_fwd_f32(const float *logits, const float *boxes, const int64_t *q_idx, const int64_t *t_idx,
+                                const int64_t *image_of, const int64_t *labels, const float *boxes_all, const float *num_boxes,
+                                int S, int B, int Q, int C, int M, float alpha, float gamma, void *scratch, float *out, void *stream);
+int zira_stacked_losses_bwd_f32(const float *logits, const float *boxes, const int64_t *q_idx, const int64_t *t_idx,
+                                const int64_t *image_of, const int64_t *labels, const float *boxes_all, const float *num_boxes,
+                                const float *g_out, int S, int B, int Q, int C, int M, float alpha, float gamma, float *g_logits,
+                                float *g_boxes, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

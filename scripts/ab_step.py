@@ -39,6 +39,9 @@ for kv in sys.argv[1:]:
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
     elif k == "gemm_arith":
         zt.Switches.gemm_arith = v
+    elif k == "native_losses":
+        from ziragroundingdino_amd.criterion import TwoStageCriterion
+        TwoStageCriterion.native_losses = bool(int(v))
     elif hasattr(zt.Switches, k):      # any boolean of transformer.Switches (native_geometry, fused_attention, ...)
         setattr(zt.Switches, k, bool(int(v)))
     elif k == "dummy_launches":   # what a tiny launch costs the step: N extra [64, 256] adds per fusion block forward

@@ -45,6 +45,53 @@ class LossDict(dict):
     total = None
 
 
+class _StackedLosses(torch.autograd.Function):
+    """Focal / L1 / GIoU losses of all prediction sets from the device-side matches: csrc/criterion.hip, two launches forward
+    and one backward instead of ~60 + ~75 launch-bound ATen kernels (``_forward_stacked`` keeps the op chain for everything
+    this does not take).  -> [3, S] = (loss_class, loss_bbox, loss_giou) per set."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, q_idx, t_idx, image_of, labels_all, boxes_all, num_boxes, alpha, gamma):
+        from . import _lib
+        S, B, Q, C = logits.shape
+        M = q_idx.shape[1]
+        lib = _lib.load()
+        scratch = torch.empty(lib.zira_stacked_losses_scratch_bytes(S, B, Q, M), dtype=torch.uint8, device=logits.device)
+        out = torch.empty((3, S), dtype=torch.float32, device=logits.device)
+        logits, boxes = logits.contiguous(), boxes.contiguous()
+        nb = num_boxes.reshape(1)
+        with torch.cuda.device(logits.device):
+            rc = lib.zira_stacked_losses_fwd_f32(logits.data_ptr(), boxes.data_ptr(), q_idx.data_ptr(), t_idx.data_ptr(),
+                                                 image_of.data_ptr(), labels_all.data_ptr(), boxes_all.data_ptr(), nb.data_ptr(),
+                                                 S, B, Q, C, M, float(alpha), float(gamma), scratch.data_ptr(), out.data_ptr(),
+                                                 torch.cuda.current_stream(logits.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_stacked_losses_fwd_f32 failed: hipError %d" % rc)
+        ctx.save_for_backward(logits, boxes, q_idx, t_idx, image_of, labels_all, boxes_all, nb)
+        ctx.alpha, ctx.gamma = float(alpha), float(gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        logits, boxes, q_idx, t_idx, image_of, labels_all, boxes_all, nb = ctx.saved_tensors
+        S, B, Q, C = logits.shape
+        M = q_idx.shape[1]
+        g = g.contiguous()
+        g_logits = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        g_boxes = torch.empty_like(boxes) if ctx.needs_input_grad[1] else None
+        if g_logits is not None or g_boxes is not None:
+            with torch.cuda.device(logits.device):
+                rc = _lib.load().zira_stacked_losses_bwd_f32(
+                    logits.data_ptr(), boxes.data_ptr(), q_idx.data_ptr(), t_idx.data_ptr(), image_of.data_ptr(),
+                    labels_all.data_ptr(), boxes_all.data_ptr(), nb.data_ptr(), g.data_ptr(), S, B, Q, C, M, ctx.alpha, ctx.gamma,
+                    0 if g_logits is None else g_logits.data_ptr(), 0 if g_boxes is None else g_boxes.data_ptr(),
+                    torch.cuda.current_stream(logits.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError("zira_stacked_losses_bwd_f32 failed: hipError %d" % rc)
+        return g_logits, g_boxes, None, None, None, None, None, None, None, None
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, losses: List[str] = ["class", "boxes"],
                  eos_coef: float = 0.1, loss_class_type: str = "focal_loss", alpha: float = 0.25,
@@ -124,6 +171,7 @@ class TwoStageCriterion(SetCriterion):
         self.two_stage_binary_cls = two_stage_binary_cls
 
     _index_cache = {}
+    native_losses = True   # device-side matches: the focal / L1 / GIoU losses of all sets as one node (csrc/criterion.hip)
 
     @classmethod
     def _set_and_image_index(cls, S, sizes, Q, dev):
@@ -180,7 +228,17 @@ class TwoStageCriterion(SetCriterion):
 
         losses = LossDict()
         losses.stacked = {}
-        if "class" in self.losses:
+        if (self.native_losses and all_indices is None and "class" in self.losses and "boxes" in self.losses and q_dev.shape[1] > 0
+                and logits.dtype == torch.float32 and boxes.dtype == torch.float32 and boxes_all.dtype == torch.float32
+                and labels_all.dtype == torch.int64 and S <= 65535):
+            # every loss of every set in two launches (csrc/criterion.hip)
+            per = _StackedLosses.apply(logits, boxes, q_dev.contiguous(), t_dev.contiguous(), b_i[:q_dev.shape[1]].contiguous(),
+                                       labels_all.contiguous(), boxes_all.contiguous(), num_boxes, self.alpha, self.gamma)
+            for row, name in enumerate(("loss_class", "loss_bbox", "loss_giou")):
+                losses.stacked[name] = (per[row], list(suffixes))
+                for s, suf in enumerate(suffixes):
+                    losses[name + suf] = per[row, s]
+        elif "class" in self.losses:
             assert self.loss_class_type == "focal_loss"
             target_classes = torch.full((S, B, Q), self.num_classes, dtype=torch.int64, device=dev)
             target_classes[s_i, b_i, q_i] = labels_all[t_i]
@@ -197,7 +255,7 @@ class TwoStageCriterion(SetCriterion):
             losses.stacked["loss_class"] = (per_set, list(suffixes))
             for s, suf in enumerate(suffixes):
                 losses["loss_class" + suf] = per_set[s]
-        if "boxes" in self.losses:
+        if "boxes" in self.losses and "loss_bbox" not in losses.stacked:
             src = boxes[s_i, b_i, q_i]
             tgt = boxes_all[t_i]
             l1 = F.l1_loss(src, tgt, reduction="none").sum(-1)
