@@ -482,6 +482,15 @@ int zira_stacked_losses_bwd_f32(const float *logits, const float *boxes, const i
                                 float *g_boxes, void *stream);
 
 
+/* The box head's last step, elementwise (groundingdino_dual_zero_rep_branch.py:563-569, inverse_sigmoid util/misc.py:704-708):
+ *   out[i] = sigmoid(delta[i] + log(max(x, eps) / max(1 - x, eps))),  x = clamp(ref[i], 0, 1);
+ *   _bwd: g_delta[i] = g_out[i] out (1 - out);  g_ref[i] = g_delta[i] * ([x >= eps] / x + [1 - x >= eps] / (1 - x)) where
+ *   0 <= ref[i] <= 1, else 0 (autograd's clamp convention); either gradient may be null.  n elements, device pointers. */
+int zira_box_head_fwd_f32(const float *delta, const float *ref, long long n, float eps, float *out, void *stream);
+int zira_box_head_bwd_f32(const float *g_out, const float *out, const float *ref, long long n, float eps, float *g_delta,
+                          float *g_ref, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -219,6 +219,41 @@ __global__ __launch_bounds__(256) void encoder_proposals_kernel(const unsigned c
     drop[idx] = bad ? 1 : 0;
 }
 
+// ---- the box head's last step, elementwise: out = sigmoid(delta + inverse_sigmoid(ref)) and its gradients ----
+// (groundingdino_dual_zero_rep_branch.py:563-569 with inverse_sigmoid util/misc.py:704-708: as ATen ops 8 launches forward and
+//  ~20 backward on 43 200 elements; autograd's conventions at the clamps: the gradient passes where min <= x <= max)
+__global__ __launch_bounds__(256) void box_head_fwd_kernel(const float *__restrict__ delta, const float *__restrict__ ref, long long n,
+                                                           float eps, float *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = fminf(fmaxf(ref[i], 0.f), 1.f);
+    const float inv = logf(fmaxf(x, eps) / fmaxf(1.f - x, eps));
+    out[i] = 1.f / (1.f + expf(-(delta[i] + inv)));
+}
+
+__global__ __launch_bounds__(256) void box_head_bwd_kernel(const float *__restrict__ g_out, const float *__restrict__ out,
+                                                           const float *__restrict__ ref, long long n, float eps,
+                                                           float *__restrict__ g_delta, float *__restrict__ g_ref)
+{
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = out[i];
+    const float gu = g_out[i] * (s * (1.f - s));
+    if (g_delta) g_delta[i] = gu;
+    if (g_ref) {
+        const float r = ref[i];
+        float d = 0.f;
+        if (r >= 0.f && r <= 1.f) {
+            const float om = 1.f - r;
+            d = (r >= eps ? 1.f / r : 0.f) + (om >= eps ? 1.f / om : 0.f);
+        }
+        g_ref[i] = gu * d;
+    }
+}
+
 }  // namespace
 
 extern "C" int zira_box_refine_fwd_f32(const float *h, const float *w, const float *b, const float *ref, long long rows, int K,
@@ -297,5 +332,23 @@ extern "C" int zira_encoder_proposals_f32(const void *mask, const int64_t *shape
     hipLaunchKernelGGL(encoder_proposals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned char *>(mask), counts_scratch, shapes, start, B, S, L, odds,
                        reinterpret_cast<unsigned char *>(drop));
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_box_head_fwd_f32(const float *delta, const float *ref, long long n, float eps, float *out, void *stream)
+{
+    if (!delta || !ref || !out || n < 0) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(box_head_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, ref, n, eps, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_box_head_bwd_f32(const float *g_out, const float *out, const float *ref, long long n, float eps, float *g_delta,
+                                     float *g_ref, void *stream)
+{
+    if (!g_out || !out || !ref || (!g_delta && !g_ref) || n < 0) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(box_head_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out, out, ref, n,
+                       eps, g_delta, g_ref);
     return (int)hipGetLastError();
 }

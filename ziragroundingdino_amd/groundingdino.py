@@ -35,7 +35,7 @@ from .rsb import RepZeroConv2d, RepZeroLinear
 from .structures import Boxes, ImageList, Instances
 from .text_masks import generate_masks_with_special_tokens_and_transfer_map
 from .transformer import build_transformer
-from .utils import (MLP, ContrastiveEmbed, NestedTensor, inverse_sigmoid,
+from .utils import (MLP, ContrastiveEmbed, NestedTensor, box_head, inverse_sigmoid,
                     nested_tensor_from_tensor_list, recover_to_cls_logits)
 
 
@@ -508,7 +508,7 @@ class GroundingDINO(nn.Module):
         if shared_heads:
             hs_all = torch.stack(list(hs))                                   # [L, B, Q, d]
             ref_all = torch.stack(list(reference[:-1]))
-            outputs_coord_list = (self.bbox_embed[0](hs_all) + inverse_sigmoid(ref_all)).sigmoid()
+            outputs_coord_list = box_head(self.bbox_embed[0](hs_all), ref_all)
             cls_in = torch.cat([hs_all, hs_enc[-1][None]]) if with_enc else hs_all
             cls_all = recover_to_cls_logits(self.class_embed[0](cls_in, text_dict),
                                             cate_to_token_mask_list, for_fill=-100.0)

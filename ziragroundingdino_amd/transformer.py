@@ -598,29 +598,29 @@ class BiAttentionBlock(nn.Module):
             return v + self.drop_path(self.gamma_v * delta_v), l + self.drop_path(self.gamma_l * delta_l)
         # the image-side residual rides in the attention's last GEMM when it can (the scale is drawn when that GEMM is
         # reached: after everything the attention itself draws, as in the reference's order)
-        in_gemm = (lambda: self._scale(self.gamma_v, v)) if self.residual_in_gemm and not self.gamma_v.requires_grad else None
+        drawn = []     # the two stochastic-depth factors of this block come from ONE draw ([2, B, 1, 1]: image side, text side)
+
+        def scale_of(gamma, x, side):
+            dp = self.drop_path
+            if not (isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training):
+                return gamma
+            if not drawn:
+                keep = 1 - dp.drop_prob
+                drawn.append(x.new_empty((2, x.shape[0]) + (1,) * (x.ndim - 1)).bernoulli_(keep).div_(keep))
+            return gamma * drawn[0][side]
+
+        in_gemm = (lambda: scale_of(self.gamma_v, v, 0)) if self.residual_in_gemm and not self.gamma_v.requires_grad else None
         got = self.attn(v, l, attention_mask_v=attention_mask_v, attention_mask_l=attention_mask_l, residual_v=in_gemm)
         if len(got) == 3:
-            return got[0], self._residual(l, self.gamma_l, got[1])
-        return self._residual(v, self.gamma_v, got[0]), self._residual(l, self.gamma_l, got[1])
+            return got[0], torch.addcmul(l, got[1], scale_of(self.gamma_l, l, 1))
+        return torch.addcmul(v, got[0], scale_of(self.gamma_v, v, 0)), torch.addcmul(l, got[1], scale_of(self.gamma_l, l, 1))
 
     fused_residual = True     # class-level switches for A/B runs
     residual_in_gemm = True
 
-    def _scale(self, gamma, x):
-        """gamma, times the per-sample stochastic-depth factor as a [B, 1, C] tensor when it is drawn."""
-        dp = self.drop_path
-        if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
-            keep = 1 - dp.drop_prob
-            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep).div_(keep)
-            return gamma * mask
-        return gamma
-
-    def _residual(self, x, gamma, delta):
-        """x + drop_path(gamma * delta) as one pass: the layer scale and the per-sample stochastic-depth
-        factor are folded into a [B, 1, C] scale first (the reference's three elementwise passes over the
-        [B, S, 256] image tokens -- scale, mask, add -- move 2.7x the bytes; same draws from the RNG)."""
-        return torch.addcmul(x, delta, self._scale(gamma, delta))
+    # (x + drop_path(gamma * delta) is one addcmul: the layer scale and the per-sample stochastic-depth factor are folded into a
+    #  [B, 1, C] scale first -- the reference's three elementwise passes over the [B, S, 256] image tokens, scale, mask, add, move
+    #  2.7x the bytes.  Round 5: the two factors of a block come from one bernoulli call -- same distribution, two launches fewer.)
 
 
 class TransformerEncoderLayer(nn.Module):

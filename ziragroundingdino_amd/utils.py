@@ -49,6 +49,50 @@ def inverse_sigmoid(x, eps=1e-3):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
+class _BoxHead(torch.autograd.Function):
+    """sigmoid(delta + inverse_sigmoid(ref)) as one node: csrc/refpoints.hip, one launch forward and one backward instead of
+    8 + ~20 ATen kernels (the box head of groundingdino_dual_zero_rep_branch.py:563-569 over all decoder layers at once)."""
+
+    @staticmethod
+    def forward(ctx, delta, ref, eps):
+        from . import _lib
+        delta, ref = delta.contiguous(), ref.contiguous()
+        out = torch.empty_like(delta)
+        with torch.cuda.device(delta.device):
+            rc = _lib.load().zira_box_head_fwd_f32(delta.data_ptr(), ref.data_ptr(), delta.numel(), float(eps), out.data_ptr(),
+                                                   torch.cuda.current_stream(delta.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_box_head_fwd_f32 failed: hipError %d" % rc)
+        ctx.save_for_backward(out, ref)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        out, ref = ctx.saved_tensors
+        g = g.contiguous()
+        g_delta = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        g_ref = torch.empty_like(out) if ctx.needs_input_grad[1] else None
+        if g_delta is not None or g_ref is not None:
+            with torch.cuda.device(out.device):
+                rc = _lib.load().zira_box_head_bwd_f32(g.data_ptr(), out.data_ptr(), ref.data_ptr(), out.numel(), ctx.eps,
+                                                       0 if g_delta is None else g_delta.data_ptr(),
+                                                       0 if g_ref is None else g_ref.data_ptr(),
+                                                       torch.cuda.current_stream(out.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError("zira_box_head_bwd_f32 failed: hipError %d" % rc)
+        return g_delta, g_ref, None
+
+
+def box_head(delta, ref, eps=1e-3):
+    """``(delta + inverse_sigmoid(ref, eps)).sigmoid()``; fp32 GPU tensors of one shape go through one native node."""
+    if (delta.is_cuda and delta.dtype == torch.float32 and ref.dtype == torch.float32 and delta.shape == ref.shape
+            and ref.device == delta.device and not torch.is_autocast_enabled("cuda")):
+        return _BoxHead.apply(delta, ref, eps)
+    return (delta + inverse_sigmoid(ref, eps)).sigmoid()
+
+
 class MLP(nn.Module):
     """num_layers Linear layers with ReLU in between (state-dict keys ``layers.{i}.*``)."""
 
