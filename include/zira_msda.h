@@ -491,6 +491,32 @@ int zira_box_head_bwd_f32(const float *g_out, const float *out, const float *ref
                           float *g_ref, void *stream);
 
 
+/* The text side of an image <-> text fusion block whose six projections are frozen and composed (BiMultiHeadAttention /
+ * BiAttentionBlock, fuse_modules.py:99-305; this package's re-bracketing around the B x T text tokens): M = B T rows,
+ * H heads, image width Dv, text width Dl.  All fp32, contiguous, on the device; enqueue only; 0 or a hipError_t.
+ * zira_text_prep_fwd_f32: l_ln [B, T, Dl] = LayerNorm(l_in; ln_w, ln_b, eps), stats [M, 2] = (mean, rstd), and
+ *     [A | C | Z] = l_ln W1 + b1 (W1 [Dl, 2 H Dv + H] = [AC | Z] of _composed_text_side) scattered as
+ *     a [B, Dv, H T] (a[b, d, h T + t] = A[b t, h Dv + d]),  c [B, H T],  z [B, H T, Dv].
+ * zira_text_prep_bwd_f32: g_l_in [B, T, Dl] from g_a / g_c / g_z (same layouts; any may be null) and g_l_ln (the gradient that
+ *     reaches l_ln directly; may be null); W1T [2 H Dv + H, Dl] = W1 transposed; scratch: zira_text_side_scratch_floats floats
+ *     (the partial products of the K split; also enough for zira_text_out_fwd_f32).
+ * zira_text_out_fwd_f32: out [B, T, Dl] = l_ln + scale (o0 + U O),  U[b t, h Dv + d] = u[b, h T + t, d] / colsum[b, h T + t],
+ *     O [H Dv, Dl], scale[b, n] = gamma[n] * keep[b] (keep: the per-sample stochastic-depth factor, may be null).
+ * zira_text_out_bwd_f32: g [B, T, Dl] -> g_u [B, H T, Dv], g_colsum [B, H T]  (the gradient of l_ln is g itself); OT [Dl, H Dv] =
+ *     O transposed.  Limit: Dl <= 256 (otherwise hipErrorInvalidValue). */
+size_t zira_text_side_scratch_floats(int B, int T, int H, int Dv, int Dl);
+int zira_text_prep_fwd_f32(const float *l_in, const float *ln_w, const float *ln_b, float eps, const float *W1, const float *b1,
+                           int B, int T, int H, int Dv, int Dl, float *l_ln, float *a, float *c, float *z, float *stats, void *stream);
+int zira_text_prep_bwd_f32(const float *g_a, const float *g_c, const float *g_z, const float *g_l_ln, const float *l_in,
+                           const float *ln_w, const float *stats, const float *W1T, int B, int T, int H, int Dv, int Dl,
+                           float *scratch, float *g_l_in, void *stream);
+int zira_text_out_fwd_f32(const float *u, const float *colsum, const float *l_ln, const float *O, const float *o0,
+                          const float *gamma, const float *keep, int B, int T, int H, int Dv, int Dl, float *scratch, float *out,
+                          void *stream);
+int zira_text_out_bwd_f32(const float *g, const float *u, const float *colsum, const float *OT, const float *gamma,
+                          const float *keep, int B, int T, int H, int Dv, int Dl, float *g_u, float *g_colsum, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

@@ -39,6 +39,8 @@ for kv in sys.argv[1:]:
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
     elif k == "gemm_arith":
         zt.Switches.gemm_arith = v
+    elif k == "native_text_side":
+        zt.BiAttentionBlock.native_text_side = bool(int(v))
     elif k == "native_losses":
         from ziragroundingdino_amd.criterion import TwoStageCriterion
         TwoStageCriterion.native_losses = bool(int(v))

@@ -455,6 +455,8 @@ class BiMultiHeadAttention(nn.Module):
                        torch.einsum("hel,dhe->lhd", Wvl, Wo).flatten(1), torch.einsum("he,dhe->hd", bvl, Wo).flatten(),
                        torch.einsum("hed,lhe->hdl", Wvv, Wol).flatten(0, 1), torch.einsum("he,lhe->l", bvv, Wol) + bol]
                 new = [t.float().contiguous() for t in new]
+                w1 = torch.cat([new[0], new[2]], 1).contiguous()      # [AC | Z], its bias, and the two transposes text_side.py reads
+                new += [w1, torch.cat([new[1], new[3]]).contiguous(), w1.t().contiguous(), new[4].t().contiguous()]
                 if cached is not None and all(o.shape == n.shape and o.device == n.device for o, n in zip(cached[1], new)):
                     for o, n in zip(cached[1], new):
                         o.copy_(n)
@@ -490,7 +492,7 @@ class BiMultiHeadAttention(nn.Module):
             fused = self.fused_softmax and bi_softmax_supported(v, H, src_len, self.training and self.dropout > 0)
             composed = self._composed_text_side(l) if fused else None
             if composed is not None:   # the text side's double projections as one constant matrix each (see there)
-                AC, ac0, Z, z0, O, o0 = composed
+                AC, ac0, Z, z0, O, o0 = composed[:6]
                 l2 = l.reshape(bsz * src_len, -1)
                 ac = torch.addmm(ac0, l2, AC).view(bsz, src_len, -1)
                 a = ac[..., :H * self.v_dim].reshape(bsz, src_len, H, self.v_dim).permute(0, 3, 2, 1)   # [B, v_dim, H, T]
@@ -592,6 +594,10 @@ class BiAttentionBlock(nn.Module):
 
     def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
         v = self.layer_norm_v(v)
+        if self.native_text_side and self.fused_residual and self.residual_in_gemm and not self.gamma_v.requires_grad:
+            got = self._forward_native_text(v, l, attention_mask_v, attention_mask_l)
+            if got is not None:
+                return got
         l = self.layer_norm_l(l)
         if not self.fused_residual:
             delta_v, delta_l = self.attn(v, l, attention_mask_v=attention_mask_v, attention_mask_l=attention_mask_l)
@@ -617,6 +623,37 @@ class BiAttentionBlock(nn.Module):
 
     fused_residual = True     # class-level switches for A/B runs
     residual_in_gemm = True
+    native_text_side = True   # frozen composed projections: the text side as two native nodes (text_side.py)
+
+    def _forward_native_text(self, v, l, attention_mask_v, attention_mask_l):
+        """The fused, re-bracketed block with its text side on csrc/textside.hip: LayerNorm of the text, the composed
+        projections in the layouts the image-side GEMMs read, and the text output with its residual -- 6 launches instead of
+        ~41 (same arithmetic up to fp32 summation order; ``v`` is already normalised).  None when it does not apply."""
+        from . import text_side
+        att = self.attn
+        bsz, _, _ = v.shape
+        T, H = l.size(1), att.num_heads
+        if not (att.reassociate and l.is_cuda and att.fused_softmax
+                and bi_softmax_supported(v, H, T, att.training and att.dropout > 0)):
+            return None
+        composed = att._composed_text_side(l)
+        if not text_side.supported(l, self.layer_norm_l, self.gamma_l, composed):
+            return None
+        O, o0, W1, b1, W1T, OT = composed[4:10]
+        dp = self.drop_path
+        keep = None
+        if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
+            kp = 1 - dp.drop_prob
+            keep = v.new_empty((2, bsz)).bernoulli_(kp).div_(kp)      # one draw: image side, text side
+        l_ln, a, c, z = text_side.text_prep(l, self.layer_norm_l, W1, b1, W1T, H, att.v_dim)
+        xm = wide_matmul(v, a)
+        pv, e, colsum = bi_softmax(xm, c, attention_mask_l, attention_mask_v, H, T, att.stable_softmax_2d,
+                                   att.clamp_min_for_underflow, att.clamp_max_for_overflow)
+        out_l = text_side.text_out(tall_reduce_nt(e, v), colsum, l_ln, O, OT, o0, self.gamma_l, None if keep is None else keep[1], H)
+        scale = self.gamma_v if keep is None else self.gamma_v * keep[0].view(bsz, 1, 1)
+        if wide_matmul_residual_supported(pv, z, att.out_v_proj.bias, v, scale):
+            return wide_matmul_residual(pv, z, att.out_v_proj.bias, v, scale), out_l
+        return torch.addcmul(v, wide_matmul(pv, z, att.out_v_proj.bias), scale), out_l
 
     # (x + drop_path(gamma * delta) is one addcmul: the layer scale and the per-sample stochastic-depth factor are folded into a
     #  [B, 1, C] scale first -- the reference's three elementwise passes over the [B, S, 256] image tokens, scale, mask, add, move
