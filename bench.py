@@ -522,6 +522,9 @@ def main():
     ap.add_argument("--no-gemm-arith-mode", action="store_true",
                     help="skip the extra timed regions with the frozen FFN products in split-bf16 arithmetic on the bf16 matrix "
                          "cores (csrc/gemm_bf16x3.hip); `value` is always the plain fp32 arithmetic")
+    ap.add_argument("--gemm-arith", default="f32", choices=["f32", "bf16x3"],
+                    help="arithmetic of the frozen 44 446-row products for THIS process's timed steps (the default run measures "
+                         "bf16x3 in a child process started with this flag and reports it beside the headline)")
     ap.add_argument("--no-second-mode", action="store_true",
                     help="skip the second timed region in the other launch mode (eager <-> hipGraph replay)")
     args = ap.parse_args()
@@ -535,6 +538,26 @@ def main():
     # encoder pieces are host-sensitive, and eight unpinned ranks share and migrate across cores)
     from ziragroundingdino_amd import placement
     pinned = placement.pin_this_rank(verbose=(rank == 0 or os.environ.get("ZIRA_VERBOSE_PLACEMENT") == "1"))
+    # The split-bf16 arithmetic is timed in a CHILD process of its own, run to completion BEFORE this process touches the GPU:
+    # a second configuration timed in the process that has already captured and timed the first comes out 1-3 ms per step
+    # slower whatever it is (scripts/ab_step.py's note; round 5: 36.5 ms in-process against 32.2 ms alone), and a process that
+    # has initialised the GPU must not start programs on this pool.  One GPU, the flagship configuration, fp32 only.
+    arith_child = None
+    if (world == 1 and "WORLD_SIZE" not in os.environ and not args.no_gemm_arith_mode and args.dtype == "f32"
+            and args.backbone == "swin_T_224_1k" and args.gemm_arith == "f32"):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gemm-arith", "bf16x3", "--no-gemm-arith-mode", "--no-second-mode",
+               "--no-micro", "--no-cpu-baseline", "--kernel-timing-steps", "0", "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--regions", str(args.regions), "--batch", str(args.batch), "--height", str(args.height),
+               "--width", str(args.width), "--categories", str(args.categories), "--minibatches", str(args.minibatches)]
+        cmd += [] if args.transformer_graph else ["--no-transformer-graph"]
+        cmd += [] if args.prefetch else ["--no-prefetch"]
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            arith_child = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:   # the headline does not depend on it
+            print("[bench] bf16x3 child run failed (%s); entry omitted" % (str(e).splitlines()[0] if str(e) else repr(e)),
+                  file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # (test hooks: ZIRA_BENCH_DEVICE pins every rank to one GPU and ZIRA_BENCH_BACKEND=gloo carries the collectives through
@@ -567,6 +590,9 @@ def main():
     print("[bench] rank %d/%d on cuda:%d, launch mode %s, %s" % (
         rank, world, dev_index, "graph" if args.transformer_graph else "eager",
         "pinned to %d cores" % len(pinned) if pinned else "not pinned"), file=sys.stderr, flush=True)
+    if args.gemm_arith != "f32":
+        from ziragroundingdino_amd import transformer as _tr0
+        _tr0.Switches.gemm_arith = args.gemm_arith
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
     model.use_transformer_graph = args.transformer_graph
@@ -631,13 +657,23 @@ def main():
         model.use_transformer_graph = args.transformer_graph
     # The same steps once more with the encoder FFN's frozen products in split-bf16 (bf16x3) arithmetic: fp32-accurate by the
     # gate of tests/test_gemm_bf16x3_gpu.py, reported BESIDE the headline (config.gemm_arith), never as `value`.
-    arith_regions = None
-    if not args.no_gemm_arith_mode and args.dtype == "f32" and args.backbone == "swin_T_224_1k":
+    arith_regions = arith_how = None
+    if arith_child is not None:
+        try:
+            mode = arith_child["config"]["launch_modes"][arith_child["config"]["launch_mode"]]
+            arith_regions = [x * args.steps / 1e3 for x in mode["regions_ms_per_step"]]
+            arith_how = ("a child process of this command (python bench.py --gemm-arith bf16x3 ...), run before this process "
+                         "touched the GPU; same GPU, launch mode %s" % arith_child["config"]["launch_mode"])
+        except (KeyError, TypeError):
+            pass
+    elif (dist_on and not args.no_gemm_arith_mode and args.dtype == "f32" and args.backbone == "swin_T_224_1k"
+          and args.gemm_arith == "f32"):
         from ziragroundingdino_amd import transformer as _tr
         _tr.Switches.gemm_arith = "bf16x3"
         try:
             run_steps(max(2, args.warmup))
             arith_regions = [timed(args.steps) for _ in range(regions)]
+            arith_how = "the same processes, after the headline's regions (N > 1: every rank switches; in-process, so 1-3 ms pessimistic)"
         finally:
             _tr.Switches.gemm_arith = "f32"
         run_steps(1)
@@ -773,15 +809,18 @@ def main():
                                      "regions_ms_per_step": [x / args.steps * 1e3 for x in all_regions[k]]}
                                  for k, v in sorted(modes.items())},
                 "value_is": "median of %d timed regions of %d steps in the configured launch mode (%s)"
-                            % (regions, args.steps, primary_mode),
-                "gemm_arith": {"f32": {"images_per_s": images / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
-                                       "note": "the library's fp32 GEMMs: `value`"},
+                            % (regions, args.steps, primary_mode)
+                            + ("" if args.gemm_arith == "f32" else "; STARTED WITH --gemm-arith %s: not the plain-fp32 headline" % args.gemm_arith),
+                "gemm_arith": {args.gemm_arith: {"images_per_s": images / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                                                 "note": "the library's fp32 GEMMs: `value`" if args.gemm_arith == "f32" else
+                                                         "this process was started with --gemm-arith bf16x3"},
                                **({"bf16x3": {"images_per_s": images / sorted(arith_regions)[len(arith_regions) // 2],
                                               "ms_per_step": sorted(arith_regions)[len(arith_regions) // 2] / args.steps * 1e3,
                                               "regions_ms_per_step": [x / args.steps * 1e3 for x in arith_regions],
                                               "note": "encoder FFN products (4 per layer) as split-bf16 sums on the bf16 matrix "
                                                       "cores, fp32-accurate against fp64 (tests/test_gemm_bf16x3_gpu.py); same "
-                                                      "launch mode as `value`; not the headline"}}
+                                                      "launch mode as `value`; not the headline",
+                                              "measured_in": arith_how}}
                                   if arith_regions else {})},
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "ranks_pinned_to_numa_cores": bool(pinned),
