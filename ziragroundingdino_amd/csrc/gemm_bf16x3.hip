@@ -190,7 +190,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16x3_kernel(const float *_
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             uint2 p1, p2, p3;
+#if defined(ZIRA_G3_DEV_NOSPLIT)   // (developer ablation: what the split costs -- wrong results)
+            p1.x = __float_as_uint(ra[j].x); p1.y = __float_as_uint(ra[j].y); p2.x = __float_as_uint(ra[j].z); p2.y = __float_as_uint(ra[j].w);
+            p3 = p1;
+#else
             split4(ra[j], p1, p2, p3);
+#endif
             unsigned char *d = wa + 32 * j * kRow;
             *reinterpret_cast<uint2 *>(d) = p1;
             *reinterpret_cast<uint2 *>(d + BM * kRow) = p2;

@@ -1552,6 +1552,11 @@ int planned_backward(const float *grad_out, const float *value, const int64_t *s
 
 extern "C" {
 
+#ifndef ZIRA_FWD_PATCH
+#define ZIRA_FWD_PATCH 0   // 1 (developer builds: scripts/build_variant.sh with EXTRA_SRC=dev/msda_patch.hip): dense calls with Q = S and D = 32
+                           // take the LDS-patch forward of csrc/dev/msda_patch.hip -- correct, and slower than the lean kernel
+#endif
+
 int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *start,
                       const float *loc, const float *attn, int B, int S, int M, int D, int L,
                       int Q, int P, float *out, void *stream)
@@ -1559,6 +1564,12 @@ int zira_msda_fwd_f32(const float *value, const int64_t *shapes, const int64_t *
     if (!args_ok(value, shapes, start, loc, attn, B, S, M, D, L, Q, P) || !out)
         return ZIRA_MSDA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+#if ZIRA_FWD_PATCH
+    if (D == 32 && Q == S && (unsigned long long)B * M * Q >= 16 * 4096) {   // every pixel is a query (the encoder): LDS patches
+        const int rc = zira::patch_forward_f32(value, shapes, start, loc, attn, B, S, M, D, L, Q, P, out, st);
+        if (rc != -1) return rc;
+    }
+#endif
     if (lean_ok(B, S, M, D, L, Q, P)) {
         if (D == 16) return launch_fwd_lean<1>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);
         if (D == 32) return launch_fwd_lean<2>(value, shapes, start, loc, attn, B, S, M, L, Q, P, out, st);

@@ -36,6 +36,11 @@ int tiles_backward_planned_f32(const float *grad_out, const float *value, const 
                                float *grad_value, float *grad_loc, float *grad_attn, void *plan, size_t plan_bytes,
                                hipStream_t st);
 
+// Forward for calls in which every pixel is a query (Q = S, D = 32: the encoder): value patches staged in LDS
+// (csrc/msda_patch.hip).  -1: not applicable (the caller takes the lean kernel), else a hipError_t.
+int patch_forward_f32(const float *value, const int64_t *shapes, const int64_t *start, const float *loc, const float *attn, int B,
+                      int S, int M, int D, int L, int Q, int P, float *out, hipStream_t st);
+
 }  // namespace zira
 
 #endif
