@@ -90,6 +90,8 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()
 model.use_transformer_graph = False
+if os.environ.get("FRONTEND_EAGER") == "1":     # the frozen front end (Swin, BERT) launched eagerly too: its ops become visible
+    model.use_frontend_graphs = False
 trainer = ZiraTrainer(model)
 batches = [synthetic_batch(2, 800, 1333, n_categories=15, seed=i, device=dev) for i in range(2)]
 for i in range(2):
