@@ -517,6 +517,15 @@ int zira_text_out_bwd_f32(const float *g, const float *u, const float *colsum, c
                           const float *keep, int B, int T, int H, int Dv, int Dl, float *g_u, float *g_colsum, void *stream);
 
 
+/* Sine position encoding of one feature level from its padding mask (PositionEmbeddingSineHW, position_encoding.py:78-134):
+ *   mask [B, H, W] bytes (non-zero = padded);  dim_t_y / dim_t_x [F] = temperature^(2 (i // 2) / F) (the caller forms them with the
+ *   reference's ops once);  out [B, H, W, 2 F] = (pos_y | pos_x) -- the reference's [B, 2 F, H, W] result is a permuted view of it.
+ *   normalize: embed / (last + eps) * scale.  The same separately rounded fp32 operations and libm's sinf / cosf: bit-identical to
+ *   the op chain (~15 ATen launches per level).  F even.  Return 0 or a hipError_t; enqueue only. */
+int zira_sine_pos_hw_f32(const void *mask, int B, int H, int W, int F, int normalize, float scale, float eps, const float *dim_t_y,
+                         const float *dim_t_x, float *out, void *stream);
+
+
 /* Human-readable build tag, e.g. "zira_msda 0.1 gfx950". Static storage. */
 const char *zira_msda_version(void);
 

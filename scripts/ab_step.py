@@ -39,6 +39,9 @@ for kv in sys.argv[1:]:
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
     elif k == "gemm_arith":
         zt.Switches.gemm_arith = v
+    elif k == "native_pos":
+        from ziragroundingdino_amd.backbone import PositionEmbeddingSineHW
+        PositionEmbeddingSineHW.native = bool(int(v))
     elif k == "native_text_side":
         zt.BiAttentionBlock.native_text_side = bool(int(v))
     elif k == "native_losses":

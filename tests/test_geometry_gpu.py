@@ -78,3 +78,27 @@ def test_proposal_memory_gradient_is_masked_like_the_reference():
         finally:
             zt.Switches.native_geometry = old
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("hw", [(100, 167), (13, 21), (1, 1), (7, 300)])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_sine_position_encoding_is_bit_identical_to_the_op_chain(hw, normalize):
+    """PositionEmbeddingSineHW (position_encoding.py:78-134) in one launch per level against its ATen op chain, which the
+    package keeps for CPU masks: rectangular padding, ragged masks and fully padded rows / columns."""
+    from ziragroundingdino_amd import backbone
+    from ziragroundingdino_amd.utils import NestedTensor
+    H, W = hw
+    gen = torch.Generator().manual_seed(H * 31 + W)
+    masks = torch.zeros(3, H, W, dtype=torch.bool)
+    masks[1, H - H // 3:, :] = True
+    masks[1, :, W - W // 4:] = True
+    masks[2] = torch.rand(H, W, generator=gen) < 0.3
+    masks = masks.cuda()
+    pe = backbone.PositionEmbeddingSineHW(128, temperatureH=20, temperatureW=20, normalize=normalize)
+    x = NestedTensor(torch.zeros(3, 4, H, W, device="cuda"), masks)
+    pe.native = False
+    ref = pe(x)
+    pe.native = True
+    got = pe(x)
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref)

@@ -26,7 +26,7 @@ SYMBOLS = (
     "zira_split_bf16x3_f32", "zira_gemm_bf16x3_f32",
     "zira_stacked_losses_scratch_bytes", "zira_stacked_losses_fwd_f32", "zira_stacked_losses_bwd_f32",
     "zira_text_side_scratch_floats", "zira_text_prep_fwd_f32", "zira_text_prep_bwd_f32", "zira_text_out_fwd_f32", "zira_text_out_bwd_f32",
-    "zira_box_head_fwd_f32", "zira_box_head_bwd_f32",
+    "zira_sine_pos_hw_f32", "zira_box_head_fwd_f32", "zira_box_head_bwd_f32",
     "zira_level_valid_ratios_f32", "zira_encoder_ref_points_f32", "zira_encoder_proposals_f32",
     "zira_msda_version", "zira_msda_variant_f32",
 )
@@ -123,6 +123,8 @@ def load():
     lib.zira_text_out_fwd_f32.restype = i
     lib.zira_text_out_bwd_f32.argtypes = [vp] * 6 + [i] * 5 + [vp, vp, vp]
     lib.zira_text_out_bwd_f32.restype = i
+    lib.zira_sine_pos_hw_f32.argtypes = [vp, i, i, i, i, i, f32_, f32_, vp, vp, vp, vp]
+    lib.zira_sine_pos_hw_f32.restype = i
     lib.zira_box_head_fwd_f32.argtypes = [vp, vp, ctypes.c_longlong, f32_, vp, vp]
     lib.zira_box_head_fwd_f32.restype = i
     lib.zira_box_head_bwd_f32.argtypes = [vp, vp, vp, ctypes.c_longlong, f32_, vp, vp, vp]

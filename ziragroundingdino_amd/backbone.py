@@ -305,8 +305,33 @@ class PositionEmbeddingSineHW(nn.Module):
         self.normalize = normalize
         self.scale = 2 * math.pi if scale is None else scale
 
+    native = True   # GPU masks: one launch per level (csrc/refpoints.hip zira_sine_pos_hw_f32), bit-identical to the op chain below
+
+    def _dim_t(self, device):
+        """temperature ** (2 (i // 2) / F) for both axes, formed with the reference's ops, once per device."""
+        cache = self.__dict__.setdefault("_dim_t_cache", {})
+        key = str(device)
+        if key not in cache:
+            i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=device)
+            expo = 2 * torch.div(i, 2, rounding_mode="floor") / self.num_pos_feats
+            cache[key] = ((self.temperatureH ** expo).contiguous(), (self.temperatureW ** expo).contiguous())
+        return cache[key]
+
     def forward(self, tensor_list: NestedTensor):
         mask = tensor_list.mask
+        if self.native and mask.is_cuda and mask.dtype == torch.bool and mask.dim() == 3 and self.num_pos_feats % 2 == 0:
+            from . import _lib
+            m = mask.contiguous()
+            B, H, W = m.shape
+            dty, dtx = self._dim_t(m.device)
+            out = torch.empty((B, H, W, 2 * self.num_pos_feats), device=m.device, dtype=torch.float32)
+            with torch.cuda.device(m.device):
+                rc = _lib.load().zira_sine_pos_hw_f32(m.data_ptr(), B, H, W, self.num_pos_feats, int(bool(self.normalize)),
+                                                      float(self.scale), 1e-6, dty.data_ptr(), dtx.data_ptr(), out.data_ptr(),
+                                                      torch.cuda.current_stream(m.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError("zira_sine_pos_hw_f32 failed: hipError %d" % rc)
+            return out.permute(0, 3, 1, 2)
         not_mask = ~mask
         y_embed = not_mask.cumsum(1, dtype=torch.float32)
         x_embed = not_mask.cumsum(2, dtype=torch.float32)

@@ -254,6 +254,56 @@ __global__ __launch_bounds__(256) void box_head_bwd_kernel(const float *__restri
     }
 }
 
+// ---- sine position encoding of a feature level from its padding mask (PositionEmbeddingSineHW, position_encoding.py:78-134) ----
+// out[b, y, x, :] = (pos_y | pos_x), pos_*[i] = sin / cos (even / odd i) of embed / dim_t[i]; embed_y = number of unpadded pixels of
+// column x in rows 0 .. y (cumsum), embed_x along the row; normalised: embed / (last + eps) * scale.  As ATen ops: two cumsums, the
+// normalisation, two pow / div, four sin / cos, two stacks, a cat -- ~15 launches per level, most of them passes over the level's
+// [B, H, W, 256] output.  Here: a block per (b, y) image row; same separately rounded fp32 operations, bit-identical.
+__global__ __launch_bounds__(256) void sine_pos_hw_kernel(const unsigned char *__restrict__ mask, int H, int W, int F, int normalize,
+                                                          float scale, float eps, const float *__restrict__ dim_t_y,
+                                                          const float *__restrict__ dim_t_x, float *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float sm[];     // [W] embed_y, [W] embed_x
+    float *ey = sm, *ex = sm + W;
+    __shared__ float x_last;
+    const int b = blockIdx.x / H, y = blockIdx.x - b * H;
+    const unsigned char *m = mask + (size_t)b * H * W;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int upto = 0, total = 0;
+        for (int yy = 0; yy < H; ++yy) {
+            const int v = m[(size_t)yy * W + x] ? 0 : 1;
+            total += v;
+            upto += yy <= y ? v : 0;
+        }
+        int left = 0;
+        for (int xx = 0; xx <= x; ++xx) left += m[(size_t)y * W + xx] ? 0 : 1;
+        float fy = (float)upto, fx = (float)left;
+        if (normalize) fy = __fmul_rn(__fdiv_rn(fy, __fadd_rn((float)total, eps)), scale);
+        ey[x] = fy;
+        ex[x] = fx;                       // (normalised below: the row's last element first)
+        if (x == W - 1) x_last = fx;
+    }
+    __syncthreads();
+    const float xl = x_last;
+    const int C = 2 * F;
+    float *o = out + ((size_t)b * H + y) * W * C;
+    for (int i = threadIdx.x; i < W * C; i += 256) {
+        const int x = i / C, c = i - x * C;
+        float e, d;
+        if (c < F) {
+            e = ey[x];
+            d = dim_t_y[c];
+        } else {
+            e = ex[x];
+            if (normalize) e = __fmul_rn(__fdiv_rn(e, __fadd_rn(xl, eps)), scale);
+            d = dim_t_x[c - F];
+        }
+        const float a = __fdiv_rn(e, d);
+        o[i] = (c & 1) ? cosf(a) : sinf(a);
+    }
+}
+
 }  // namespace
 
 extern "C" int zira_box_refine_fwd_f32(const float *h, const float *w, const float *b, const float *ref, long long rows, int K,
@@ -350,5 +400,14 @@ extern "C" int zira_box_head_bwd_f32(const float *g_out, const float *out, const
     if (n == 0) return 0;
     hipLaunchKernelGGL(box_head_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_out, out, ref, n,
                        eps, g_delta, g_ref);
+    return (int)hipGetLastError();
+}
+
+extern "C" int zira_sine_pos_hw_f32(const void *mask, int B, int H, int W, int F, int normalize, float scale, float eps,
+                                    const float *dim_t_y, const float *dim_t_x, float *out, void *stream)
+{
+    if (!mask || !dim_t_y || !dim_t_x || !out || B <= 0 || H <= 0 || W <= 0 || F <= 0 || (F & 1) || W > 8192) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sine_pos_hw_kernel, dim3((unsigned)(B * H)), dim3(256), 2 * (size_t)W * sizeof(float), (hipStream_t)stream,
+                       reinterpret_cast<const unsigned char *>(mask), H, W, F, normalize, scale, eps, dim_t_y, dim_t_x, out);
     return (int)hipGetLastError();
 }
