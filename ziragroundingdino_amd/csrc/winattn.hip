@@ -350,9 +350,14 @@ int launch_window_attn(const T *qkv, const float *qkv_bias, const float *bias_t,
     const int nwx = (W + window - 1) / window, nwy = (H + window - 1) / window;
     const long long nitems = (long long)B * nwx * nwy * heads;
     if (nitems >= (1ll << 31) || (long long)B * H * W * 3 * heads * kHD >= (1ll << 40)) return ZIRA_MSDA_EINVAL;
-    if (window != 12) return ZIRA_MSDA_EINVAL;
-    hipLaunchKernelGGL((window_attn_mfma<12, T>), dim3((unsigned)nitems), dim3(64 * 5), 0, st, qkv, qkv_bias, bias_t, B, H, W, heads,
-                       shift, scale, out);
+    if (window == 7)          // 49-token windows on the matrix cores: two waves of 32 queries per (image, window, head)
+        hipLaunchKernelGGL((window_attn_mfma<7, T>), dim3((unsigned)nitems), dim3(64 * 2), 0, st, qkv, qkv_bias, bias_t, B, H, W, heads,
+                           shift, scale, out);
+    else if (window == 12)
+        hipLaunchKernelGGL((window_attn_mfma<12, T>), dim3((unsigned)nitems), dim3(64 * 5), 0, st, qkv, qkv_bias, bias_t, B, H, W, heads,
+                           shift, scale, out);
+    else
+        return ZIRA_MSDA_EINVAL;
     return (int)hipGetLastError();
 }
 
@@ -367,7 +372,10 @@ int zira_window_attn_f32(const float *qkv, const float *qkv_bias, const float *b
         shift >= window)
         return ZIRA_MSDA_EINVAL;
     if (!qkv || !qkv_bias || !bias_t || !out) return ZIRA_MSDA_EINVAL;
-    if (window == 12)   // 144-token windows: the MFMA kernel
+#ifndef ZIRA_WINATTN_MFMA7
+#define ZIRA_WINATTN_MFMA7 1   // 7 x 7 windows on the matrix-core kernel as well (0: the one-wave-per-window vector kernel)
+#endif
+    if (window == 12 || (window == 7 && ZIRA_WINATTN_MFMA7))   // the MFMA kernel
         return launch_window_attn<float>(qkv, qkv_bias, bias_t, B, H, W, heads, window, shift, scale, out, (hipStream_t)stream);
     const int N = window * window;
     const int nwx = (W + window - 1) / window, nwy = (H + window - 1) / window;
