@@ -20,7 +20,7 @@ rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(out + "/bench_kernel_stats.txt", "w") as fh:
     fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-gemm-arith-mode\n")
-    fh.write("total kernel time %.1f ms over %d kernel names (3 warm-up + 10 timed steps replayed from hipGraphs, the capture of\n"
+    fh.write("total kernel time %.1f ms over %d kernel names (3 warm-up steps, 3 timed regions of 10 steps in the configured launch mode and as many in the other one, the capture of\n"
              "the graphs -- 3 warm-up passes and one capture pass per piece -- and 1 + 4 eager steps for the MSDA event timing)\n" % (tot / 1e6, len(rows)))
     fh.write("%7s %11s %8s %12s  %s\n" % ("share", "total_ms", "calls", "avg_us", "kernel"))
     for r in rows[:60]:
