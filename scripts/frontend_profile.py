@@ -18,6 +18,9 @@ model = build_model(zira_swint_config(device="cuda")).to(dev).train()
 model.use_frontend_graphs = False
 data = synthetic_batch(2, 800, 1333, device=dev)
 which = os.environ.get("PART", "both")
+if os.environ.get("GEMM_ARITH"):      # f32 | bf16x3
+    from ziragroundingdino_amd import transformer as _zt
+    _zt.Switches.gemm_arith = os.environ["GEMM_ARITH"]
 from ziragroundingdino_amd.utils import nested_tensor_from_tensor_list  # noqa: E402
 with torch.no_grad():
     samples = nested_tensor_from_tensor_list(model.preprocess_image(data))

@@ -122,3 +122,40 @@ def test_argument_errors_are_returned():
     a = torch.randn(8, 64, device="cuda")
     with pytest.raises(RuntimeError):                            # epilogue without its operand
         g3.gemm(a, torch.zeros(3, 128, 64, device="cuda", dtype=torch.int16), g3.EPI_MASK)
+
+
+def test_swin_linears_take_the_split_products_in_that_mode_and_follow_their_weights():
+    """backbone._frozen_linear: under ``Switches.gemm_arith = "bf16x3"`` the frozen Swin linears with >= 8192 rows and fitting
+    shapes go through the split-bf16 GEMM -- closer to fp64 than the library's fp32 GEMM --, smaller or unfitting ones stay on the
+    library, and the cached planes follow an in-place weight change (Joiner.refresh_derived, as before a graph replay)."""
+    from ziragroundingdino_amd import backbone, transformer as zt
+    torch.manual_seed(0)
+    mlp = backbone.Mlp(384, 1536).cuda()
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 4200, 384, device="cuda")
+    ref64 = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(
+        x.double(), mlp.fc1.weight.double(), mlp.fc1.bias.double())).float().double(), mlp.fc2.weight.double(), mlp.fc2.bias.double())
+    old = zt.Switches.gemm_arith
+    try:
+        with torch.no_grad():
+            zt.Switches.gemm_arith = "f32"
+            lib = mlp(x)
+            assert "_bf16x3_split" not in mlp.__dict__
+            zt.Switches.gemm_arith = "bf16x3"
+            got = mlp(x)
+            assert set(n for n, _ in mlp.__dict__["_bf16x3_split"]) == {"fc1", "fc2"}
+            small = mlp(x[:, :1000])                                   # 2000 rows: the library
+            assert torch.equal(small, torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(
+                x[:, :1000], mlp.fc1.weight, mlp.fc1.bias)), mlp.fc2.weight, mlp.fc2.bias))
+            e_got, e_lib = (got.double() - ref64).abs().max().item(), (lib.double() - ref64).abs().max().item()
+            assert e_got <= 1.5 * e_lib + 1e-7, (e_got, e_lib)
+            # an in-place weight change is followed by the planes
+            mlp.fc1.weight.mul_(0.5)
+            j = backbone.Joiner(torch.nn.Sequential(mlp), torch.nn.Identity())
+            j.refresh_derived()
+            again = mlp(x)
+            zt.Switches.gemm_arith = "f32"
+            assert (again - mlp(x)).abs().max().item() <= 1e-4 * again.abs().max().item()
+    finally:
+        zt.Switches.gemm_arith = old

@@ -69,6 +69,10 @@ class GraphedNoGrad:
             entry = self._capture(args, tensors)
             self._cache[key] = entry
         static_in, graph, static_out = entry
+        for m in self.modules:      # derived weights (the bf16 planes of the split-bf16 arithmetic) follow their parameters IN PLACE
+            refresh = getattr(m, "refresh_derived", None)
+            if refresh is not None:
+                refresh()
         for s, t in zip(static_in, tensors):
             s.copy_(t, non_blocking=True)
         graph.replay()
