@@ -440,7 +440,7 @@ def pmc_traffic():
 
 PROFILE_GROUPS = {   # kernels of a timed group as they are named in profiles/*_bench_kernel_stats.txt
     "fwd_dec": ("zira::msda_fwd_plan",),
-    "bwd_dec": ("zira::msda_bwd_tile_accum<256u>", "zira::msda_bwd_fold"),
+    "bwd_dec": ("zira::msda_bwd_tile_accum<256u>", "zira::msda_bwd_fold"),   # (the fold launch: rounds 3-4 only)
     "fwd_enc": ("msda_fwd_lean<2>",),
     "bwd_enc": ("msda_bwd_bin", "msda_bwd_accum<32, 512>", "msda_bwd_fold<32>", "msda_bwd_walk<32, 4>"),
 }
@@ -734,7 +734,7 @@ def main():
                 us = sum(prof_avg.get(n, 0.0) for n in names)
                 kernels[key]["avg_us_profiles"] = us
                 kernels[key]["frac_profiles"] = kernels[key]["algorithmic_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-                kernels[key]["profiles_source"] = prof_file + ": " + " + ".join(names)
+                kernels[key]["profiles_source"] = prof_file + ": " + " + ".join(n for n in names if n in prof_avg)
         dominant = max(kernels, key=lambda k: kernels[k]["share_of_step"]) if kernels else None
         roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                     "kernels": kernels, "dominant": dominant, "timing_source": timing_source}
