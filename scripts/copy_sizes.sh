@@ -2,7 +2,7 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/cs
-rocprofv3 --kernel-trace --output-format csv -d /tmp/cs -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-second-mode > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/cs -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-second-mode --no-gemm-arith-mode --regions 1 > /dev/null 2>&1
 python3 - > $root/gpurun_out/copy_sizes.txt <<'PY'
 import csv, glob, collections, re
 rows = []
