@@ -35,7 +35,8 @@ def _case(S, B, Q, C, sizes, seed, exact_pairs=False):
 
 
 @pytest.mark.parametrize("shape", [(7, 2, 900, 256, (6, 4), False), (7, 2, 40, 32, (5, 3), False), (3, 3, 70, 64, (9, 0, 2), False),
-                                   (7, 2, 40, 32, (5, 3), True), (2, 1, 5, 8, (9,), False)])
+                                   (7, 2, 40, 32, (5, 3), True), (2, 1, 5, 8, (9,), False),
+                                   (3, 2, 300, 16, (90, 75), False)])     # 165 pairs per set: more than one wave of candidates per row
 def test_native_losses_match_the_op_chain(shape):
     S, B, Q, C, sizes, exact = shape
     logits, boxes, targets = _case(S, B, Q, C, sizes, seed=S * 100 + Q, exact_pairs=exact)
