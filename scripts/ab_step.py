@@ -39,6 +39,12 @@ for kv in sys.argv[1:]:
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
     elif k == "gemm_arith":
         zt.Switches.gemm_arith = v
+    elif k == "prefetch_after_encoder":
+        ZiraTrainer.prefetch_after_encoder = bool(int(v))
+        import faulthandler
+        faulthandler.dump_traceback_later(90, exit=True)     # (a hung GPU must not hold the box)
+    elif k == "frontend_graphs":
+        _fg = bool(int(v))
     elif k == "native_pos":
         from ziragroundingdino_amd.backbone import PositionEmbeddingSineHW
         PositionEmbeddingSineHW.native = bool(int(v))
@@ -68,6 +74,8 @@ for kv in sys.argv[1:]:
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()
+if "_fg" in globals():
+    model.use_frontend_graphs = _fg
 trainer = ZiraTrainer(model)
 if os.environ.get("ZIRA_AB_FREE_FRONTEND") == "1":    # what the concurrent front end costs the step: one minibatch, its front end computed once
     n_distinct = 1

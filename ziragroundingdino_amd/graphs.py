@@ -301,6 +301,8 @@ class GraphedTransformer:
                 entry["layers"].append(self._capture(piece, args, shared, key) if self.graph_encoder else piece)
             output, memory_text = entry["layers"][i](*args)
         text_dict["encoded_text"] = memory_text
+        if entry["decode"] is not None:      # (not while pieces are still being captured: the hook's owner falls back)
+            t.fire_after_encoder()
 
         if not self.graph_selection:   # selection eager, decoder layers graphed
             refpoint_embed, tgt, init_box, hs_enc, ref_enc = t.select_queries(output, mask_flat, shapes, text_dict)

@@ -110,6 +110,8 @@ class ZiraTrainer:
                 raise RuntimeError("[ZiraTrainer] .grad of %s left the flat gradient bucket "
                                    "(zero_grad(set_to_none=True)?); call trainer._bind()" % n)
 
+    prefetch_after_encoder = True   # class-level switch for A/B runs (False: behind the whole forward, as until round 5)
+
     def run_step(self, data, next_data=None) -> Dict[str, torch.Tensor]:
         """One optimisation step on one minibatch; returns the (detached) weighted loss dict.
         ``next_data``: the minibatch of the NEXT step, if the caller has it already (a data loader with prefetch
@@ -122,6 +124,15 @@ class ZiraTrainer:
         self._prefetched = None
         if pre is not None and pre["inputs"] is data:
             kw["frontend"] = pre
+        can_prefetch = (next_data is not None and self.amp_dtype is None and hasattr(self.model, "can_prefetch_frontend")
+                        and self.model.can_prefetch_frontend())
+        tr = getattr(self.model, "transformer", None)
+        if can_prefetch and self.prefetch_after_encoder and hasattr(tr, "fire_after_encoder"):
+            # the next minibatch's front end is queued when this step's ENCODER forward has been launched (round 5: 34.1 ->
+            # 32.4 ms per step against queuing it behind the whole forward; queuing it at the start of the step hangs the GPU)
+            def _queue(self=self, next_data=next_data):
+                self._prefetched = self.model.prefetch_frontend(next_data)
+            tr.__dict__["after_encoder"] = _queue
         if self.amp_dtype is not None:
             # (graph capture under autocast needs the weight-cast cache off: torch.cuda.make_graphed_callables)
             graphs = bool(getattr(self.model, "use_transformer_graph", False))
@@ -129,8 +140,9 @@ class ZiraTrainer:
                 loss_dict = self.model(data, **kw)
         else:
             loss_dict = self.model(data, **kw)
-        if (next_data is not None and self.amp_dtype is None and hasattr(self.model, "can_prefetch_frontend")
-                and self.model.can_prefetch_frontend()):
+        if tr is not None:
+            tr.__dict__["after_encoder"] = None          # (not fired: pieces still being captured, or a forward that skipped it)
+        if can_prefetch and self._prefetched is None:
             self._prefetched = self.model.prefetch_frontend(next_data)
         losses = getattr(loss_dict, "total", None)   # the model's own sum of the same terms (criterion.LossDict)
         if losses is None:

@@ -1287,6 +1287,14 @@ class Transformer(nn.Module):
                                           attn_mask, no_padding)
         return hs, references, hs_enc, ref_enc, init_box_proposal
 
+    def fire_after_encoder(self):
+        """Call (once) what ``after_encoder`` holds: a trainer puts the next minibatch's frozen front end there, so that it is
+        queued when the encoder's forward has been launched and runs beside the launch-bound part of the step -- query
+        selection, decoder, criterion, decoder backward -- instead of beside the backward's large GEMMs."""
+        hook, self.__dict__["after_encoder"] = self.__dict__.get("after_encoder"), None
+        if hook is not None:
+            hook()
+
     def forward(self, srcs, masks, refpoint_embed, pos_embeds, tgt, attn_mask=None, text_dict=None,
                 no_padding=False):
         """``no_padding``: the caller knows (on the host, from the image sizes) that ``masks`` are
@@ -1303,6 +1311,7 @@ class Transformer(nn.Module):
             text_self_attention_masks=text_dict["text_self_attention_masks"],
             spatial_shapes_list=shapes)
         text_dict["encoded_text"] = memory_text
+        self.fire_after_encoder()
         hs, references, hs_enc, ref_enc, init_box_proposal = self.select_and_decode(
             memory, mask_flatten, lvl_pos_embed_flatten, shapes, spatial_shapes, level_start_index,
             valid_ratios, text_dict, refpoint_embed, tgt, attn_mask, no_padding=no_padding)
