@@ -103,7 +103,8 @@
 #define ZIRA_ACC_MINW 4    // accumulate: waves per SIMD the register allocation must allow
 #endif
 #ifndef ZIRA_ACC_SKIP_TRASH
-#define ZIRA_ACC_SKIP_TRASH 0   // accumulate: 1 = the lanes of a corner that belongs to a neighbouring tile sit the adds out (exec mask)
+#define ZIRA_ACC_SKIP_TRASH 0   // accumulate: 1 = the lanes of a corner that belongs to a neighbouring tile sit the adds out (exec mask):
+                                // measured in round 5, SLOWER (386 -> 393 us: a masked ds_add_u64 costs what a full one does)
 #endif
 #ifndef ZIRA_ACC_DR
 #define ZIRA_ACC_DR 3      // accumulate: grad_out rows requested this many records ahead (DR + 1 divides 8)
