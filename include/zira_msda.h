@@ -415,6 +415,28 @@ int zira_split_bf16x3_f32(const float *w, int rows, int cols, int transpose, voi
 int zira_gemm_bf16x3_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
                          const float *aux, float *C, void *stream);
 
+/* ---- The frozen feed-forward block as ONE launch per direction, on the f16 matrix cores in fp32 accuracy ----
+ * forward   y  = relu(x W1^T + b1) W2^T + b2        (reference FFN: transformer_for_adapter.py:877-886)
+ * backward  gx = aux + ((gy W2) * [h > 0]) W1       (its autograd under the freeze of
+ *                                                    groundingdino_dual_zero_rep_branch.py:722-745: no weight gradients)
+ * Both are out = epi(phi(A P^T) Q^T), A [M, 256] fp32 row-major, P [F, 256], Q [256, F] (csrc/ffn_f16x2.hip): each fp32
+ * operand, scaled by a power of two, is split into two f16 planes, three exact product terms per pair; sums in fp32.  The
+ * hidden activation [M, F] never exists in memory: the forward writes its sign bits (F / 8 bytes per row), the backward reads
+ * them.  d_model is 256; F % 256 == 0; pointers 16-byte aligned.
+ *   zira_ffn_f16x2_pack_bytes(F): size of one packed direction (0: unsupported F).
+ *   zira_ffn_f16x2_pack_f32: P(h, k) = p[h * p_row_stride + k * p_col_stride], Q(n, h) = q[n * q_row_stride + h * q_col_stride]
+ *     (strides in floats), p_bias [F] or NULL -> packed.  Forward: p = W1 (F x 256 row-major: strides 256, 1), q = W2
+ *     (256 x F: strides F, 1), p_bias = b1.  Backward: p = W2 read transposed (strides 1, F), q = W1 read transposed
+ *     (strides 1, 256), p_bias NULL.  Once per weight version.
+ *   zira_ffn_f16x2_f32: backward = 0: out = relu(A P^T + p_bias) Q^T (+ q_bias[256]) (+ aux[M, 256]), mask [M, F / 32] words
+ *     WRITTEN; backward = 1: out = ((A P^T) * mask bits) Q^T (+ q_bias) (+ aux), mask READ.  aux may be out.
+ * Return 0, a hipError_t, or -1 for unsupported arguments.  Device pointers; enqueue only. */
+size_t zira_ffn_f16x2_pack_bytes(int F);
+int zira_ffn_f16x2_pack_f32(const float *p, long long p_row_stride, long long p_col_stride, const float *q, long long q_row_stride,
+                            long long q_col_stride, const float *p_bias, int F, void *packed, void *stream);
+int zira_ffn_f16x2_f32(const float *A, const void *packed, int M, int F, int backward, const float *q_bias, const float *aux,
+                       void *mask, float *out, void *stream);
+
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):
  *   pos [rows, C] (x, y[, w, h]), C = 2 or 4;  dim_t [T] = temperature^(2 (i // 2) / T);  scale = 2 pi;
