@@ -80,9 +80,10 @@ def gemm(a: torch.Tensor, planes: torch.Tensor, epilogue: int, bias: torch.Tenso
 # ---- cached split weights of modules -----------------------------------------------------------------------------------------
 
 def enabled() -> bool:
-    """Whether the callers should take the split-bf16 products (``transformer.Switches.gemm_arith`` = "bf16x3")."""
+    """Whether the callers should take the split-bf16 products (``transformer.Switches.gemm_arith`` = "bf16x3", or "f16x2":
+    the fused f16x2 FFN launches with these products everywhere else)."""
     from .transformer import Switches
-    return Switches.gemm_arith == "bf16x3"
+    return Switches.gemm_arith in ("bf16x3", "f16x2")
 
 
 def _cache(owner, name, transpose):

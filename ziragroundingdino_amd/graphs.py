@@ -53,7 +53,8 @@ class GraphedNoGrad:
     def _mode_key(self):
         training = tuple(bool(m.training) for m in self.modules)
         autocast = (torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else None)
-        return training, autocast
+        from .transformer import Switches
+        return training, autocast, Switches.gemm_arith   # (a capture bakes the arithmetic of the frozen products in)
 
     def __call__(self, *args):
         tensors = _flatten(args, [])
@@ -256,9 +257,11 @@ class GraphedTransformer:
 
     def __call__(self, srcs, masks, poss, text_dict, no_padding=False):
         t = self.transformer
+        from .transformer import Switches
         key = (tuple((tuple(x.shape), x.requires_grad) for x in srcs),
                tuple(text_dict["encoded_text"].shape), text_dict["encoded_text"].requires_grad, bool(no_padding),
-               torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))   # a capture bakes the dtype path in
+               torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"),   # a capture bakes the dtype path in
+               Switches.gemm_arith)                                                    # and the arithmetic of the frozen products
         self._refresh_derived_weights()
         if key in self._eager_keys or (key not in self._cache and len(self._cache) >= self.max_signatures):
             hs, refs, hs_enc, ref_enc, init_box, _ = t(srcs, masks, None, poss, None, None, text_dict,

@@ -171,7 +171,9 @@ class Switches:
     fused_ffn_backward = True  # frozen FFNs: (gy @ W2) * (h > 0) in one native GEMM (csrc/gemm_drelu.hip) instead of mm + threshold_backward
     sort_for_topk = False    # select_queries: stable sort instead of torch.topk everywhere (developer switch)
     # arithmetic of the frozen FFN products on the image-token rows: "f32" = the library's fp32 GEMMs (+ csrc/gemm_drelu.hip);
-    # "bf16x3" = fp32-accurate split-bf16 products on the bf16 matrix cores (csrc/gemm_bf16x3.hip, gemm_bf16x3.py)
+    # "bf16x3" = fp32-accurate split-bf16 products on the bf16 matrix cores (csrc/gemm_bf16x3.hip, gemm_bf16x3.py);
+    # "f16x2" = the frozen FFN as ONE launch per direction on the f16 matrix cores in fp32 accuracy (csrc/ffn_f16x2.hip,
+    # ffn_f16x2.py: the [rows, d_ffn] activation stays on chip), and "bf16x3" for the other frozen products
     gemm_arith = "f32"
 
 
@@ -216,12 +218,32 @@ class _FFNSplit:
             sw.planes(w)
 
 
+class _FFNFused:
+    """The packed weights of a frozen FFN for the fused f16x2 launches (ffn_f16x2.PackedFFN: both directions, refreshed in place)."""
+    fused = True
+
+    def __init__(self):
+        from .ffn_f16x2 import PackedFFN
+        self.packed = PackedFFN()
+
+    def refresh(self, lin1, lin2):
+        self.packed.refresh(lin1, lin2)
+
+
 def _ffn_split(layer, x2):
-    """The layer's split weights when ``Switches.gemm_arith`` asks for the bf16x3 products and the shapes allow them, else None."""
-    if Switches.gemm_arith != "bf16x3":
+    """The layer's packed / split weights when ``Switches.gemm_arith`` asks for them and the shapes allow them, else None:
+    "f16x2" -> _FFNFused where d_model = 256 and d_ffn % 256 == 0 (else as "bf16x3"), "bf16x3" -> _FFNSplit."""
+    if Switches.gemm_arith not in ("bf16x3", "f16x2"):
         return None
     from . import gemm_bf16x3 as g3
     lin1, lin2 = layer.linear1, layer.linear2
+    if Switches.gemm_arith == "f16x2" and x2.shape[0] >= 1024 and lin1.bias is not None and lin2.bias is not None:
+        from . import ffn_f16x2 as ff
+        if ff.supported(x2, lin1.out_features) and lin2.out_features == ff.D_MODEL and lin2.in_features == lin1.out_features:
+            sp = getattr(layer, "_ffn_fused_weights", None)
+            if sp is None:
+                sp = layer._ffn_fused_weights = _FFNFused()
+            return sp
     if not (g3.supported(x2, lin1.out_features, lin1.in_features) and lin2.out_features % 128 == 0 and lin2.in_features % 32 == 0
             and x2.shape[0] >= 1024):
         return None
@@ -240,6 +262,13 @@ class _FrozenFFN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, split=None):
         ctx.split = split
+        if getattr(split, "fused", False):   # one launch; the activation's sign bits are what the backward needs
+            from . import ffn_f16x2 as ff
+            F_ = w1.shape[0]
+            bits = ff.mask_like(x, F_)
+            y = ff.run(x, split.packed.get(w1, b1, w2, False), F_, False, bits, q_bias=b2)
+            ctx.save_for_backward(w1, w2, bits, b1)
+            return y
         if split is not None:
             from . import gemm_bf16x3 as g3
             h = g3.gemm(x, split.w1.planes(w1), g3.EPI_BIAS_RELU, bias=b1)
@@ -252,8 +281,13 @@ class _FrozenFFN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         from . import _lib
-        w1, w2, h = ctx.saved_tensors
         gy = gy.contiguous()
+        if getattr(ctx.split, "fused", False):
+            from . import ffn_f16x2 as ff
+            w1, w2, bits, b1 = ctx.saved_tensors
+            gx = ff.run(gy, ctx.split.packed.get(w1, b1, w2, True), w1.shape[0], True, bits)
+            return gx, None, None, None, None, None
+        w1, w2, h = ctx.saved_tensors
         if ctx.split is not None:
             from . import gemm_bf16x3 as g3
             g = g3.gemm(gy, ctx.split.w2t.planes(w2), g3.EPI_MASK, aux=h)
@@ -278,7 +312,11 @@ class _FrozenFFNNorm(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, ln_w, ln_b, eps, split=None):
         from . import _lib
         ctx.split = split
-        if split is not None:
+        if getattr(split, "fused", False):
+            from . import ffn_f16x2 as ff
+            h = ff.mask_like(x, w1.shape[0])     # (the sign bits stand for the activation)
+            y = ff.run(x, split.packed.get(w1, b1, w2, False), w1.shape[0], False, h, q_bias=b2)
+        elif split is not None:
             from . import gemm_bf16x3 as g3
             h = g3.gemm(x, split.w1.planes(w1), g3.EPI_BIAS_RELU, bias=b1)
             y = g3.gemm(h, split.w2.planes(w2), g3.EPI_BIAS, bias=b2)
@@ -294,17 +332,19 @@ class _FrozenFFNNorm(torch.autograd.Function):
                                                         stats[1].data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
         if rc != 0:
             raise RuntimeError("zira_add_layernorm_fwd_f32 failed with code %d" % rc)
-        ctx.save_for_backward(w1, w2, h, s, ln_w, stats)
+        ctx.save_for_backward(w1, w2, h, s, ln_w, stats, b1)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         from . import _lib
-        w1, w2, h, s, ln_w, stats = ctx.saved_tensors
+        w1, w2, h, s, ln_w, stats, b1 = ctx.saved_tensors
         lib = _lib.load()
         gout = gout.contiguous()
         rows, C = s.shape
-        gs, g = torch.empty_like(s), torch.empty_like(h)
+        fused = getattr(ctx.split, "fused", False)
+        gs = torch.empty_like(s)
+        g = None if fused else torch.empty_like(h)
         with torch.cuda.device(s.device):
             st = torch.cuda.current_stream(s.device).cuda_stream
             rc = lib.zira_layernorm_bwd_f32(gout.data_ptr(), s.data_ptr(), ln_w.data_ptr(), stats[0].data_ptr(),
@@ -313,6 +353,9 @@ class _FrozenFFNNorm(torch.autograd.Function):
                 rc = lib.zira_gemm_drelu_f32(gs.data_ptr(), w2.data_ptr(), h.data_ptr(), rows, h.shape[1], C, g.data_ptr(), st)
         if rc != 0:
             raise RuntimeError("frozen FFN + LayerNorm backward failed with code %d" % rc)
+        if fused:   # gs += ((gs W2) * [h > 0]) W1 in one launch, in place
+            from . import ffn_f16x2 as ff
+            return (ff.run(gs, ctx.split.packed.get(w1, b1, w2, True), w1.shape[0], True, h, aux=gs, out=gs),) + (None,) * 8
         if ctx.split is not None:   # the same two products on the bf16 matrix cores: ReLU mask and the residual sum in their epilogues
             from . import gemm_bf16x3 as g3
             g3.gemm(gs, ctx.split.w2t.planes(w2), g3.EPI_MASK, aux=h, out=g)
@@ -728,9 +771,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def refresh_fused_projection(self, *unused):
         """The bf16 planes of the FFN weights (``Switches.gemm_arith`` = "bf16x3") follow the parameters in place."""
-        sp = getattr(self, "_ffn_split_weights", None)
-        if sp is not None:
-            sp.refresh(self.linear1, self.linear2)
+        for sp in (getattr(self, "_ffn_split_weights", None), getattr(self, "_ffn_fused_weights", None)):
+            if sp is not None:
+                sp.refresh(self.linear1, self.linear2)
 
     fuse_bias_relu = True   # bias + ReLU in the GEMM epilogue: -117 us per layer (scripts/enclayer_profile.py)
     native_attention = True   # frozen fp32 GPU calls without padding: the attention sublayer as one autograd node (encoder_layer.py)
