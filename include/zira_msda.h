@@ -430,12 +430,17 @@ int zira_gemm_bf16x3_f32(const float *A, const void *b_planes, int M, int N, int
  *     (strides 1, 256), p_bias NULL.  Once per weight version.
  *   zira_ffn_f16x2_f32: backward = 0: out = relu(A P^T + p_bias) Q^T (+ q_bias[256]) (+ aux[M, 256]), mask [M, F / 32] words
  *     WRITTEN; backward = 1: out = ((A P^T) * mask bits) Q^T (+ q_bias) (+ aux), mask READ.  aux may be out.
+ *     workspace: zira_ffn_f16x2_workspace_bytes(M, F) bytes, ZEROED ONCE by the caller (the launch leaves it zeroed where it
+ *     must be), not shared by launches that may run at the same time; or NULL.  With it the row blocks of the chip's last,
+ *     partly filled round are cut into shares of the hidden units whose sums meet there and are added in a fixed order by the
+ *     block that arrives last (results repeat bit for bit from launch to launch); without it every block takes 128 whole rows.
  * Return 0, a hipError_t, or -1 for unsupported arguments.  Device pointers; enqueue only. */
 size_t zira_ffn_f16x2_pack_bytes(int F);
+size_t zira_ffn_f16x2_workspace_bytes(int M, int F);
 int zira_ffn_f16x2_pack_f32(const float *p, long long p_row_stride, long long p_col_stride, const float *q, long long q_row_stride,
                             long long q_col_stride, const float *p_bias, int F, void *packed, void *stream);
 int zira_ffn_f16x2_f32(const float *A, const void *packed, int M, int F, int backward, const float *q_bias, const float *aux,
-                       void *mask, float *out, void *stream);
+                       void *mask, float *out, void *workspace, void *stream);
 
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):

@@ -40,6 +40,13 @@ flop = 2 * 2.0 * M * 256 * F
 t_f = timed(lambda: ff.run(x, pf, F, False, mask, q_bias=b2, out=out))
 t_b = timed(lambda: ff.run(gy, pb, F, True, mask, aux=gs, out=gs))
 print("f16x2 fused   forward %7.1f us (%5.1f TF/s fp32-equivalent)   backward %7.1f us (%5.1f TF/s)" % (t_f, flop / t_f * 1e-6, t_b, flop / t_b * 1e-6))
+t_f = timed(lambda: ff.run(x, pf, F, False, mask, q_bias=b2, out=out, use_workspace=False))
+t_b = timed(lambda: ff.run(gy, pb, F, True, mask, aux=gs, out=gs, use_workspace=False))
+print("  whole blocks forward %7.1f us (%5.1f TF/s fp32-equivalent)   backward %7.1f us (%5.1f TF/s)" % (t_f, flop / t_f * 1e-6, t_b, flop / t_b * 1e-6))
+for mm in (32768, 65536):
+    xx, oo, mk = torch.randn(mm, 256, device="cuda"), torch.empty(mm, 256, device="cuda"), torch.empty(mm, F // 32, device="cuda", dtype=torch.int32)
+    t = timed(lambda: ff.run(xx, pf, F, False, mk, q_bias=b2, out=oo))
+    print("  M = %d (whole rounds) forward %7.1f us (%5.1f TF/s)" % (mm, t, 4.0 * mm * 256 * F / t * 1e-6))
 
 h = torch.empty(M, F, device="cuda")
 

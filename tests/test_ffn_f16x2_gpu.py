@@ -15,9 +15,11 @@ def _ints(shape, lo, hi, g):
     return torch.randint(lo, hi + 1, shape, device="cuda", generator=g).float()
 
 
-@pytest.mark.parametrize("M", [1, 100, 128, 391])
-def test_exact_on_small_integers(M):
-    """Small integers: every product and sum is exact in f16 x f16 -> fp32, so the result must EQUAL the fp32 evaluation."""
+@pytest.mark.parametrize("M,ws", [(1, True), (100, False), (128, True), (391, True), (391, False), (128 * 300, True)])
+def test_exact_on_small_integers(M, ws):
+    """Small integers: every product and sum is exact in f16 x f16 -> fp32, so the result must EQUAL the fp32 evaluation --
+    with whole 128-row blocks (``ws`` False) and with the last round's row blocks cut into shares of the hidden units whose
+    sums meet in the workspace (1, 3 and 4 row blocks: four shares each; 300: 44 row blocks behind a full round, four shares)."""
     g = torch.Generator(device="cuda").manual_seed(1)
     F = 512
     x = _ints((M, 256), -2, 2, g)
@@ -30,18 +32,22 @@ def test_exact_on_small_integers(M):
     want = h @ w2.t() + b2
     pk = ff.PackedFFN()
     mask = ff.mask_like(x, F)
-    got = ff.run(x, pk.get(w1, b1, w2, False), F, False, mask, q_bias=b2)
+    got = ff.run(x, pk.get(w1, b1, w2, False), F, False, mask, q_bias=b2, use_workspace=ws)
     assert torch.equal(got, want)
     # backward: gx = aux + ((gy W2) * [h > 0]) W1
     gy = _ints((M, 256), -2, 2, g)
     aux = _ints((M, 256), -5, 5, g)
     want_g = aux + ((gy @ w2) * (h > 0)) @ w1
-    got_g = ff.run(gy, pk.get(w1, b1, w2, True), F, True, mask, aux=aux)
+    got_g = ff.run(gy, pk.get(w1, b1, w2, True), F, True, mask, aux=aux, use_workspace=ws)
     assert torch.equal(got_g, want_g)
     # in place on aux
     acc = aux.clone()
-    ff.run(gy, pk.get(w1, b1, w2, True), F, True, mask, aux=acc, out=acc)
+    ff.run(gy, pk.get(w1, b1, w2, True), F, True, mask, aux=acc, out=acc, use_workspace=ws)
     assert torch.equal(acc, want_g)
+    if ws:   # the tickets are left zeroed
+        n_tail = ((M + 127) // 128) % 256          # (row blocks of the last round on a 256-CU chip)
+        tickets = ff.workspace(x.device, torch.cuda.current_stream().cuda_stream, M, F)[:4 * n_tail].view(torch.int32)
+        assert int(tickets.abs().sum()) == 0
 
 
 def _decode_bits(mask, M, F):
@@ -104,6 +110,27 @@ def test_accuracy_gate_against_fp64_beside_the_library_fp32_gemms():
     print(stats)
     assert float(eo.max()) <= float(el.max()), stats
     assert float(eo.pow(2).mean().sqrt()) <= float(el.pow(2).mean().sqrt()), stats
+
+
+def test_shares_of_the_last_round_repeat_bit_for_bit():
+    """M = 44446: 256 whole row blocks and 92 cut in two; the shares' sums are added in share order by whichever block arrives
+    last, so two launches agree bit for bit, and with the whole-block deal to fp32 rounding."""
+    M, F = 44446, 2048
+    x, w1, b1, w2, b2 = _model_like(M, F, 8)
+    pk = ff.PackedFFN()
+    mask = ff.mask_like(x, F)
+    a = ff.run(x, pk.get(w1, b1, w2, False), F, False, mask, q_bias=b2).clone()
+    bits = mask.clone()
+    for _ in range(3):
+        assert torch.equal(ff.run(x, pk.get(w1, b1, w2, False), F, False, mask, q_bias=b2), a) and torch.equal(mask, bits)
+    whole = ff.run(x, pk.get(w1, b1, w2, False), F, False, mask, q_bias=b2, use_workspace=False)
+    assert torch.equal(mask, bits)
+    assert float((whole - a).abs().max()) <= 2e-6 * float(a.abs().max())
+    assert torch.equal(whole[:256 * 128], a[:256 * 128])          # the whole blocks are the same blocks
+    gy = torch.randn(M, 256, device="cuda")
+    g = ff.run(gy, pk.get(w1, b1, w2, True), F, True, mask, aux=gy).clone()
+    for _ in range(3):
+        assert torch.equal(ff.run(gy, pk.get(w1, b1, w2, True), F, True, mask, aux=gy), g)
 
 
 def test_sign_bits_match_the_activation():

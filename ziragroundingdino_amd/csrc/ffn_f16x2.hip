@@ -101,26 +101,34 @@ __device__ __forceinline__ void split2(float x, float y, unsigned &p1, unsigned 
     p2 = pk_f16(x - f16_lo(p1), y - f16_hi(p1));   // (exact differences)
 }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-// one wave copies 1 KB: lane l's 16 bytes from src + 16 l to dst + 16 l (dst wave-uniform)
-__device__ __forceinline__ void dma_1k(const unsigned char *src_lane, unsigned char *dst_uniform)
+// One wave copies 1 KB global -> LDS: lane l's 16 bytes from src + 16 l to LDS byte address dst + 16 l (src, dst wave-uniform).
+// Inline assembly on purpose: issued through the builtin, the compiler orders every later ds_read behind the copy with
+// s_waitcnt vmcnt(0) -- it cannot tell that the reads go to the OTHER stage -- and the stream would never run ahead of the
+// matrix work.  The waves that issue these wait for them by hand (s_waitcnt vmcnt(0) before the step's barrier).
+__device__ __forceinline__ void dma_1k(const unsigned char *src_uniform, unsigned lane_off, unsigned dst_lds)
 {
-    __builtin_amdgcn_global_load_lds((gbl_void *)src_lane, (lds_void *)dst_uniform, 16, 0, 0);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(dst_lds), "s"(src_uniform)
+                 : "memory");
 }
 
 __device__ __forceinline__ f16x8 frag(const unsigned char *p) { return *reinterpret_cast<const f16x8 *>(p); }
 
-// 4 NQ pieces of 1 KB from src to dst (LDS), piece q by the wave with part == q & 3
+// 4 NQ pieces of 1 KB from src to LDS byte address dst, piece q by the wave with part == q & 3
 template <int NQ>
-__device__ __forceinline__ void issue_pieces(const unsigned char *src, unsigned char *dst, int part, int lane)
+__device__ __forceinline__ void issue_pieces(const unsigned char *src, unsigned dst, int part, int lane)
 {
-    const unsigned voff = (unsigned)lane * 16u;   // (uniform base + 32-bit lane offset: the scalar-base form of the load, no 64-bit lane pointers)
+    const unsigned voff = (unsigned)lane * 16u;
     src += part * kFrag;
     dst += part * kFrag;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) dma_1k(src + q * 4 * kFrag + voff, dst + q * 4 * kFrag);
+    for (int q = 0; q < NQ; ++q) dma_1k(src + q * 4 * kFrag, voff, dst + q * 4 * kFrag);
 }
 
 template <int MODE>
@@ -128,14 +136,27 @@ __global__ __launch_bounds__(kThreads) void ffn_f16x2_kernel(const float *__rest
                                                             int nsteps, const float *__restrict__ pbias,
                                                             const float *__restrict__ qinv,
                                                             const float *__restrict__ qbias, const float *aux, unsigned *mask,
-                                                            float *out, int M)
+                                                            float *out, int M, int nfull, int nsplit, float *partial,
+                                                            unsigned *tickets)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave & 3;
     const int lm = lane & 31, hf = lane >> 5;
-    int m = blockIdx.x * kRows + pair * 32 + lm;
+    // Blocks 0 .. nfull - 1 take 128 rows and all the steps.  The row blocks behind them -- the last, partly filled round of
+    // the chip -- are cut into nsplit blocks each, every one with a share [s0, s1) of the steps; the shares' sums meet in
+    // `partial` and the block that arrives last adds them in share order (host side: launch()).
+    int rb = blockIdx.x, s0 = 0, s1 = nsteps, tail = -1, share = 0;
+    if (rb >= nfull) {
+        const int t = rb - nfull, per = nsteps / nsplit;
+        tail = t / nsplit;
+        share = t - tail * nsplit;
+        rb = nfull + tail;
+        s0 = share * per;
+        s1 = s0 + per;
+    }
+    int m = rb * kRows + pair * 32 + lm;
     const bool live = m < M;
     m = live ? m : M - 1;            // (rows past the end compute on the last row; nothing of theirs is stored)
     const unsigned char *const lbase = smem + lane * 16;
@@ -179,14 +200,14 @@ __global__ __launch_bounds__(kThreads) void ffn_f16x2_kernel(const float *__rest
         // the sign bits: [m][hf][step] 16 bits each (F / 8 bytes per row), 128 bits per lane and 8 steps
         uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
         unsigned *const mrow = mask + (size_t)m * nsteps + hf * (nsteps >> 1);
-        if (MODE == MODE_BWD) mbits = *reinterpret_cast<const uint4 *>(mrow);
+        if (MODE == MODE_BWD) mbits = *reinterpret_cast<const uint4 *>(mrow + (s0 >> 3) * 4);
         // the bias of a step (times the scale of its row of P; forward only): register 4 g + e <-> hidden unit 8 g + 4 hf + e;
         // each quarter is reloaded for the next step right behind its last use
         float4 cb[4];
         const float *const brow = pbias + 4 * hf;
         if (MODE == MODE_FWD) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) cb[g] = *reinterpret_cast<const float4 *>(brow + 8 * g);
+            for (int g = 0; g < 4; ++g) cb[g] = *reinterpret_cast<const float4 *>(brow + 32 * s0 + 8 * g);
         }
 
         // The matrix core's A operand is the weight fragment (rows = hidden units), its B operand the rows of A.  Group
@@ -259,27 +280,47 @@ __global__ __launch_bounds__(kThreads) void ffn_f16x2_kernel(const float *__rest
         mbits.z = __builtin_amdgcn_alignbit(mbits.w, mbits.z, 16);                                                                \
         mbits.w = __builtin_amdgcn_alignbit(MODE == MODE_FWD ? word : 0u, mbits.w, 16);                                           \
         if (MODE == MODE_FWD && (s_ & 7) == 7 && live) *reinterpret_cast<uint4 *>(mrow + (s_ >> 3) * 4) = mbits;                  \
-        if (MODE == MODE_BWD && (s_ & 7) == 7 && s_ + 1 < nsteps) mbits = *reinterpret_cast<const uint4 *>(mrow + ((s_ + 1) >> 3) * 4); \
+        if (MODE == MODE_BWD && (s_ & 7) == 7 && s_ + 1 < s1) mbits = *reinterpret_cast<const uint4 *>(mrow + ((s_ + 1) >> 3) * 4); \
         __syncthreads();                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);   /* (nothing of a step moves into the next) */                                        \
     } while (0)
 
-        for (int s = 0; s < nsteps; s += 2) {   // (nsteps is a multiple of 8)
+        for (int s = s0; s < s1; s += 2) {   // (s0 and s1 are multiples of 8)
             ZIRA_FFN_STEP1(s, 0, d, dn);
             ZIRA_FFN_STEP1(s + 1, 1, dn, d);
         }
-        __syncthreads();                 // step nsteps: the second waves' last
+        __syncthreads();                 // step s1: the second waves' last
 #undef ZIRA_FFN_STEP1
 #undef ZIRA_FFN_MFMA3
 #undef ZIRA_FFN_PFRAG
+        if (tail < 0) return;
+        // (a block with a share of the steps: the first waves take part in the hand-over's two barriers)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // every storing wave has drained its stores and passed the barrier: release them, then draw the ticket
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(tickets + tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(nsplit - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(tickets + tail, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *reinterpret_cast<volatile int *>(smem) = last;
+        }
+        __syncthreads();
         return;
     }
 
     // ===================== second wave of the pair: the stream, the second product, the output tile ===============================
     const int part = wave - 4;
-    issue_pieces<8>(stream, smem + kUnit, part, lane);                    // P(0) -> second stage
-    issue_pieces<16>(stream + kPBytes, smem, part, lane);                  // unit 0 -> first stage
-    f32x16 run[8];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;   // LDS byte address of the first stage
+    const unsigned char *const units = stream + kPBytes;                                    // unit s at units + s * kUnit
+    issue_pieces<8>(s0 == 0 ? stream : units + (size_t)(s0 - 1) * kUnit, lds0 + kUnit, part, lane);   // P(s0) -> second stage
+    issue_pieces<16>(units + (size_t)s0 * kUnit, lds0, part, lane);                        // unit s0 -> first stage
+    float run[8][16];   // (plain floats: as 16-wide vectors each tile needs 16 CONTIGUOUS registers and the allocator spills whole tiles)
 #pragma unroll
     for (int t8 = 0; t8 < 8; ++t8)
 #pragma unroll
@@ -287,15 +328,18 @@ __global__ __launch_bounds__(kThreads) void ffn_f16x2_kernel(const float *__rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // barrier 0
     __builtin_amdgcn_s_barrier();        // barrier 1
-    issue_pieces<16>(stream + kPBytes + kUnit, smem + kUnit, part, lane);  // step 0: unit 1 -> second stage
+    issue_pieces<16>(units + (size_t)(s0 + 1) * kUnit, lds0 + kUnit, part, lane);           // step s0: unit s0 + 1 -> second stage
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+#define ZIRA_FFN_PIN16(X)                                                                                                         \
+    asm volatile("" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]), "+v"(X[9]), \
+                      "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]))
     // step S >= 1: the hidden tile of step S - 1 (buffer (S - 1) & 1) times Q(S - 1) (stage ST = S & 1)
 #define ZIRA_FFN_STEP2(S, ST)                                                                                                     \
     do {                                                                                                                          \
         const int s_ = (S);                                                                                                       \
-        if (s_ + 1 <= nsteps) issue_pieces<16>(stream + kPBytes + (size_t)(s_ + 1) * kUnit, smem + ((ST) ^ 1) * kUnit, part, lane); \
+        if (s_ + 1 <= s1) issue_pieces<16>(units + (size_t)(s_ + 1) * kUnit, lds0 + ((ST) ^ 1) * kUnit, part, lane);               \
         float tv[16];                                                                                                             \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                           \
             const float4 x = *reinterpret_cast<const float4 *>(tbase + ((ST) ^ 1) * 4 * kTBytes + g * 1024);                      \
@@ -314,42 +358,69 @@ __global__ __launch_bounds__(kThreads) void ffn_f16x2_kernel(const float *__rest
             t2[j] = __builtin_bit_cast(f16x8, make_uint4(x2[0], x2[1], x2[2], x2[3]));                                            \
         }                                                                                                                         \
         const unsigned char *qb = lbase + (ST) * kUnit + kPBytes;                                                                 \
-        f16x8 q1[2][2], q2[2][2];   /* [tile parity][j] */                                                                        \
-        f32x16 c[2];                                                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                           \
-            q1[0][j] = frag(qb + (j * 2 + 0) * kFrag);                                                                            \
-            q2[0][j] = frag(qb + (j * 2 + 1) * kFrag);                                                                            \
+        f16x8 q1[3], q2[3];   /* half tiles u = 2 t8 + j, read two ahead */                                                    \
+        f32x16 c[2];          /* a tile's slice; the running sums of tile t8 are updated beside the first instructions of t8 + 1 */ \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                           \
+            q1[u] = frag(qb + (u * 2 + 0) * kFrag);                                                                               \
+            q2[u] = frag(qb + (u * 2 + 1) * kFrag);                                                                               \
         }                                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                        \
-        _Pragma("unroll") for (int t8 = 0; t8 < 8; ++t8) {                                                                        \
-            if (t8 + 1 < 8) {                                                                                                     \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                   \
-                    q1[(t8 + 1) & 1][j] = frag(qb + (((t8 + 1) * 2 + j) * 2 + 0) * kFrag);                                        \
-                    q2[(t8 + 1) & 1][j] = frag(qb + (((t8 + 1) * 2 + j) * 2 + 1) * kFrag);                                        \
-                }                                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                                          \
+            const int t8 = u >> 1, j = u & 1;                                                                                     \
+            if (u + 2 < 16) {                                                                                                     \
+                q1[(u + 2) % 3] = frag(qb + ((u + 2) * 2 + 0) * kFrag);                                                           \
+                q2[(u + 2) % 3] = frag(qb + ((u + 2) * 2 + 1) * kFrag);                                                           \
             }                                                                                                                     \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) c[t8 & 1][r] = 0.f;                                                    \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                       \
-                c[t8 & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q2[t8 & 1][j], t1[j], c[t8 & 1], 0, 0, 0);                     \
-                c[t8 & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1[t8 & 1][j], t2[j], c[t8 & 1], 0, 0, 0);                     \
-                c[t8 & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1[t8 & 1][j], t1[j], c[t8 & 1], 0, 0, 0);                     \
+            if (j == 0) { _Pragma("unroll") for (int r = 0; r < 16; ++r) c[t8 & 1][r] = 0.f; }                                    \
+            c[t8 & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q2[u % 3], t1[j], c[t8 & 1], 0, 0, 0);                             \
+            c[t8 & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1[u % 3], t2[j], c[t8 & 1], 0, 0, 0);                             \
+            c[t8 & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1[u % 3], t1[j], c[t8 & 1], 0, 0, 0);                             \
+            if (j == 0 && t8 > 0) {                                                                                               \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) run[t8 - 1][r] = fmaf(c[(t8 - 1) & 1][r], t_inv, run[t8 - 1][r]);  \
+                ZIRA_FFN_PIN16(run[t8 - 1]);   /* (or instruction selection orders the sums of all eight tiles behind the last   \
+                                                  matrix instruction and every tile's slice stays live: 112 registers, spilled) */ \
             }                                                                                                                     \
-            /* the running sum of the PREVIOUS tile, beside this tile's matrix instructions */                                    \
-            if (t8 > 0) { _Pragma("unroll") for (int r = 0; r < 16; ++r) run[t8 - 1][r] = fmaf(c[(t8 - 1) & 1][r], t_inv, run[t8 - 1][r]); } \
             __builtin_amdgcn_sched_barrier(0);                                                                                    \
         }                                                                                                                         \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) run[7][r] = fmaf(c[1][r], t_inv, run[7][r]);                               \
-        asm volatile("" : "+v"(run[7]));   /* (or the optimiser sinks these sums into the next step and spills their operands) */ \
+        ZIRA_FFN_PIN16(run[7]);                                                                                                   \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                               \
         __builtin_amdgcn_s_barrier();                                                                                             \
         __builtin_amdgcn_sched_barrier(0);   /* (nothing of a step moves into the next) */                                        \
     } while (0)
 
-    for (int s = 1; s <= nsteps; s += 2) {
+    for (int s = s0 + 1; s <= s1; s += 2) {
         ZIRA_FFN_STEP2(s, 1);
         ZIRA_FFN_STEP2(s + 1, 0);
     }
 #undef ZIRA_FFN_STEP2
+#undef ZIRA_FFN_PIN16
+
+    if (tail >= 0) {
+        // ---- a share of the steps: the sums to `partial`, lane for lane; the block that arrives last adds the shares in order ----
+        float *const mine = partial + ((size_t)(tail * nsplit + share) * 4 + pair) * (32 * 64 * 4) + lane * 4;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(mine + (t8 * 4 + g) * 256) = make_float4(run[t8][4 * g], run[t8][4 * g + 1], run[t8][4 * g + 2], run[t8][4 * g + 3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __syncthreads();                 // (thread 0 has drawn the ticket)
+        if (*reinterpret_cast<volatile int *>(smem) == 0) return;
+        const float *const first = partial + ((size_t)(tail * nsplit) * 4 + pair) * (32 * 64 * 4) + lane * 4;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 acc = *reinterpret_cast<const float4 *>(first + (t8 * 4 + g) * 256);
+                for (int sh = 1; sh < nsplit; ++sh) {
+                    const float4 x = *reinterpret_cast<const float4 *>(first + (size_t)sh * 4 * (32 * 64 * 4) + (t8 * 4 + g) * 256);
+                    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+                }
+                run[t8][4 * g] = acc.x; run[t8][4 * g + 1] = acc.y; run[t8][4 * g + 2] = acc.z; run[t8][4 * g + 3] = acc.w;
+            }
+    }
 
     // ---- out: register 4 g + e of tile t8 is column 32 t8 + 8 g + 4 hf + e of row m -----------------------------------------------
     if (!live) return;
@@ -455,9 +526,36 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ p, 
 
 __host__ __device__ inline size_t stream_bytes(int F) { return (size_t)kPBytes + (size_t)(F / 32 + 1) * kUnit; }
 
+// How the row blocks are dealt: `nfull` whole blocks (complete rounds of the chip's CUs), and each row block of the last,
+// partly filled round cut into `nsplit` shares of the steps so that the round fills (and takes 1 / nsplit of the time).
+struct Deal { int blocks, nfull, nsplit, ntail; };
+Deal deal(int M, int nsteps)
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int rbs = (M + kRows - 1) / kRows, rest = rbs % cus;
+    int nsplit = 1;
+    while (rest > 0 && nsplit < 4 && rest * nsplit * 2 <= cus && (nsteps / (nsplit * 2)) % 8 == 0) nsplit *= 2;
+    Deal d;
+    d.nsplit = nsplit;
+    d.ntail = nsplit > 1 ? rest : 0;
+    d.nfull = rbs - d.ntail;
+    d.blocks = d.nfull + d.ntail * nsplit;
+    return d;
+}
+
+size_t workspace_bytes(int M, int nsteps)
+{
+    const Deal d = deal(M, nsteps);
+    return (size_t)d.ntail * 256 + (size_t)d.ntail * d.nsplit * kRows * kC * sizeof(float);   // tickets (zeroed once), then the shares' sums
+}
+
 template <int MODE>
 int launch(const float *a, const unsigned char *stream, int nsteps, const float *pbias, const float *qinv, const float *qbias, const float *aux,
-           unsigned *mask, float *out, int M, hipStream_t st)
+           unsigned *mask, float *out, int M, void *workspace, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -465,8 +563,14 @@ int launch(const float *a, const unsigned char *stream, int nsteps, const float 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ffn_f16x2_kernel<MODE>), dim3((M + kRows - 1) / kRows), dim3(kThreads), kLdsBytes, st, a, stream, nsteps, pbias, qinv, qbias,
-                       aux, mask, out, M);
+    Deal d = deal(M, nsteps);
+    if (!workspace && d.ntail) {   // no scratch: whole blocks only
+        d.nfull += d.ntail; d.blocks = d.nfull; d.ntail = 0; d.nsplit = 1;
+    }
+    unsigned *tickets = reinterpret_cast<unsigned *>(workspace);
+    float *partial = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)d.ntail * 256);
+    hipLaunchKernelGGL((ffn_f16x2_kernel<MODE>), dim3(d.blocks), dim3(kThreads), kLdsBytes, st, a, stream, nsteps, pbias, qinv, qbias, aux, mask, out, M,
+                       d.nfull, d.nsplit, partial, tickets);
     return (int)hipGetLastError();
 }
 
@@ -495,14 +599,20 @@ extern "C" int zira_ffn_f16x2_pack_f32(const float *p, long long p_row_stride, l
     return (int)hipGetLastError();
 }
 
+extern "C" size_t zira_ffn_f16x2_workspace_bytes(int M, int F)
+{
+    if (M <= 0 || F <= 0 || F % 256) return 0;
+    return workspace_bytes(M, F / 32);
+}
+
 extern "C" int zira_ffn_f16x2_f32(const float *a, const void *packed, int M, int F, int backward, const float *q_bias, const float *aux,
-                                  void *mask, float *out, void *stream_)
+                                  void *mask, float *out, void *workspace, void *stream_)
 {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!a || !packed || !mask || !out || M <= 0 || F <= 0 || F % 256) return -1;
-    if (((uintptr_t)a | (uintptr_t)packed | (uintptr_t)mask | (uintptr_t)out | (uintptr_t)q_bias | (uintptr_t)aux) & 15) return -1;
+    if (((uintptr_t)a | (uintptr_t)packed | (uintptr_t)mask | (uintptr_t)out | (uintptr_t)q_bias | (uintptr_t)aux | (uintptr_t)workspace) & 15) return -1;
     const unsigned char *base = reinterpret_cast<const unsigned char *>(packed);
     const float *qinv = reinterpret_cast<const float *>(base + stream_bytes(F)), *pb = qinv + 2 * kC + 2 * F;
-    if (backward) return launch<MODE_BWD>(a, base, F / 32, pb, qinv, q_bias, aux, reinterpret_cast<unsigned *>(mask), out, M, stream);
-    return launch<MODE_FWD>(a, base, F / 32, pb, qinv, q_bias, aux, reinterpret_cast<unsigned *>(mask), out, M, stream);
+    if (backward) return launch<MODE_BWD>(a, base, F / 32, pb, qinv, q_bias, aux, reinterpret_cast<unsigned *>(mask), out, M, workspace, stream);
+    return launch<MODE_FWD>(a, base, F / 32, pb, qinv, q_bias, aux, reinterpret_cast<unsigned *>(mask), out, M, workspace, stream);
 }

@@ -74,8 +74,22 @@ def mask_like(x2: torch.Tensor, d_ffn: int) -> torch.Tensor:
     return torch.empty((x2.shape[0], d_ffn // 32), device=x2.device, dtype=torch.int32)
 
 
+_WORKSPACES = {}
+
+
+def workspace(device, stream: int, M: int, d_ffn: int) -> torch.Tensor:
+    """Scratch of the launches of one (device, stream, shape): zeroed once, left zeroed by every launch where it must be
+    (the kernel's tickets), kept for the life of the process (captured graphs hold its address)."""
+    key = (device, stream, M, d_ffn)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        n = _lib.load().zira_ffn_f16x2_workspace_bytes(M, d_ffn)
+        ws = _WORKSPACES[key] = torch.zeros(max(n, 16), device=device, dtype=torch.uint8)
+    return ws
+
+
 def run(a: torch.Tensor, packed: torch.Tensor, d_ffn: int, backward: bool, mask: torch.Tensor, q_bias: torch.Tensor = None,
-        aux: torch.Tensor = None, out: torch.Tensor = None) -> torch.Tensor:
+        aux: torch.Tensor = None, out: torch.Tensor = None, use_workspace: bool = True) -> torch.Tensor:
     """forward: relu(a P^T + b1) Q^T (+ q_bias) (+ aux), ``mask`` written; backward: ((a P^T) * mask) Q^T (+ q_bias) (+ aux).
     ``out`` may be ``aux``."""
     M = a.shape[0]
@@ -89,9 +103,11 @@ def run(a: torch.Tensor, packed: torch.Tensor, d_ffn: int, backward: bool, mask:
     if aux is not None:
         assert aux.shape == a.shape and aux.is_contiguous() and aux.dtype == torch.float32
     with torch.cuda.device(a.device):
+        st = _stream(a)
+        ws = workspace(a.device, st, M, d_ffn).data_ptr() if use_workspace else 0
         rc = _lib.load().zira_ffn_f16x2_f32(a.data_ptr(), packed.data_ptr(), M, d_ffn, 1 if backward else 0,
                                             0 if q_bias is None else q_bias.data_ptr(), 0 if aux is None else aux.data_ptr(),
-                                            mask.data_ptr(), out.data_ptr(), _stream(a))
+                                            mask.data_ptr(), out.data_ptr(), ws, st)
     if rc != 0:
         raise RuntimeError("zira_ffn_f16x2_f32 failed with code %d (M=%d d_ffn=%d backward=%d)" % (rc, M, d_ffn, int(backward)))
     return out
