@@ -298,12 +298,14 @@ def cpu_baseline_msda(threads):
     B, M, D, P, shapes = 2, 8, 32, 4, NORTH_STAR_SHAPES
     S = sum(h * w for h, w in shapes)
     out = {}
-    for name, Q, iters in (("northstar_B2_Q900", 900, 5), ("encoder_B2_Q22223", S, 2)):
+    for name, Q, iters in (("northstar_B2_Q900", 900, 20), ("encoder_B2_Q22223", S, 5)):
         v, sh, st, loc, attn, go = make_msda_inputs(B, Q, M, D, shapes, P, 0, "cpu")
         if Q == S:
             loc = encoder_loc(B, M, shapes, P, 3, "cpu")
         vv, ll, aa = v.clone().requires_grad_(), loc.clone().requires_grad_(), attn.clone().requires_grad_()
-        msda_torch(vv, sh, ll, aa).backward(go)  # warm-up
+        for _ in range(2):                       # warm-up (allocator, thread pools, first-call set-up)
+            vv.grad = ll.grad = aa.grad = None
+            msda_torch(vv, sh, ll, aa).backward(go)
         tf = tb = 0.0
         for _ in range(iters):
             vv.grad = ll.grad = aa.grad = None
@@ -316,6 +318,7 @@ def cpu_baseline_msda(threads):
             tb += t2 - t1
         npv = [x.numpy() for x in (v, sh, st, loc, attn, go)]
         msda_oracle.msda_forward(*npv[:5])
+        msda_oracle.msda_backward(npv[5], *npv[:5])
         t0 = time.perf_counter()
         for _ in range(iters):
             msda_oracle.msda_forward(*npv[:5])
@@ -397,16 +400,100 @@ def cpu_baseline_step(height=800, width=1333, sample_div=2, threads=None):
         trainer = ZiraTrainer(model)
         h, w = height // sample_div, width // sample_div
         data = synthetic_batch(1, h, w, device="cpu")
+        trainer.run_step(data)                    # (first step: lazy set-up, allocator growth, thread pools -- not timed)
         t0 = time.perf_counter()
         trainer.run_step(data)
         el = time.perf_counter() - t0
-        desc = ("1 full training step at batch 1 on a %dx%d image (1/%d of the %dx%d pixels; counted as "
+        desc = ("the SECOND of 2 full training steps at batch 1 on a %dx%d image (1/%d of the %dx%d pixels; counted as "
                 "that fraction of an image) on the host: this package's model on CPU tensors (torch CPU "
                 "ops, %d of %d cores) with MSDA served by oracle/msda_oracle.c (OpenMP), %.1f s"
                 % (h, w, sample_div * sample_div, height, width, threads, cores, el))
         return (h * w) / float(height * width), el, threads, desc
     finally:
         _C.ms_deform_attn_forward, _C.ms_deform_attn_backward = saved
+
+
+def copy_ceiling(dev, nbytes=1 << 30, iters=10):
+    """What a plain streaming kernel moves on THIS box: a 1 GiB device-to-device copy (bytes read +
+    bytes written per second), a read-only pass (sum) and a write-only pass (fill) over the same 1 GiB, GB/s each."""
+    n = nbytes // 4
+    a = torch.empty(n, device=dev, dtype=torch.float32).normal_()
+    b = torch.empty_like(a)
+
+    def ev(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    t_copy, t_read, t_write = ev(lambda: b.copy_(a)), ev(lambda: a.sum()), ev(lambda: b.fill_(1.0))
+    del a, b
+    return {"bytes": nbytes, "copy_GBs": 2 * nbytes / t_copy / 1e9, "read_GBs": nbytes / t_read / 1e9,
+            "write_GBs": nbytes / t_write / 1e9,
+            "note": "1 GiB: torch copy_ (read + written bytes), sum (read only), fill_ (write only); HIP events, %d calls each" % iters}
+
+
+def arithmetic_accuracy(dev):
+    """The evidence for the configured arithmetic of the frozen products (reference: the FFN of transformer_for_adapter.py:877-886
+    and the 256-wide projections of ms_deform_attn.py:262-288 under the freeze of groundingdino_dual_zero_rep_branch.py:722-745):
+    on the encoder's own shape (44 446 rows), against an fp64 evaluation, the maximum and rms error -- relative to the largest
+    |value| of the fp64 result -- of (a) the fused f16x2 FFN launches (csrc/ffn_f16x2.hip), forward and backward, beside the
+    library's fp32 GEMM chain they replace, and (b) the split-bf16 product (csrc/gemm_bf16x3.hip) beside the library's fp32 GEMM
+    on a 256-wide projection.  `ok` = no figure of the package exceeds the library's."""
+    from ziragroundingdino_amd import ffn_f16x2 as ff, gemm_bf16x3 as g3
+    M, F = 44446, 2048
+    g = torch.Generator(device=dev).manual_seed(11)
+    rn = lambda *shape: torch.randn(*shape, device=dev, generator=g)
+    x, w1, b1, w2, b2 = rn(M, 256), rn(F, 256) * 0.06, rn(F) * 0.1, rn(256, F) * 0.03, rn(256) * 0.1
+    gy, aux = rn(M, 256), rn(M, 256)
+    pk = ff.PackedFFN()
+    bits = ff.mask_like(x, F)
+    ours_f = ff.run(x, pk.get(w1, b1, w2, False), F, False, bits, q_bias=b2)
+    lib_h = torch._addmm_activation(b1, x, w1.t())
+    lib_f = torch.addmm(b2, lib_h, w2.t())
+    ours_b = ff.run(gy, pk.get(w1, b1, w2, True), F, True, bits, aux=aux)
+    # the sign pattern the fused forward saved (a unit within rounding of zero may differ from fp64's): decoded from the bits
+    words = bits.view(torch.int16).view(M, 2, F // 32).to(torch.int32) & 0xFFFF
+    sign = torch.zeros(M, F, dtype=torch.bool, device=dev)
+    for hf in range(2):
+        for r in range(16):
+            sign[:, 8 * (r // 4) + 4 * hf + r % 4::32] = ((words[:, hf, :] >> r) & 1).bool()
+    lib_b = torch.addmm(aux, (gy @ w2) * sign, w1)
+    acc = {k: [0.0, 0.0, 0.0] for k in ("ours_f", "lib_f", "ours_b", "lib_b")}   # max err, sum err^2, max |ref|
+    n_el = 0
+    for lo in range(0, M, 4096):
+        sl = slice(lo, min(M, lo + 4096))
+        ref_f = torch.addmm(b2.double(), torch.addmm(b1.double(), x[sl].double(), w1.double().t()).relu_(), w2.double().t())
+        ref_b = aux[sl].double() + ((gy[sl].double() @ w2.double()) * sign[sl]) @ w1.double()
+        for key, got, ref in (("ours_f", ours_f, ref_f), ("lib_f", lib_f, ref_f), ("ours_b", ours_b, ref_b), ("lib_b", lib_b, ref_b)):
+            e = (got[sl].double() - ref).abs()
+            acc[key][0] = max(acc[key][0], float(e.max()))
+            acc[key][1] += float(e.pow(2).sum())
+            acc[key][2] = max(acc[key][2], float(ref.abs().max()))
+        n_el += ref_f.numel()
+    rel = lambda k: {"max": acc[k][0] / acc[k][2], "rms": (acc[k][1] / n_el) ** 0.5 / acc[k][2]}
+    out = {"shape": "M=%d rows, d_model 256, d_ffn %d, N(0,1) rows, weights N(0, 0.06 / 0.03)" % (M, F),
+           "errors_are": "|result - fp64 result| / max |fp64 result|",
+           "ffn_forward": {"f16x2_fused": rel("ours_f"), "library_fp32": rel("lib_f")},
+           "ffn_backward": {"f16x2_fused": rel("ours_b"), "library_fp32": rel("lib_b")}}
+    del ours_f, lib_h, lib_f, ours_b, lib_b, sign, words
+    wp = rn(256, 256) * 0.06
+    ref = x.double() @ wp.double().t()
+    ours = g3.gemm(x, g3.split_planes(wp, False), g3.EPI_ADD, aux=torch.zeros(M, 256, device=dev)).double()
+    lib = (x @ wp.t()).double()
+    sc = float(ref.abs().max())
+    out["projection_256"] = {"bf16x3": {"max": float((ours - ref).abs().max()) / sc, "rms": float((ours - ref).pow(2).mean().sqrt()) / sc},
+                             "library_fp32": {"max": float((lib - ref).abs().max()) / sc, "rms": float((lib - ref).pow(2).mean().sqrt()) / sc}}
+    pairs = [(out[k][a], out[k]["library_fp32"]) for k, a in (("ffn_forward", "f16x2_fused"), ("ffn_backward", "f16x2_fused"),
+                                                                 ("projection_256", "bf16x3"))]
+    out["ok"] = all(o["max"] <= l["max"] and o["rms"] <= l["rms"] for o, l in pairs)
+    return out
 
 
 def pmc_traffic():
@@ -520,11 +607,16 @@ def main():
                     help="timed regions of --steps steps per launch mode; the line reports the MEDIAN region (each region is "
                          "bracketed by barrier + synchronize on both sides; all of them are listed in config.launch_modes)")
     ap.add_argument("--no-gemm-arith-mode", action="store_true",
-                    help="skip the extra timed regions with the frozen FFN products in split-bf16 arithmetic on the bf16 matrix "
-                         "cores (csrc/gemm_bf16x3.hip); `value` is always the plain fp32 arithmetic")
-    ap.add_argument("--gemm-arith", default="f32", choices=["f32", "bf16x3"],
-                    help="arithmetic of the frozen 44 446-row products for THIS process's timed steps (the default run measures "
-                         "bf16x3 in a child process started with this flag and reports it beside the headline)")
+                    help="skip the extra timed regions with the frozen products in the library's plain fp32 GEMMs (a child "
+                         "process, reported beside the headline in config.gemm_arith)")
+    ap.add_argument("--gemm-arith", default="f16x2", choices=["f32", "bf16x3", "f16x2"],
+                    help="arithmetic of the frozen 44 446-row products for THIS process's timed steps.  f16x2 (the package's "
+                         "default, transformer.Switches.gemm_arith): the encoder FFN as one fp32-accurate launch per direction "
+                         "on the f16 matrix cores (csrc/ffn_f16x2.hip) and split-bf16 products for the other frozen "
+                         "projections (csrc/gemm_bf16x3.hip); f32: the library's fp32 GEMMs.  The default run measures f32 in a "
+                         "child process and reports it beside the headline, with the measured accuracy of both (`accuracy`)")
+    ap.add_argument("--no-accuracy", action="store_true",
+                    help="skip the accuracy block (fp64 comparison of the f16x2 / bf16x3 products and the library's fp32 GEMMs)")
     ap.add_argument("--no-second-mode", action="store_true",
                     help="skip the second timed region in the other launch mode (eager <-> hipGraph replay)")
     args = ap.parse_args()
@@ -538,16 +630,16 @@ def main():
     # encoder pieces are host-sensitive, and eight unpinned ranks share and migrate across cores)
     from ziragroundingdino_amd import placement
     pinned = placement.pin_this_rank(verbose=(rank == 0 or os.environ.get("ZIRA_VERBOSE_PLACEMENT") == "1"))
-    # The split-bf16 arithmetic is timed in a CHILD process of its own, run to completion BEFORE this process touches the GPU:
+    # The OTHER arithmetic (the library's plain fp32 GEMMs) is timed in a CHILD process of its own, run to completion BEFORE this process touches the GPU:
     # a second configuration timed in the process that has already captured and timed the first comes out 1-3 ms per step
     # slower whatever it is (scripts/ab_step.py's note; round 5: 36.5 ms in-process against 32.2 ms alone), and a process that
     # has initialised the GPU must not start programs on this pool.  One GPU, the flagship configuration, fp32 only.
     arith_child = None
     if (world == 1 and "WORLD_SIZE" not in os.environ and not args.no_gemm_arith_mode and args.dtype == "f32"
-            and args.backbone == "swin_T_224_1k" and args.gemm_arith == "f32"):
+            and args.backbone == "swin_T_224_1k" and args.gemm_arith != "f32"):
         import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--gemm-arith", "bf16x3", "--no-gemm-arith-mode", "--no-second-mode",
-               "--no-micro", "--no-cpu-baseline", "--kernel-timing-steps", "0", "--steps", str(args.steps),
+        cmd = [sys.executable, os.path.abspath(__file__), "--gemm-arith", "f32", "--no-gemm-arith-mode", "--no-second-mode",
+               "--no-micro", "--no-cpu-baseline", "--no-accuracy", "--kernel-timing-steps", "0", "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--regions", str(args.regions), "--batch", str(args.batch), "--height", str(args.height),
                "--width", str(args.width), "--categories", str(args.categories), "--minibatches", str(args.minibatches)]
         cmd += [] if args.transformer_graph else ["--no-transformer-graph"]
@@ -556,7 +648,7 @@ def main():
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             arith_child = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         except Exception as e:   # the headline does not depend on it
-            print("[bench] bf16x3 child run failed (%s); entry omitted" % (str(e).splitlines()[0] if str(e) else repr(e)),
+            print("[bench] plain-fp32 child run failed (%s); entry omitted" % (str(e).splitlines()[0] if str(e) else repr(e)),
                   file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
@@ -590,9 +682,9 @@ def main():
     print("[bench] rank %d/%d on cuda:%d, launch mode %s, %s" % (
         rank, world, dev_index, "graph" if args.transformer_graph else "eager",
         "pinned to %d cores" % len(pinned) if pinned else "not pinned"), file=sys.stderr, flush=True)
-    if args.gemm_arith != "f32":
-        from ziragroundingdino_amd import transformer as _tr0
-        _tr0.Switches.gemm_arith = args.gemm_arith
+    from ziragroundingdino_amd import transformer as _tr0
+    arith_is_default = args.gemm_arith == _tr0.Switches.gemm_arith
+    _tr0.Switches.gemm_arith = args.gemm_arith
     torch.manual_seed(0)  # identical replicas on every rank (as after loading one checkpoint)
     model = build_model(zira_swint_config(device=str(dev), backbone=args.backbone)).to(dev).train()
     model.use_transformer_graph = args.transformer_graph
@@ -655,28 +747,16 @@ def main():
                 raise
             print("[bench] second mode skipped (%s)" % (str(e).splitlines()[0] if str(e) else repr(e)), file=sys.stderr, flush=True)
         model.use_transformer_graph = args.transformer_graph
-    # The same steps once more with the encoder FFN's frozen products in split-bf16 (bf16x3) arithmetic: fp32-accurate by the
-    # gate of tests/test_gemm_bf16x3_gpu.py, reported BESIDE the headline (config.gemm_arith), never as `value`.
+    # The same steps with the frozen products in the library's plain fp32 GEMMs, reported BESIDE the headline (config.gemm_arith).
     arith_regions = arith_how = None
     if arith_child is not None:
         try:
             mode = arith_child["config"]["launch_modes"][arith_child["config"]["launch_mode"]]
             arith_regions = [x * args.steps / 1e3 for x in mode["regions_ms_per_step"]]
-            arith_how = ("a child process of this command (python bench.py --gemm-arith bf16x3 ...), run before this process "
+            arith_how = ("a child process of this command (python bench.py --gemm-arith f32 ...), run before this process "
                          "touched the GPU; same GPU, launch mode %s" % arith_child["config"]["launch_mode"])
         except (KeyError, TypeError):
             pass
-    elif (dist_on and not args.no_gemm_arith_mode and args.dtype == "f32" and args.backbone == "swin_T_224_1k"
-          and args.gemm_arith == "f32"):
-        from ziragroundingdino_amd import transformer as _tr
-        _tr.Switches.gemm_arith = "bf16x3"
-        try:
-            run_steps(max(2, args.warmup))
-            arith_regions = [timed(args.steps) for _ in range(regions)]
-            arith_how = "the same processes, after the headline's regions (N > 1: every rank switches; in-process, so 1-3 ms pessimistic)"
-        finally:
-            _tr.Switches.gemm_arith = "f32"
-        run_steps(1)
     timing_source = "HIP events around every native MSDA call of the timed steps"
     if args.transformer_graph and args.kernel_timing_steps > 0:   # (every rank: the steps hold collectives)
         # graph replays hide the launches from event timing: the same step, launched eagerly, right after
@@ -715,6 +795,16 @@ def main():
     primary_mode = "graph" if args.transformer_graph else "eager"
     reported_mode = primary_mode
     elapsed = modes[reported_mode]
+
+    peak_mem = int(torch.cuda.max_memory_allocated(dev))          # (of the timed steps: read before the side measurements below)
+    rank_devices = [[rank, dev_index, torch.cuda.get_device_name(dev)]]
+    if dist_on:
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, rank_devices[0])
+        rank_devices = gathered
+        t = torch.tensor([peak_mem], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        peak_mem = int(t)
 
     if rank == 0:
         groups = summarize_timing(records, args.batch)
@@ -775,8 +865,31 @@ def main():
                                                 "included; "
                                                 "warm_replay = the same calls back to back (round 3's headline); "
                                                 "eager_events = " + timing_source})
+        # what a plain streaming kernel moves on this box, and the headline against it
+        if not args.no_micro:
+            try:
+                roofline["copy_ceiling"] = copy_ceiling(dev)
+                if roofline.get("achieved"):
+                    roofline["frac_of_copy_ceiling"] = roofline["achieved"] / roofline["copy_ceiling"]["copy_GBs"]
+            except RuntimeError as e:
+                print("[bench] copy ceiling skipped (%s)" % str(e).splitlines()[0], file=sys.stderr, flush=True)
         images = args.steps * args.batch * world
         flagship = args.backbone == "swin_T_224_1k" and args.dtype == "f32"
+        accuracy = None
+        if flagship and world == 1 and not args.no_accuracy and args.gemm_arith != "f32":
+            try:
+                accuracy = arithmetic_accuracy(dev)
+            except RuntimeError as e:
+                print("[bench] accuracy block skipped (%s)" % str(e).splitlines()[0], file=sys.stderr, flush=True)
+        # scratch the native paths hold: the decoder's six backward plans (forward -> backward), the dense MSDA backward's
+        # workspace (one, reused), the fused FFN's shares (one per stream)
+        lib_ = _lib.load()
+        S_tok = sum(-(-args.height // d) * -(-args.width // d) for d in (8, 16, 32, 64))
+        mem = {"peak_allocated_bytes": peak_mem,
+               "msda_plan_bytes_per_decoder_layer": int(lib_.zira_msda_plan_bytes(args.batch, S_tok, 8, 32, 4, 900, 4)),
+               "msda_dense_backward_workspace_bytes": int(lib_.zira_msda_bwd_workspace_bytes(args.batch, S_tok, 8, 32, 4, S_tok, 4)),
+               "ffn_f16x2_workspace_bytes": int(lib_.zira_ffn_f16x2_workspace_bytes(args.batch * S_tok, 2048)),
+               "note": "peak_allocated_bytes = torch.cuda.max_memory_allocated over the timed steps (max over ranks)"}
         size = "T" if args.backbone.startswith("swin_T") else "B"
         line = {
             "metric": "images/sec fwd+bwd GroundingDINO-%s+ZiRa @800x1333" % size,
@@ -810,24 +923,36 @@ def main():
                                  for k, v in sorted(modes.items())},
                 "value_is": "median of %d timed regions of %d steps in the configured launch mode (%s)"
                             % (regions, args.steps, primary_mode)
-                            + ("" if args.gemm_arith == "f32" else "; STARTED WITH --gemm-arith %s: not the plain-fp32 headline" % args.gemm_arith),
+                            + ("; arithmetic of the frozen products: %s (%s)" % (
+                                args.gemm_arith, "the package's configured default, transformer.Switches.gemm_arith"
+                                if arith_is_default else "NOT the package default: started with --gemm-arith")),
+                "gemm_arith_configured": args.gemm_arith,
                 "gemm_arith": {args.gemm_arith: {"images_per_s": images / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
-                                                 "note": "the library's fp32 GEMMs: `value`" if args.gemm_arith == "f32" else
-                                                         "this process was started with --gemm-arith bf16x3"},
-                               **({"bf16x3": {"images_per_s": images / sorted(arith_regions)[len(arith_regions) // 2],
-                                              "ms_per_step": sorted(arith_regions)[len(arith_regions) // 2] / args.steps * 1e3,
-                                              "regions_ms_per_step": [x / args.steps * 1e3 for x in arith_regions],
-                                              "note": "encoder FFN products (4 per layer) as split-bf16 sums on the bf16 matrix "
-                                                      "cores, fp32-accurate against fp64 (tests/test_gemm_bf16x3_gpu.py); same "
-                                                      "launch mode as `value`; not the headline",
-                                              "measured_in": arith_how}}
+                                                 "note": {"f32": "the library's fp32 GEMMs for every frozen product",
+                                                          "bf16x3": "split-bf16 products (csrc/gemm_bf16x3.hip) for the frozen "
+                                                                    "44 446-row products, fp32-accurate",
+                                                          "f16x2": "`value`: the encoder FFN as one fp32-accurate launch per "
+                                                                   "direction on the f16 matrix cores (csrc/ffn_f16x2.hip), "
+                                                                   "split-bf16 products (csrc/gemm_bf16x3.hip) for the other "
+                                                                   "frozen projections; outputs stay fp32 and closer to fp64 "
+                                                                   "than the library's (see `accuracy`)"}[args.gemm_arith]},
+                               **({"f32": {"images_per_s": images / sorted(arith_regions)[len(arith_regions) // 2],
+                                           "ms_per_step": sorted(arith_regions)[len(arith_regions) // 2] / args.steps * 1e3,
+                                           "regions_ms_per_step": [x / args.steps * 1e3 for x in arith_regions],
+                                           "note": "the same steps with the library's plain fp32 GEMMs for every frozen product "
+                                                   "(last round's headline arithmetic); same launch mode as `value`",
+                                           "measured_in": arith_how}}
                                   if arith_regions else {})},
+                "rccl_ranks": (dist.get_world_size() if dist_on else 1), "rank_devices": rank_devices,
                 "trainable_values": int(trainer.flat_grad.numel()),
                 "ranks_pinned_to_numa_cores": bool(pinned),
                 "msda_kernel_variant": _lib.variant_f32(32),
             },
             "roofline": roofline,
+            "memory": mem,
         }
+        if accuracy is not None:
+            line["accuracy"] = accuracy
         if world == 1 and not args.no_cpu_baseline and flagship:
             n_img, el, cores, desc = cpu_baseline_step(args.height, args.width, args.cpu_sample_div)
             line["cpu_baseline"] = {"value": n_img / el, "unit": "images/s", "cores": cores,

@@ -25,9 +25,10 @@ def test_gemm_drelu_matches_torch(M, N, K):
     assert torch.equal(C == 0, (H <= 0) | (want == 0).bool())
 
 
-def test_frozen_ffn_backward_matches_module_chain():
+def test_frozen_ffn_backward_matches_module_chain(monkeypatch):
     from ziragroundingdino_amd import transformer as T
 
+    monkeypatch.setattr(T.Switches, "gemm_arith", "f32")   # (this is the library-fp32 form of the frozen FFN; the default is f16x2)
     torch.manual_seed(0)
     layer = T.DeformableTransformerEncoderLayer(256, 2048, 0.0, "relu", 4, 8, 4).cuda().train()
     for p in layer.parameters():

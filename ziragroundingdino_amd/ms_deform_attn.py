@@ -374,6 +374,12 @@ class MultiScaleDeformableAttention(nn.Module):
             fq = self._fused_query_projection()
             g3.refresh(self, {"value": self.value_proj.weight, "output": self.output_proj.weight,
                               **({"query": fq[0]} if fq is not None else {})})
+        # (the planes _MultiValueProjections keeps on the value projection's own Parameter: the decoder's batched projections
+        #  of the memory are replayed from a graph as well)
+        w = self.value_proj.weight
+        if "_bf16x3_split" in w.__dict__:
+            from . import gemm_bf16x3 as g3
+            g3.refresh(w, {"self": w})
 
     fuse_query_projections = True   # class-level switch (tests compare both ways)
     fuse_sampling_plan = True       # ... softmax + sampling locations in one native launch each way (needs the fused projection)
