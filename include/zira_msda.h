@@ -415,6 +415,14 @@ int zira_split_bf16x3_f32(const float *w, int rows, int cols, int transpose, voi
 int zira_gemm_bf16x3_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
                          const float *aux, float *C, void *stream);
 
+/* ---- The same products in two-plane f16 arithmetic (csrc/gemm_f16x2.hip): each fp32 operand, scaled by a power of two per
+ * (row, 32-deep K step) of A and per row of the weight, is a1 + a2 to 2^-22 with a_i f16; three exact product terms, fp32
+ * sums.  Same shapes, epilogues and return codes as zira_gemm_bf16x3_f32.
+ *   zira_split_f16x2_f32: planes = 2 * N * K halves followed by N floats (1 / scale of every row): 4 N K + 4 N bytes. */
+int zira_split_f16x2_f32(const float *w, int rows, int cols, int transpose, void *planes, void *stream);
+int zira_gemm_f16x2_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
+                        const float *aux, float *C, void *stream);
+
 /* ---- The frozen feed-forward block as ONE launch per direction, on the f16 matrix cores in fp32 accuracy ----
  * forward   y  = relu(x W1^T + b1) W2^T + b2        (reference FFN: transformer_for_adapter.py:877-886)
  * backward  gx = aux + ((gy W2) * [h > 0]) W1       (its autograd under the freeze of

@@ -144,7 +144,7 @@ def test_swin_linears_take_the_split_products_in_that_mode_and_follow_their_weig
             assert "_bf16x3_split" not in mlp.__dict__
             zt.Switches.gemm_arith = "bf16x3"
             got = mlp(x)
-            assert set(n for n, _ in mlp.__dict__["_bf16x3_split"]) == {"fc1", "fc2"}
+            assert set(k[0] for k in mlp.__dict__["_bf16x3_split"]) == {"fc1", "fc2"}
             small = mlp(x[:, :1000])                                   # 2000 rows: the library
             assert torch.equal(small, torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(
                 x[:, :1000], mlp.fc1.weight, mlp.fc1.bias)), mlp.fc2.weight, mlp.fc2.bias))

@@ -1,0 +1,108 @@
+"""fp32-accurate GEMM in two-plane f16 arithmetic (csrc/gemm_f16x2.hip; reference products: the 256-wide projections of
+ms_deform_attn.py:262-288 and the backbone's linears under the freeze of groundingdino_dual_zero_rep_branch.py:722-745).
+The accuracy gate: against an fp64 product on the model's own shapes, the maximum and the rms error must not exceed those of
+the library's fp32 GEMM on the same inputs.  Plus an exact-integer layout check, the four epilogues, ragged row counts,
+magnitudes over 24 orders and the cached helpers under ``Switches.gemm_arith = "f16x2"``."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ziragroundingdino_amd import gemm_bf16x3 as g3  # noqa: E402
+
+
+def _ref64(a, w_nk):
+    return a.double() @ w_nk.double().t()
+
+
+def test_exact_on_small_integers_with_asymmetric_operands():
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for M, N, K in ((130, 128, 32), (257, 256, 96), (200, 384, 64)):
+        a = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+        w = torch.randint(-8, 9, (N, K), device="cuda", generator=g).float() + torch.arange(N, device="cuda")[:, None] % 3
+        bias = torch.randint(-4, 5, (N,), device="cuda", generator=g).float()
+        want = a @ w.t() + bias
+        got = g3.gemm_f16x2(a, g3.split_planes_f16x2(w, False), N, g3.EPI_BIAS, bias=bias)
+        assert torch.equal(got, want), (M, N, K)
+        got_t = g3.gemm_f16x2(a, g3.split_planes_f16x2(w.t().contiguous(), True), N, g3.EPI_BIAS, bias=bias)   # the weight stored [K, N]
+        assert torch.equal(got_t, want), (M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K,what", [(44446, 256, 256, "the 256-wide projections"), (44446, 384, 256, "the query projection"),
+                                         (44446, 256, 384, "its input gradient"), (33600, 768, 192, "a Swin stage-2 fc1"),
+                                         (44446, 256, 2048, "K = 2048 on post-ReLU operands")])
+def test_accuracy_gate_against_fp64_beside_the_library_fp32_gemm(M, N, K, what):
+    torch.manual_seed(2)
+    a = torch.randn(M, K, device="cuda")
+    if K == 2048:
+        a = a.relu_()
+    w = torch.randn(N, K, device="cuda") * 0.05
+    ref = _ref64(a, w)
+    lib = (a @ w.t()).double()
+    ours = g3.gemm_f16x2(a, g3.split_planes_f16x2(w, False), N, g3.EPI_ADD, aux=torch.zeros(M, N, device="cuda")).double()
+    scale = float(ref.abs().max())
+    e_lib, e_ours = (lib - ref).abs(), (ours - ref).abs()
+    stats = "max %.3e / %.3e, rms %.3e / %.3e of the scale (ours / library)" % (
+        float(e_ours.max()) / scale, float(e_lib.max()) / scale, float(e_ours.pow(2).mean().sqrt()) / scale,
+        float(e_lib.pow(2).mean().sqrt()) / scale)
+    print(what, stats)
+    assert float(e_ours.max()) <= float(e_lib.max()), stats
+    assert float(e_ours.pow(2).mean().sqrt()) <= float(e_lib.pow(2).mean().sqrt()), stats
+
+
+def test_accuracy_over_magnitudes_and_cancellation():
+    torch.manual_seed(3)
+    M, N, K = 1024, 128, 256
+    a = torch.randn(M, K, device="cuda") * torch.logspace(-12, 12, M, device="cuda")[:, None]
+    a[:, ::7] *= 1e-3                                   # columns of very different size inside a row's K step
+    w = torch.randn(N, K, device="cuda") * torch.logspace(-6, 6, N, device="cuda")[:, None]
+    ref, absref = _ref64(a, w), a.double().abs() @ w.double().abs().t()
+    ours = g3.gemm_f16x2(a, g3.split_planes_f16x2(w, False), N, g3.EPI_BIAS, bias=torch.zeros(N, device="cuda")).double()
+    lib = (a @ w.t()).double()
+    assert float(((ours - ref).abs() / absref).max()) <= max(float(((lib - ref).abs() / absref).max()), 3e-7)
+
+
+@pytest.mark.parametrize("M", [1, 127, 192, 1000])
+def test_epilogues_and_ragged_rows(M):
+    torch.manual_seed(4)
+    N, K = 256, 64
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    bias, aux = torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+    planes = g3.split_planes_f16x2(w, False)
+    prod = (a.double() @ w.double().t())
+    close = lambda x, y: float((x.double() - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+    assert close(g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS, bias=bias), prod + bias.double())
+    assert close(g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS_RELU, bias=bias), (prod + bias.double()).relu())
+    masked = g3.gemm_f16x2(a, planes, N, g3.EPI_MASK, aux=aux)
+    assert close(masked, torch.where(aux > 0, prod, torch.zeros_like(prod))) and bool((masked[aux <= 0] == 0).all())
+    acc = aux.clone()
+    out = g3.gemm_f16x2(a, planes, N, g3.EPI_ADD, aux=acc, out=acc)
+    assert out.data_ptr() == acc.data_ptr() and close(acc, prod + aux.double())
+    guard = torch.full((M + 8, N), 7.0, device="cuda")
+    g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS, bias=bias, out=guard[:M])
+    assert bool((guard[M:] == 7.0).all())
+
+
+def test_cached_helpers_take_the_two_plane_form_under_f16x2_and_follow_the_weight(monkeypatch):
+    from ziragroundingdino_amd import transformer as zt
+    monkeypatch.setattr(zt.Switches, "gemm_arith", "f16x2")
+    calls = []
+    real = g3.gemm_f16x2
+    monkeypatch.setattr(g3, "gemm_f16x2", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    owner = torch.nn.Linear(128, 128).cuda()
+    owner.weight.requires_grad_(False)
+    x = torch.randn(300, 128, device="cuda")
+    y = g3.linear(owner, "w", x, owner.weight, owner.bias.detach())
+    assert len(calls) == 1 and float((y.double() - (x.double() @ owner.weight.double().t() + owner.bias.detach().double())).abs().max()) <= 1e-5
+    gx = g3.linear_input_grad(owner, "w", y, owner.weight)
+    assert len(calls) == 2 and float((gx.double() - y.double() @ owner.weight.double()).abs().max()) <= 1e-4
+    acc = torch.ones_like(x)
+    g3.linear_input_grad(owner, "w", y, owner.weight, accumulate_into=acc)
+    assert float((acc.double() - 1 - y.double() @ owner.weight.double()).abs().max()) <= 1e-4
+    ptrs = {k: sw.buf.data_ptr() for k, sw in owner.__dict__["_bf16x3_split"].items()}
+    with torch.no_grad():
+        owner.weight.mul_(2.0)
+    g3.refresh(owner, {"w": owner.weight})
+    assert {k: sw.buf.data_ptr() for k, sw in owner.__dict__["_bf16x3_split"].items()} == ptrs      # in place
+    y2 = g3.linear(owner, "w", x, owner.weight, owner.bias.detach())
+    assert float((y2.double() - (x.double() @ owner.weight.double().t() + owner.bias.detach().double())).abs().max()) <= 1e-5

@@ -53,7 +53,8 @@ def test_autograd_wrappers_match_torch():
         assert _rel(x, y.double()) < 1e-5
 
 
-@pytest.mark.parametrize("T,with_masks", [(16, True), (9, False), (32, True), (50, True), (256, True)])
+@pytest.mark.parametrize("T,with_masks", [(16, True), (9, False), (32, True), (50, True), (256, True), (194, True), (70, False),
+                                          (100, True), (161, True), (208, False)])   # (T > 64: a wave per image token)
 def test_fused_bi_softmax_matches_unfused_attention(T, with_masks):
     """BiMultiHeadAttention with the fused score post-processing (csrc/bisoftmax.hip) against the
     same module running the PyTorch chain (itself pinned to the reference's order of operations and

@@ -376,7 +376,7 @@ class Joiner(nn.Sequential):
         from . import gemm_bf16x3 as g3
         for m in self.modules():
             if m.__dict__.get("_bf16x3_split"):
-                g3.refresh(m, {n: getattr(m, n).weight for (n, _) in m.__dict__["_bf16x3_split"]})
+                g3.refresh(m, {k[0]: getattr(m, k[0]).weight for k in m.__dict__["_bf16x3_split"]})
 
     def forward(self, tensor_list: NestedTensor):
         xs = self[0](tensor_list)

@@ -296,6 +296,176 @@ __global__ __launch_bounds__(kThreads) void bis_rows_fwd_t32(
     }
 }
 
+// Longer texts (T > 64: COCO-like captions pad to ~195 tokens, reference utils.py:234-269): a WAVE per image token.  Lane l
+// holds columns l, l + 64, ... (KPL of them) of its row in registers; a head's T columns are spread over the lanes, so its
+// softmax maximum and sum are two wave reductions per head.  No LDS tile, no barrier in the loop, whole rows of coalesced
+// loads in flight.  (The tile kernel above walks a (row, head) with ONE thread for T > 64: 2.3 ms per call at T = 194 against
+// the 0.1 ms its 414 MB take.)
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+template <int KPL>
+__global__ __launch_bounds__(kThreads) void bis_rows_fwd_wave(
+    const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
+    const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l, const uint8_t *__restrict__ mask_v, int N, int H, int T,
+    int stable, int clamp_lo, int clamp_hi, float *__restrict__ pv, float *__restrict__ e, float *__restrict__ part_sum)
+{
+    __shared__ float red[kThreads / 64][64 * KPL];
+    const int HT = H * T;
+    const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = stable ? gmax[0] : 0.f;
+    float cj[KPL], cm1[KPL], acc[KPL];
+    int hk[KPL];          // the head of column lane + 64 k (H: no such column)
+    bool live[KPL];       // ... and whether its text token takes part
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const int j = lane + 64 * k;
+        const bool valid = j < HT;
+        hk[k] = valid ? j / T : H;
+        live[k] = valid && !(mask_l && mask_l[b * T + (j - hk[k] * T)]);
+        cj[k] = valid ? c[(size_t)b * HT + j] : 0.f;
+        cm1[k] = valid ? clampf(colmax[(size_t)b * HT + j] - g, clamp_lo, clamp_hi) : 0.f;   // max_n x1 (clamp is monotone)
+        acc[k] = 0.f;
+    }
+    const int nw = (kThreads / 64) * chunks;   // waves per batch element: wave w takes rows w, w + nw, ...
+    for (int row = chunk * (kThreads / 64) + wave; row < N; row += nw) {
+        const size_t o = ((size_t)b * N + row) * HT + lane;
+        float x1[KPL], mk[KPL], ex[KPL], sk[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) x1[k] = hk[k] < H ? xm[o + 64 * k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            x1[k] = clampf(x1[k] + cj[k] - g, clamp_lo, clamp_hi);
+            mk[k] = -INFINITY;
+            sk[k] = 1.f;
+        }
+        for (int h = 0; h < H; ++h) {
+            float loc = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) loc = (hk[k] == h && live[k]) ? fmaxf(loc, x1[k]) : loc;
+            loc = wave_max(loc);
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) mk[k] = hk[k] == h ? loc : mk[k];
+        }
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) ex[k] = live[k] ? expf(x1[k] - mk[k]) : 0.f;
+        for (int h = 0; h < H; ++h) {
+            float loc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) loc += hk[k] == h ? ex[k] : 0.f;
+            loc = wave_sum(loc);
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) sk[k] = hk[k] == h ? loc : sk[k];
+        }
+        const bool dead = mask_v && mask_v[(size_t)b * N + row];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            if (hk[k] < H) {
+                pv[o + 64 * k] = live[k] ? ex[k] * (1.f / sk[k]) : 0.f;
+                const float ev = dead ? 0.f : expf(clampf(x1[k] - cm1[k], clamp_lo, clamp_hi));
+                e[o + 64 * k] = ev;
+                acc[k] += ev;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) red[wave][64 * k + lane] = acc[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < HT; j += kThreads) {
+        float t = red[0][j];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) t += red[w][j];
+        part_sum[((size_t)b * chunks + chunk) * HT + j] = t;
+    }
+}
+
+template <int KPL>
+__global__ __launch_bounds__(kThreads) void bis_rows_bwd_wave(
+    const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
+    const float *__restrict__ gmax, const float *__restrict__ pv, const float *__restrict__ e, const float *__restrict__ g_pv,
+    const float *__restrict__ g_e, const float *__restrict__ g_colsum, int N, int H, int T, int stable, int clamp_lo, int clamp_hi,
+    float *__restrict__ g_xm, float *__restrict__ part_gc)
+{
+    __shared__ float red[kThreads / 64][64 * KPL];
+    const int HT = H * T;
+    const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = stable ? gmax[0] : 0.f;
+    float cj[KPL], cm1[KPL], gcs[KPL], acc[KPL];
+    int hk[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+        const int j = lane + 64 * k;
+        const bool valid = j < HT;
+        hk[k] = valid ? j / T : H;
+        cj[k] = valid ? c[(size_t)b * HT + j] : 0.f;
+        cm1[k] = valid ? clampf(colmax[(size_t)b * HT + j] - g, clamp_lo, clamp_hi) : 0.f;
+        gcs[k] = valid ? g_colsum[(size_t)b * HT + j] : 0.f;
+        acc[k] = 0.f;
+    }
+    const int nw = (kThreads / 64) * chunks;
+    for (int row = chunk * (kThreads / 64) + wave; row < N; row += nw) {
+        const size_t o = ((size_t)b * N + row) * HT + lane;
+        float pp[KPL], gp[KPL], xv[KPL], ge[KPL], ev[KPL], dk[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            const bool valid = hk[k] < H;
+            pp[k] = valid ? pv[o + 64 * k] : 0.f;
+            gp[k] = valid ? g_pv[o + 64 * k] : 0.f;
+            xv[k] = valid ? xm[o + 64 * k] : 0.f;
+            ge[k] = valid ? g_e[o + 64 * k] : 0.f;
+            ev[k] = valid ? e[o + 64 * k] : 0.f;
+            dk[k] = 0.f;
+        }
+        // softmax backward per (row, head): p * (g - <g, p>)   (0 on masked text tokens: p = 0)
+        for (int h = 0; h < H; ++h) {
+            float loc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) loc = hk[k] == h ? fmaf(gp[k], pp[k], loc) : loc;
+            loc = wave_sum(loc);
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) dk[k] = hk[k] == h ? loc : dk[k];
+        }
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+            if (hk[k] < H) {
+                const float gpv = pp[k] * (gp[k] - dk[k]);
+                const float xs = xv[k] + cj[k] - g;                        // before clamp 1
+                const float x1 = clampf(xs, clamp_lo, clamp_hi);
+                const float d2 = x1 - cm1[k];                              // before clamp 2
+                const bool pass2 = !((clamp_lo && d2 < -kClamp) || (clamp_hi && d2 > kClamp));
+                const bool pass1 = !((clamp_lo && xs < -kClamp) || (clamp_hi && xs > kClamp));
+                float gl = (ge[k] + gcs[k]) * ev[k];                       // through exp (e = 0 on padded image tokens)
+                if (!pass2) gl = 0.f;
+                float gx = gpv + gl;
+                if (!pass1) gx = 0.f;
+                g_xm[o + 64 * k] = gx;
+                acc[k] += gx;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) red[wave][64 * k + lane] = acc[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < HT; j += kThreads) {
+        float t = red[0][j];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) t += red[w][j];
+        part_gc[((size_t)b * chunks + chunk) * HT + j] = t;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void bis_rows_bwd(
     const float *__restrict__ xm, const float *__restrict__ c, const float *__restrict__ colmax,
     const float *__restrict__ gmax, const uint8_t *__restrict__ mask_l, const float *__restrict__ pv,
@@ -413,6 +583,22 @@ inline int row_blocks(int N, int HT)
     return tiles < kMaxRowBlocks ? tiles : kMaxRowBlocks;
 }
 
+// the wave-per-row kernels: T > 64 (the tile kernels keep the lane-group forms for short texts), H * T <= 1024
+inline bool use_wave_rows(int H, int T) { return T > 64 && H * T <= 1024; }
+inline int wave_row_blocks(int N)
+{
+    const int blocks = (N + kThreads / 64 - 1) / (kThreads / 64);
+    return blocks < kMaxRowBlocks ? blocks : kMaxRowBlocks;
+}
+#define ZIRA_BIS_KPL(HT_, CALL_)                                   \
+    do {                                                           \
+        if ((HT_) <= 256) { constexpr int KPL = 4; CALL_; }        \
+        else if ((HT_) <= 512) { constexpr int KPL = 8; CALL_; }   \
+        else if ((HT_) <= 768) { constexpr int KPL = 12; CALL_; }  \
+        else if ((HT_) <= 832) { constexpr int KPL = 13; CALL_; }  \
+        else { constexpr int KPL = 16; CALL_; }                    \
+    } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -421,7 +607,7 @@ size_t zira_bisoftmax_workspace_floats(int B, int N, int H, int T)
 {
     if (B <= 0 || N <= 0 || H <= 0 || T <= 0) return 0;
     const int HT = H * T;
-    const size_t row_chunks = (size_t)row_blocks(N, HT);
+    const size_t row_chunks = use_wave_rows(H, T) ? (size_t)wave_row_blocks(N) : (size_t)row_blocks(N, HT);
     const size_t chunks = row_chunks > (size_t)colmax_chunks(N) ? row_chunks : (size_t)colmax_chunks(N);
     return (size_t)B * chunks * HT + (size_t)B * HT + 8;  // partials, column maxima, global maximum
 }
@@ -441,9 +627,14 @@ int zira_bisoftmax_fwd_f32(const float *xm, const float *c, const uint8_t *mask_
     hipLaunchKernelGGL(bis_colmax_partial, dim3(cchunks, B), dim3(kThreads), 0, st, xm, N, HT, crow, workspace);
     hipLaunchKernelGGL(bis_fold, dim3(B, (HT + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, workspace, cchunks, HT, 0, c, colmax);
     hipLaunchKernelGGL(bis_global_max, dim3(1), dim3(kThreads), 0, st, colmax, total, gmax);
-    const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
+    const int R = rows_per_block(HT);
+    int rchunks = row_blocks(N, HT);
     const int vec = (HT % 4 == 0) && !(((uintptr_t)xm | (uintptr_t)c | (uintptr_t)colmax | (uintptr_t)pv | (uintptr_t)e) & 15);
-    if (T == 32 && (HT == 64 || HT == 128 || HT == 256)) {   // a (row, head) = half a wave: the register form
+    if (use_wave_rows(H, T)) {   // a wave per image token
+        rchunks = wave_row_blocks(N);
+        ZIRA_BIS_KPL(HT, hipLaunchKernelGGL(bis_rows_fwd_wave<KPL>, dim3(rchunks, B), dim3(kThreads), 0, st, xm, c, colmax, gmax, mask_l, mask_v, N,
+                                            H, T, stable, clamp_lo, clamp_hi, pv, e, workspace));
+    } else if (T == 32 && (HT == 64 || HT == 128 || HT == 256)) {   // a (row, head) = half a wave: the register form
         const dim3 grid(rchunks, B);
         if (HT == 64) hipLaunchKernelGGL(bis_rows_fwd_t32<1>, grid, dim3(kThreads), 0, st, xm, c, colmax, gmax, mask_l, mask_v, N, stable, clamp_lo, clamp_hi, pv, e, workspace);
         else if (HT == 128) hipLaunchKernelGGL(bis_rows_fwd_t32<2>, grid, dim3(kThreads), 0, st, xm, c, colmax, gmax, mask_l, mask_v, N, stable, clamp_lo, clamp_hi, pv, e, workspace);
@@ -466,9 +657,15 @@ int zira_bisoftmax_bwd_f32(const float *xm, const float *c, const uint8_t *mask_
         return ZIRA_MSDA_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int HT = H * T;
-    const int R = rows_per_block(HT), rchunks = row_blocks(N, HT);
+    const int R = rows_per_block(HT);
+    int rchunks = row_blocks(N, HT);
     const int vec = (HT % 4 == 0) && !(((uintptr_t)xm | (uintptr_t)c | (uintptr_t)colmax | (uintptr_t)pv | (uintptr_t)e | (uintptr_t)g_pv |
                                         (uintptr_t)g_e | (uintptr_t)g_colsum | (uintptr_t)g_xm) & 15);
+    if (use_wave_rows(H, T)) {
+        rchunks = wave_row_blocks(N);
+        ZIRA_BIS_KPL(HT, hipLaunchKernelGGL(bis_rows_bwd_wave<KPL>, dim3(rchunks, B), dim3(kThreads), 0, st, xm, c, colmax, gmax, pv, e, g_pv, g_e,
+                                            g_colsum, N, H, T, stable, clamp_lo, clamp_hi, g_xm, workspace));
+    } else
     hipLaunchKernelGGL(bis_rows_bwd, dim3(rchunks, B), dim3(kThreads), ((size_t)2 * R + 1) * HT * sizeof(float), st,
                        xm, c, colmax, gmax, mask_l, pv, e, g_pv, g_e, g_colsum, N, H, T, R, stable, clamp_lo,
                        clamp_hi, vec, g_xm, workspace);

@@ -5,6 +5,10 @@ weight's three planes are made once and follow the parameter in place (captured 
 the activation is split inside the kernel.  Stands for ``F.linear`` / autograd's ``mm`` in the reference FFN
 (transformer_for_adapter.py:877-886) under the freeze of groundingdino_dual_zero_rep_branch.py:722-745.
 
+Under ``transformer.Switches.gemm_arith = "f16x2"`` the cached helpers at the end of this file (``linear``,
+``linear_input_grad``, ``refresh``) take the two-plane f16 form of the same products instead (csrc/gemm_f16x2.hip: three
+terms per fragment pair instead of six; ``split_planes_f16x2`` / ``gemm_f16x2`` below).
+
 No autograd here: the callers are hand-written forward / backward pairs (transformer._FrozenFFN, _FrozenFFNNorm)."""
 import torch
 
@@ -33,19 +37,38 @@ def split_planes(weight: torch.Tensor, transpose: bool, out: torch.Tensor = None
     return out
 
 
-class SplitWeight:
-    """The bf16 planes of one frozen weight in one orientation, refreshed IN PLACE when the parameter changes
-    (``data_ptr`` / ``_version``): a replayed hipGraph keeps reading the same buffer."""
+def split_planes_f16x2(weight: torch.Tensor, transpose: bool, out: torch.Tensor = None) -> torch.Tensor:
+    """weight [rows, cols] fp32 on the GPU -> flat int16 [2 N K + 2 N]: the two f16 planes [2, N, K] of the row-scaled weight,
+    then 1 / scale of every row as N floats; B[n][k] = weight[n][k] (``transpose`` False) or weight[k][n] (True)."""
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+    rows, cols = weight.shape
+    n = 2 * rows * cols + 2 * (cols if transpose else rows)
+    if out is None:
+        out = torch.empty(n, device=weight.device, dtype=torch.int16)
+    assert out.shape == (n,) and out.dtype == torch.int16 and out.is_contiguous()
+    with torch.cuda.device(weight.device):
+        rc = _lib.load().zira_split_f16x2_f32(weight.data_ptr(), rows, cols, 1 if transpose else 0, out.data_ptr(), _stream(weight))
+    if rc != 0:
+        raise RuntimeError("zira_split_f16x2_f32 failed with code %d" % rc)
+    return out
 
-    def __init__(self, transpose: bool):
-        self.transpose, self.key, self.buf = transpose, None, None
+
+class SplitWeight:
+    """The planes of one frozen weight in one orientation (bf16 x 3, or f16 x 2 with ``f16x2``), refreshed IN PLACE when the
+    parameter changes (``data_ptr`` / ``_version``): a replayed hipGraph keeps reading the same buffer."""
+
+    def __init__(self, transpose: bool, f16x2: bool = False):
+        self.transpose, self.key, self.buf, self.f16x2 = transpose, None, None, f16x2
+        self.shape = None
 
     def planes(self, weight: torch.Tensor) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, weight.device)
         if key != self.key:
             with torch.no_grad():
-                same = self.buf is not None and self.buf.device == weight.device and self.buf.numel() == 3 * weight.numel()
-                self.buf = split_planes(weight.detach(), self.transpose, self.buf if same else None)
+                same = self.buf is not None and self.buf.device == weight.device and self.shape == tuple(weight.shape)
+                fn = split_planes_f16x2 if self.f16x2 else split_planes
+                self.buf = fn(weight.detach(), self.transpose, self.buf if same else None)
+                self.shape = tuple(weight.shape)
             self.key = key
         return self.buf
 
@@ -77,7 +100,33 @@ def gemm(a: torch.Tensor, planes: torch.Tensor, epilogue: int, bias: torch.Tenso
     return out
 
 
+def gemm_f16x2(a: torch.Tensor, planes: torch.Tensor, N: int, epilogue: int, bias: torch.Tensor = None, aux: torch.Tensor = None,
+               out: torch.Tensor = None) -> torch.Tensor:
+    """epilogue(a [M, K] @ B^T) -> [M, N] with B = ``planes`` (split_planes_f16x2 of an [N, K] weight).  ``out`` may be ``aux``."""
+    M, K = a.shape
+    assert planes.shape == (2 * N * K + 2 * N,) and planes.dtype == torch.int16 and planes.is_contiguous() and planes.device == a.device
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
+    if bias is not None:
+        assert bias.shape == (N,) and bias.is_contiguous() and bias.dtype == torch.float32
+    if aux is not None:
+        assert aux.shape == (M, N) and aux.is_contiguous() and aux.dtype == torch.float32
+    with torch.cuda.device(a.device):
+        rc = _lib.load().zira_gemm_f16x2_f32(a.data_ptr(), planes.data_ptr(), M, N, K, epilogue,
+                                             0 if bias is None else bias.data_ptr(), 0 if aux is None else aux.data_ptr(),
+                                             out.data_ptr(), _stream(a))
+    if rc != 0:
+        raise RuntimeError("zira_gemm_f16x2_f32 failed with code %d (M=%d N=%d K=%d epilogue=%d)" % (rc, M, N, K, epilogue))
+    return out
+
+
 # ---- cached split weights of modules -----------------------------------------------------------------------------------------
+
+def _two_plane() -> bool:
+    from .transformer import Switches
+    return Switches.gemm_arith == "f16x2"
+
 
 def enabled() -> bool:
     """Whether the callers should take the split-bf16 products (``transformer.Switches.gemm_arith`` = "bf16x3", or "f16x2":
@@ -87,29 +136,37 @@ def enabled() -> bool:
 
 
 def _cache(owner, name, transpose):
+    # (one store per owner; the two arithmetics keep their planes under different keys)
     store = owner.__dict__.setdefault("_bf16x3_split", {})
-    sw = store.get((name, transpose))
+    two = _two_plane()
+    sw = store.get((name, transpose, two) if two else (name, transpose))
     if sw is None:
-        sw = store[(name, transpose)] = SplitWeight(transpose)
+        sw = store[(name, transpose, two) if two else (name, transpose)] = SplitWeight(transpose, f16x2=two)
     return sw
+
+
+def _gemm_cached(sw, a, weight, N, epilogue, **kw):
+    planes = sw.planes(weight)
+    if sw.f16x2:
+        return gemm_f16x2(a, planes, N, epilogue, **kw)
+    return gemm(a, planes, epilogue, **kw)
 
 
 def linear(owner, name, x2, weight, bias=None, out=None):
     """``x2 @ weight.T (+ bias)`` for a frozen ``weight`` [N, K]; the planes are cached on ``owner`` under ``name``."""
     N = weight.shape[0]
-    planes = _cache(owner, name, False).planes(weight)
     if bias is None:
         bias = _zeros(N, x2.device)
-    return gemm(x2, planes, EPI_BIAS, bias=bias, out=out)
+    return _gemm_cached(_cache(owner, name, False), x2, weight, N, EPI_BIAS, bias=bias, out=out)
 
 
 def linear_input_grad(owner, name, g2, weight, accumulate_into=None):
     """``g2 @ weight`` for a frozen ``weight`` [N_out, K_in] (the input gradient of ``F.linear``): [M, N_out] -> [M, K_in];
     ``accumulate_into`` [M, K_in]: added to IN PLACE (the gradient that meets this one) and returned."""
-    planes = _cache(owner, name, True).planes(weight)          # B[n][k] = weight[k][n]
+    sw, N = _cache(owner, name, True), weight.shape[1]          # B[n][k] = weight[k][n]
     if accumulate_into is not None:
-        return gemm(g2, planes, EPI_ADD, aux=accumulate_into, out=accumulate_into)
-    return gemm(g2, planes, EPI_BIAS, bias=_zeros(weight.shape[1], g2.device))
+        return _gemm_cached(sw, g2, weight, N, EPI_ADD, aux=accumulate_into, out=accumulate_into)
+    return _gemm_cached(sw, g2, weight, N, EPI_BIAS, bias=_zeros(N, g2.device))
 
 
 _ZEROS = {}
@@ -125,7 +182,7 @@ def _zeros(n, device):
 def refresh(owner, weights):
     """Bring every cached plane set of ``owner`` up to date (``weights``: name -> tensor), in place; for
     ``refresh_fused_projection`` hooks (a replayed hipGraph re-runs no Python)."""
-    for (name, _), sw in owner.__dict__.get("_bf16x3_split", {}).items():
-        w = weights.get(name)
+    for key, sw in owner.__dict__.get("_bf16x3_split", {}).items():
+        w = weights.get(key[0])
         if w is not None:
             sw.planes(w)
