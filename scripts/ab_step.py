@@ -41,6 +41,8 @@ for kv in sys.argv[1:]:
         zt.Switches.gemm_arith = v
     elif k == "prefetch_after_encoder":
         ZiraTrainer.prefetch_after_encoder = bool(int(v))
+    elif k == "prefetch_at_start":   # (hangs with gemm_arith=f32: two streams of Stream-K library GEMMs, scripts/repro_streamk_two_streams.py)
+        ZiraTrainer.prefetch_at_start = bool(int(v))
         import faulthandler
         faulthandler.dump_traceback_later(90, exit=True)     # (a hung GPU must not hold the box)
     elif k == "frontend_graphs":

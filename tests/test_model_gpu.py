@@ -783,3 +783,20 @@ def test_task_chain_survives_a_restart_of_the_rccl_group(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_GROUP_RESTART], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL-GROUP-RESTART-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_front_end_queued_before_the_forward_completes_200_steps():
+    """Regression test of the parked round-5 hang.  ROOT CAUSE (scripts/repro_streamk_two_streams.py, no model needed): every
+    fp32 GEMM the library picks on gfx950 is a Stream-K kernel -- a persistent grid whose workgroups wait for their peers'
+    partial sums --, and two streams that both run LARGE ones at the same time (the front end's Swin linears in their graph
+    beside the encoder's 44 446-row products) leave each grid holding CU slots its peers need: the GPU never finishes.  With the
+    package's own kernels for those products (the default arithmetic) the earlier placement runs; the trainer still queues the
+    front end behind the encoder (train.py), where no large library GEMM of the step runs beside it in any arithmetic.
+    Here: the earlier placement, default arithmetic, 200 steps, in a child process under a watchdog (a hang fails the test
+    instead of the suite; the child is never re-executed)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "repro_frontend_hang.py")
+    out = subprocess.run([sys.executable, script, "at=start", "steps=200", "watchdog=60"], capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0 and "DONE" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

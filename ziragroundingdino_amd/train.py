@@ -111,6 +111,12 @@ class ZiraTrainer:
                                    "(zero_grad(set_to_none=True)?); call trainer._bind()" % n)
 
     prefetch_after_encoder = True   # class-level switch for A/B runs (False: behind the whole forward, as until round 5)
+    # Developer switch (scripts/repro_frontend_hang.py): queue it BEFORE this step's forward.  Slower (26.4 against 25.4 ms), and
+    # with the library's fp32 GEMMs for the large frozen products it HANGS THE GPU: every fp32 GEMM hipBLASLt / rocBLAS pick
+    # on gfx950 is a Stream-K kernel (persistent grid, workgroups wait for their peers' partial sums), and two streams that
+    # both run large ones at the same time deadlock (scripts/repro_streamk_two_streams.py: no model needed).  Behind the
+    # encoder no large library GEMM of the step runs beside the front end, whatever the arithmetic.
+    prefetch_at_start = False
 
     def run_step(self, data, next_data=None) -> Dict[str, torch.Tensor]:
         """One optimisation step on one minibatch; returns the (detached) weighted loss dict.
@@ -127,21 +133,29 @@ class ZiraTrainer:
         can_prefetch = (next_data is not None and self.amp_dtype is None and hasattr(self.model, "can_prefetch_frontend")
                         and self.model.can_prefetch_frontend())
         tr = getattr(self.model, "transformer", None)
-        if can_prefetch and self.prefetch_after_encoder and hasattr(tr, "fire_after_encoder"):
+        if can_prefetch and self.prefetch_at_start:
+            from .transformer import Switches
+            if Switches.gemm_arith == "f32":
+                raise RuntimeError("[ZiraTrainer] prefetch_at_start with gemm_arith = 'f32' deadlocks the GPU (two streams of "
+                                   "Stream-K library GEMMs); see scripts/repro_streamk_two_streams.py")
+            self._prefetched = self.model.prefetch_frontend(next_data)
+        elif can_prefetch and self.prefetch_after_encoder and hasattr(tr, "fire_after_encoder"):
             # the next minibatch's front end is queued when this step's ENCODER forward has been launched (round 5: 34.1 ->
             # 32.4 ms per step against queuing it behind the whole forward; queuing it at the start of the step hangs the GPU)
             def _queue(self=self, next_data=next_data):
                 self._prefetched = self.model.prefetch_frontend(next_data)
             tr.__dict__["after_encoder"] = _queue
-        if self.amp_dtype is not None:
-            # (graph capture under autocast needs the weight-cast cache off: torch.cuda.make_graphed_callables)
-            graphs = bool(getattr(self.model, "use_transformer_graph", False))
-            with torch.autocast(self.flat_grad.device.type, dtype=self.amp_dtype, cache_enabled=not graphs):
+        try:
+            if self.amp_dtype is not None:
+                # (graph capture under autocast needs the weight-cast cache off: torch.cuda.make_graphed_callables)
+                graphs = bool(getattr(self.model, "use_transformer_graph", False))
+                with torch.autocast(self.flat_grad.device.type, dtype=self.amp_dtype, cache_enabled=not graphs):
+                    loss_dict = self.model(data, **kw)
+            else:
                 loss_dict = self.model(data, **kw)
-        else:
-            loss_dict = self.model(data, **kw)
-        if tr is not None:
-            tr.__dict__["after_encoder"] = None          # (not fired: pieces still being captured, or a forward that skipped it)
+        finally:
+            if tr is not None:   # (not fired: pieces still being captured, a forward that skipped it -- or one that raised: the
+                tr.__dict__["after_encoder"] = None   # hook must not stay armed, holding the next minibatch)
         if can_prefetch and self._prefetched is None:
             self._prefetched = self.model.prefetch_frontend(next_data)
         losses = getattr(loss_dict, "total", None)   # the model's own sum of the same terms (criterion.LossDict)
