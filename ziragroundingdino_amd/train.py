@@ -135,7 +135,7 @@ class ZiraTrainer:
         tr = getattr(self.model, "transformer", None)
         if can_prefetch and self.prefetch_at_start:
             from .transformer import Switches
-            if Switches.gemm_arith == "f32":
+            if Switches.gemm_arith == "f32" and not getattr(self, "allow_deadlock_repro", False):
                 raise RuntimeError("[ZiraTrainer] prefetch_at_start with gemm_arith = 'f32' deadlocks the GPU (two streams of "
                                    "Stream-K library GEMMs); see scripts/repro_streamk_two_streams.py")
             self._prefetched = self.model.prefetch_frontend(next_data)
