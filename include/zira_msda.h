@@ -106,14 +106,16 @@ int zira_msda_bwd_f32_ws(const float *grad_out, const float *value, const int64_
  *   zira_msda_bwd_planned_f32 the backward from a plan: ONE launch whose persistent workgroups sum grad_value tile by
  *                             tile in LDS (the only load that depends on a record is the query's grad_out row) while
  *                             forward-style waves -- one per (b, q, m) -- gather the value rows again and form
- *                             grad_sampling_loc / grad_attn_weight, and a small launch that adds up the partial tiles of
- *                             split tiles.  `plan` must come from zira_msda_*plan_f32 for the same dimensions,
- *                             level tables, sampling_loc AND attn_weight.  Same outputs / contract as
+ *                             grad_sampling_loc / grad_attn_weight.  The shares of a split tile meet INSIDE that launch
+ *                             (since round 5; there is no fold launch): each share writes its partial tile through to
+ *                             memory and draws a ticket from the tile's agent-scope counter, and the share that arrives
+ *                             last adds all of them in share order.  `plan` must come from zira_msda_*plan_f32 for the
+ *                             same dimensions, level tables, sampling_loc AND attn_weight.  Same outputs / contract as
  *                             zira_msda_bwd_f32_ws; deterministic apart from the order of the LDS sums in double (no fp32
  *                             atomics anywhere).
- * The plan buffer needs no initialisation and 16-byte alignment; the backward uses a region of it as scratch (the partial
- * tiles: hence `plan` is not const there), so a plan may serve several backward calls one after the other on a stream, not
- * concurrently.  Limits of the planned path (zira_msda_plan_bytes returns 0 beyond them and the callers take
+ * The plan buffer needs no initialisation and 16-byte alignment; the backward uses regions of it as scratch (the partial
+ * tiles and their tickets: hence `plan` is not const there).  A plan is NOT REENTRANT: it may serve several backward calls one
+ * after the other on a stream, never two at the same time (they would race on the tickets and the partial tiles).  Limits of the planned path (zira_msda_plan_bytes returns 0 beyond them and the callers take
  * zira_msda_bwd_f32_ws): D = 32, L <= 16, and the plan kernel's LDS tables -- S / 8 + L tile counters beside 64 KB of
  * per-thread ranks -- within 78 KB, i.e. S up to about 27 000 value rows per image (the decoder shape has 22 223).  Where the
  * runtime refuses the kernels' dynamic-LDS opt-in, zira_msda_fwd_plan_f32 falls back to zira_msda_fwd_f32 +

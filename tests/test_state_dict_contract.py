@@ -71,3 +71,38 @@ def test_full_model_state_dict_names_and_shapes():
     trainable = {n: p.numel() for n, p in model.named_parameters() if p.requires_grad}
     assert all("adapter" in n for n in trainable) and len(trainable) == 25
     assert sum(trainable.values()) == 4_622_853                # the DDP payload of the reference (18 491 412 B)
+
+
+def _fixture():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_keys.json")) as fh:
+        return json.load(fh)
+
+
+def _under(sd, prefix):
+    return {k[len(prefix):]: list(v.shape) for k, v in sd.items() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("backbone", ["swin_T_224_1k", "swin_B_384_22k"])
+def test_every_key_and_shape_of_the_reference_modules(backbone):
+    """The COMPLETE lists (tests/golden/state_dict_keys.json, written by gen_state_dict_keys.py from the imported reference:
+    its Transformer with the heads of groundingdino_dual_zero_rep_branch.py:321-361, both Swin backbones, the side-branch
+    modules): every key of the reference exists here under the model's prefix with the same shape, and this package adds
+    none of its own (derived buffers -- fused projections, packed weights -- are not registered state)."""
+    ref = _fixture()
+    model = build_model(zira_swint_config(device="cpu", backbone=backbone))
+    sd = model.state_dict()
+    for prefix, name in (("transformer.", "transformer"), ("backbone.0.", backbone)):
+        mine, want = _under(sd, prefix), ref[name]
+        assert sorted(mine) == sorted(want), (sorted(set(want) - set(mine))[:10], sorted(set(mine) - set(want))[:10])
+        wrong = {k: (mine[k], want[k]) for k in want if mine[k] != want[k]}
+        assert not wrong, dict(list(wrong.items())[:10])
+    # the side branches: one linear (text) and four convolutions (image levels), reference :57-135, :300-318
+    c3 = {"swin_T_224_1k": 768, "swin_B_384_22k": 1024}[backbone]
+    assert _under(sd, "rep_linear_adapter.") == ref["rep_zero_linear_768_256"]
+    if backbone == "swin_T_224_1k":
+        assert _under(sd, "input_proj_conv_adapter.0.") == ref["rep_zero_conv_192_256_1x1"]
+        assert _under(sd, "input_proj_conv_adapter.3.") == ref["rep_zero_conv_768_256_3x3s2"]
+    else:
+        assert list(sd["input_proj_conv_adapter.3.weight"].shape) == [256, c3, 3, 3]
