@@ -798,6 +798,13 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
                 // in their fixed order 0 .. K - 1 (read with agent-scope loads: past this CU's L1) and writes the tile's
                 // pixels: the same sum in every run, whoever arrives last.  cdna_hip_programming.md section 5 ("in-launch
                 // split-K reduction", write-through form) / Guideline 16 R1.  No other block waits: nothing can deadlock.
+                // NOTE: this is that guide's write-through recipe, not a C++ release / acquire pair: the ordering rests on gfx950
+                // behaviour the guide measured -- agent-scope (sc1) stores have left the XCD's L2 when the storing wave's
+                // s_waitcnt vmcnt(0) returns, the counter add comes behind every storing wave's wait and a workgroup barrier,
+                // and EVERY load of the handed-off bytes is an agent-scope (sc1) load, past this CU's L1.  Pinned to the target:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "msda_bwd_tile_accum's in-launch hand-off is validated for gfx950 only (write-through stores + sc1 loads)"
+#endif
                 typedef unsigned long long u64;
                 const size_t toff = (size_t)p0 * D + c4 * 4;          // this thread's float4 of a tile, round 0
                 u64 *pb = reinterpret_cast<u64 *>(partial + (size_t)it.slot * kNPix * D + toff);
