@@ -425,6 +425,16 @@ int zira_split_f16x2_f32(const float *w, int rows, int cols, int transpose, void
 int zira_gemm_f16x2_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
                         const float *aux, float *C, void *stream);
 
+/* ---- The skinny ones among them (K = 256 or 384, N % 32 == 0: the 256-wide projections of the deformable attention and their
+ * input gradients), bound by memory: a block takes 32 rows and ALL of K -- one burst of loads, one barrier, no K loop -- and the
+ * weight fragments come packed in the order the matrix core reads them (csrc/gemm_f16x2_panel.hip).  Same arithmetic,
+ * epilogues and return codes; A2 (or NULL) is added to A element-wise on the way in (the position code of the query,
+ * transformer_for_adapter.py:893-900).
+ *   zira_split_f16x2_frag_f32: frags = 2 * N * K halves in fragment order, then N floats: 4 N K + 4 N bytes. */
+int zira_split_f16x2_frag_f32(const float *w, int rows, int cols, int transpose, void *frags, void *stream);
+int zira_gemm_f16x2_panel_f32(const float *A, const float *A2, const void *b_frags, int M, int N, int K, int epilogue,
+                              const float *bias, const float *aux, float *C, void *stream);
+
 /* ---- The frozen feed-forward block as ONE launch per direction, on the f16 matrix cores in fp32 accuracy ----
  * forward   y  = relu(x W1^T + b1) W2^T + b2        (reference FFN: transformer_for_adapter.py:877-886)
  * backward  gx = aux + ((gy W2) * [h > 0]) W1       (its autograd under the freeze of

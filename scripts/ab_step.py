@@ -39,6 +39,9 @@ for kv in sys.argv[1:]:
         zt.BiAttentionBlock.residual_in_gemm = bool(int(v))
     elif k == "gemm_arith":
         zt.Switches.gemm_arith = v
+    elif k == "panel":
+        from ziragroundingdino_amd import gemm_bf16x3 as _g3
+        _g3.USE_PANEL = bool(int(v))
     elif k == "prefetch_after_encoder":
         ZiraTrainer.prefetch_after_encoder = bool(int(v))
     elif k == "prefetch_at_start":   # (hangs with gemm_arith=f32: two streams of Stream-K library GEMMs, scripts/repro_streamk_two_streams.py)

@@ -35,5 +35,10 @@ for what, M, N, K in (("value / output projection", 44446, 256, 256), ("query pr
     t3 = timed(lambda: g3.gemm(a, p3, g3.EPI_BIAS, bias=b, out=out))
     t2 = timed(lambda: g3.gemm_f16x2(a, p2, N, g3.EPI_BIAS, bias=b, out=out))
     fl = 2.0 * M * N * K
-    print("%-26s M=%6d N=%4d K=%4d  library %6.1f us (%5.1f TF/s)  bf16x3 %6.1f (%5.1f)  f16x2 %6.1f (%5.1f)" % (
-        what, M, N, K, t_lib, fl / t_lib * 1e-6, t3, fl / t3 * 1e-6, t2, fl / t2 * 1e-6))
+    panel = ""
+    if g3.panel_supported(N, K):
+        pf = g3.split_frags_f16x2(w, False)
+        tp = timed(lambda: g3.gemm_f16x2_panel(a, pf, N, g3.EPI_BIAS, bias=b, out=out))
+        panel = "  panel %6.1f (%5.1f; %.2f of the bytes at 4.95 TB/s)" % (tp, fl / tp * 1e-6, (4.0 * M * (N + K)) / 4.95e12 / (tp * 1e-6))
+    print("%-26s M=%6d N=%4d K=%4d  library %6.1f us (%5.1f TF/s)  bf16x3 %6.1f (%5.1f)  f16x2 %6.1f (%5.1f)%s" % (
+        what, M, N, K, t_lib, fl / t_lib * 1e-6, t3, fl / t3 * 1e-6, t2, fl / t2 * 1e-6, panel))

@@ -72,8 +72,9 @@ def test_full_size_transformer_matches_reference(monkeypatch, frozen, arith):
     real_gemm = gemm_bf16x3.gemm
     split_gemms = []
     monkeypatch.setattr(gemm_bf16x3, "gemm", lambda *a, **k: (split_gemms.append(1), real_gemm(*a, **k))[1])
-    real_gemm2 = gemm_bf16x3.gemm_f16x2     # (the two-plane f16 form of the same products, under "f16x2")
+    real_gemm2, real_gemm3 = gemm_bf16x3.gemm_f16x2, gemm_bf16x3.gemm_f16x2_panel     # (the two-plane f16 forms of the same products, under "f16x2")
     monkeypatch.setattr(gemm_bf16x3, "gemm_f16x2", lambda *a, **k: (split_gemms.append(1), real_gemm2(*a, **k))[1])
+    monkeypatch.setattr(gemm_bf16x3, "gemm_f16x2_panel", lambda *a, **k: (split_gemms.append(1), real_gemm3(*a, **k))[1])
     real_ffn, fused_ffns = ffn_f16x2.run, []
     monkeypatch.setattr(ffn_f16x2, "run", lambda *a, **k: (fused_ffns.append(1), real_ffn(*a, **k))[1])
 

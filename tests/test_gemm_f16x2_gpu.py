@@ -106,3 +106,67 @@ def test_cached_helpers_take_the_two_plane_form_under_f16x2_and_follow_the_weigh
     assert {k: sw.buf.data_ptr() for k, sw in owner.__dict__["_bf16x3_split"].items()} == ptrs      # in place
     y2 = g3.linear(owner, "w", x, owner.weight, owner.bias.detach())
     assert float((y2.double() - (x.double() @ owner.weight.double().t() + owner.bias.detach().double())).abs().max()) <= 1e-5
+
+
+# ---- the panel kernel (csrc/gemm_f16x2_panel.hip): K = 256 / 384, a block = 32 rows and all of K ------------------------------------
+
+def test_panel_exact_on_small_integers_and_the_added_operand():
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, N, K in ((1, 32, 256), (130, 96, 256), (257, 384, 256), (200, 256, 384)):
+        a = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+        a2 = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+        w = torch.randint(-8, 9, (N, K), device="cuda", generator=g).float() + torch.arange(N, device="cuda")[:, None] % 3
+        bias = torch.randint(-4, 5, (N,), device="cuda", generator=g).float()
+        fr = g3.split_frags_f16x2(w, False)
+        assert torch.equal(g3.gemm_f16x2_panel(a, fr, N, g3.EPI_BIAS, bias=bias), a @ w.t() + bias), (M, N, K)
+        assert torch.equal(g3.gemm_f16x2_panel(a, fr, N, g3.EPI_BIAS, bias=bias, add=a2), (a + a2) @ w.t() + bias), (M, N, K)
+        fr_t = g3.split_frags_f16x2(w.t().contiguous(), True)                       # the weight stored [K, N]
+        assert torch.equal(fr_t, fr)
+        guard = torch.full((M + 8, N), 7.0, device="cuda")
+        g3.gemm_f16x2_panel(a, fr, N, g3.EPI_BIAS, bias=bias, out=guard[:M])
+        assert bool((guard[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("M,N,K,what", [(44446, 256, 256, "value / output projection"), (44446, 384, 256, "query projection"),
+                                         (44446, 256, 384, "its input gradient")])
+def test_panel_accuracy_gate_against_fp64_beside_the_library_fp32_gemm(M, N, K, what):
+    torch.manual_seed(12)
+    a = torch.randn(M, K, device="cuda") * torch.logspace(-2, 2, M, device="cuda")[:, None]
+    w = torch.randn(N, K, device="cuda") * 0.05
+    ref, absref = _ref64(a, w), a.double().abs() @ w.double().abs().t()
+    lib = (a @ w.t()).double()
+    ours = g3.gemm_f16x2_panel(a, g3.split_frags_f16x2(w, False), N, g3.EPI_ADD, aux=torch.zeros(M, N, device="cuda")).double()
+    e_lib, e_ours = ((lib - ref).abs() / absref), ((ours - ref).abs() / absref)     # (rows of very different size: relative to sum |a b|)
+    stats = "max %.3e / %.3e, rms %.3e / %.3e of sum |a b| (ours / library)" % (
+        float(e_ours.max()), float(e_lib.max()), float(e_ours.pow(2).mean().sqrt()), float(e_lib.pow(2).mean().sqrt()))
+    print(what, stats)
+    assert float(e_ours.max()) <= float(e_lib.max()), stats
+    assert float(e_ours.pow(2).mean().sqrt()) <= float(e_lib.pow(2).mean().sqrt()), stats
+
+
+def test_panel_epilogues_and_the_cached_helpers_choose_it(monkeypatch):
+    from ziragroundingdino_amd import transformer as zt
+    torch.manual_seed(4)
+    M, N, K = 1000, 256, 256
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    bias, aux = torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+    fr = g3.split_frags_f16x2(w, False)
+    prod = a.double() @ w.double().t()
+    close = lambda x, y: float((x.double() - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max()))
+    assert close(g3.gemm_f16x2_panel(a, fr, N, g3.EPI_BIAS_RELU, bias=bias), (prod + bias.double()).relu())
+    masked = g3.gemm_f16x2_panel(a, fr, N, g3.EPI_MASK, aux=aux)
+    assert close(masked, torch.where(aux > 0, prod, torch.zeros_like(prod))) and bool((masked[aux <= 0] == 0).all())
+    acc = aux.clone()
+    g3.gemm_f16x2_panel(a, fr, N, g3.EPI_ADD, aux=acc, out=acc)
+    assert close(acc, prod + aux.double())
+    monkeypatch.setattr(zt.Switches, "gemm_arith", "f16x2")
+    calls = []
+    real = g3.gemm_f16x2_panel
+    monkeypatch.setattr(g3, "gemm_f16x2_panel", lambda *a_, **k: (calls.append(1), real(*a_, **k))[1])
+    owner = torch.nn.Linear(256, 384).cuda()
+    owner.weight.requires_grad_(False)
+    x, pos = torch.randn(300, 256, device="cuda"), torch.randn(300, 256, device="cuda")
+    y = g3.linear(owner, "w", x, owner.weight, owner.bias.detach(), add=pos)
+    assert len(calls) == 1 and close(y, (x + pos).double() @ owner.weight.double().t() + owner.bias.detach().double())
+    gx = g3.linear_input_grad(owner, "w", y, owner.weight)                  # K = 384 -> N = 256
+    assert len(calls) == 2 and float((gx.double() - y.double() @ owner.weight.double()).abs().max()) <= 1e-3

@@ -64,12 +64,13 @@ class _FrozenEncoderAttention(torch.autograd.Function):
         s2 = src.view(rows, C)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            sp = (src + pos).view(rows, C)
-            arith = g3.enabled() and g3.supported(s2, C, C) and g3.supported(sp, wq.shape[0], C)
-            if arith:   # the 256-wide products on the bf16 matrix cores in split-bf16 arithmetic (gemm_bf16x3.py)
+            arith = g3.enabled() and g3.supported(s2, C, C) and g3.supported(s2, wq.shape[0], C)
+            if arith:   # the 256-wide products on the matrix cores in split arithmetic (gemm_bf16x3.py); the position code is
+                #         added to the query inside the kernel where the panel kernel takes the product
                 value = g3.linear(ms, "value", s2, wv, bv).view(B, S, M, C // M)
-                proj = g3.linear(ms, "query", sp, wq, bq)
+                proj = g3.linear(ms, "query", s2, wq, bq, add=pos.contiguous().view(rows, C))
             else:
+                sp = (src + pos).view(rows, C)
                 value = torch.addmm(bv, s2, wv.t()).view(B, S, M, C // M)
                 proj = torch.addmm(bq, sp, wq.t())
             nproj = proj.shape[1]

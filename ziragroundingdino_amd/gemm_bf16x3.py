@@ -53,12 +53,39 @@ def split_planes_f16x2(weight: torch.Tensor, transpose: bool, out: torch.Tensor 
     return out
 
 
-class SplitWeight:
-    """The planes of one frozen weight in one orientation (bf16 x 3, or f16 x 2 with ``f16x2``), refreshed IN PLACE when the
-    parameter changes (``data_ptr`` / ``_version``): a replayed hipGraph keeps reading the same buffer."""
+def split_frags_f16x2(weight: torch.Tensor, transpose: bool, out: torch.Tensor = None) -> torch.Tensor:
+    """As ``split_planes_f16x2`` with the halves in the order the matrix core reads them ([N / 32][K / 16][plane][lane][8]):
+    the operand of ``gemm_f16x2_panel`` (N % 32 == 0, K % 16 == 0)."""
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+    rows, cols = weight.shape
+    n = 2 * rows * cols + 2 * (cols if transpose else rows)
+    if out is None:
+        out = torch.empty(n, device=weight.device, dtype=torch.int16)
+    assert out.shape == (n,) and out.dtype == torch.int16 and out.is_contiguous()
+    with torch.cuda.device(weight.device):
+        rc = _lib.load().zira_split_f16x2_frag_f32(weight.data_ptr(), rows, cols, 1 if transpose else 0, out.data_ptr(), _stream(weight))
+    if rc != 0:
+        raise RuntimeError("zira_split_f16x2_frag_f32 failed with code %d" % rc)
+    return out
 
-    def __init__(self, transpose: bool, f16x2: bool = False):
-        self.transpose, self.key, self.buf, self.f16x2 = transpose, None, None, f16x2
+
+USE_PANEL = True   # module-level switch for A/B runs (scripts/ab_step.py panel=0|1)
+
+
+def panel_supported(N: int, K: int) -> bool:
+    """The skinny products csrc/gemm_f16x2_panel.hip takes: all of K in one block's LDS panel, a few column tiles per wave --
+    the 256-wide projections of the deformable attention and their input gradients (the backbone's K = 384 linears have
+    8400 rows and up to 1536 columns: 263 blocks walking 48 column tiles each lose to the tiled kernel, 53 against 30-80 us)."""
+    return USE_PANEL and N % 32 == 0 and ((K == 256 and N <= 512) or (K == 384 and N == 256))
+
+
+class SplitWeight:
+    """The planes of one frozen weight in one orientation (bf16 x 3; with ``f16x2`` f16 x 2, in fragment order where the
+    panel kernel takes the product), refreshed IN PLACE when the parameter changes (``data_ptr`` / ``_version``): a replayed
+    hipGraph keeps reading the same buffer."""
+
+    def __init__(self, transpose: bool, f16x2: bool = False, panel: bool = False):
+        self.transpose, self.key, self.buf, self.f16x2, self.panel = transpose, None, None, f16x2, panel
         self.shape = None
 
     def planes(self, weight: torch.Tensor) -> torch.Tensor:
@@ -66,7 +93,7 @@ class SplitWeight:
         if key != self.key:
             with torch.no_grad():
                 same = self.buf is not None and self.buf.device == weight.device and self.shape == tuple(weight.shape)
-                fn = split_planes_f16x2 if self.f16x2 else split_planes
+                fn = (split_frags_f16x2 if self.panel else split_planes_f16x2) if self.f16x2 else split_planes
                 self.buf = fn(weight.detach(), self.transpose, self.buf if same else None)
                 self.shape = tuple(weight.shape)
             self.key = key
@@ -121,6 +148,29 @@ def gemm_f16x2(a: torch.Tensor, planes: torch.Tensor, N: int, epilogue: int, bia
     return out
 
 
+def gemm_f16x2_panel(a: torch.Tensor, frags: torch.Tensor, N: int, epilogue: int, bias: torch.Tensor = None, aux: torch.Tensor = None,
+                     out: torch.Tensor = None, add: torch.Tensor = None) -> torch.Tensor:
+    """epilogue((a [+ add]) [M, K] @ B^T) -> [M, N] with B = ``frags`` (split_frags_f16x2 of an [N, K] weight), K = 256 or 384."""
+    M, K = a.shape
+    assert panel_supported(N, K) and frags.shape == (2 * N * K + 2 * N,) and frags.dtype == torch.int16 and frags.device == a.device
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
+    if bias is not None:
+        assert bias.shape == (N,) and bias.is_contiguous() and bias.dtype == torch.float32
+    if aux is not None:
+        assert aux.shape == (M, N) and aux.is_contiguous() and aux.dtype == torch.float32
+    if add is not None:
+        assert add.shape == a.shape and add.is_contiguous() and add.dtype == torch.float32 and add.data_ptr() % 16 == 0
+    with torch.cuda.device(a.device):
+        rc = _lib.load().zira_gemm_f16x2_panel_f32(a.data_ptr(), 0 if add is None else add.data_ptr(), frags.data_ptr(), M, N, K, epilogue,
+                                                   0 if bias is None else bias.data_ptr(), 0 if aux is None else aux.data_ptr(),
+                                                   out.data_ptr(), _stream(a))
+    if rc != 0:
+        raise RuntimeError("zira_gemm_f16x2_panel_f32 failed with code %d (M=%d N=%d K=%d epilogue=%d)" % (rc, M, N, K, epilogue))
+    return out
+
+
 # ---- cached split weights of modules -----------------------------------------------------------------------------------------
 
 def _two_plane() -> bool:
@@ -135,35 +185,43 @@ def enabled() -> bool:
     return Switches.gemm_arith in ("bf16x3", "f16x2")
 
 
-def _cache(owner, name, transpose):
-    # (one store per owner; the two arithmetics keep their planes under different keys)
+def _cache(owner, name, transpose, N, K):
+    # (one store per owner; the arithmetics and kernels keep their planes under different keys)
     store = owner.__dict__.setdefault("_bf16x3_split", {})
     two = _two_plane()
-    sw = store.get((name, transpose, two) if two else (name, transpose))
+    panel = two and panel_supported(N, K)
+    key = (name, transpose, "panel" if panel else "tiled") if two else (name, transpose)
+    sw = store.get(key)
     if sw is None:
-        sw = store[(name, transpose, two) if two else (name, transpose)] = SplitWeight(transpose, f16x2=two)
+        sw = store[key] = SplitWeight(transpose, f16x2=two, panel=panel)
     return sw
 
 
-def _gemm_cached(sw, a, weight, N, epilogue, **kw):
+def _gemm_cached(sw, a, weight, N, epilogue, add=None, **kw):
     planes = sw.planes(weight)
+    if sw.panel:
+        return gemm_f16x2_panel(a, planes, N, epilogue, add=add, **kw)
+    if add is not None:
+        a = a + add
     if sw.f16x2:
         return gemm_f16x2(a, planes, N, epilogue, **kw)
     return gemm(a, planes, epilogue, **kw)
 
 
-def linear(owner, name, x2, weight, bias=None, out=None):
-    """``x2 @ weight.T (+ bias)`` for a frozen ``weight`` [N, K]; the planes are cached on ``owner`` under ``name``."""
-    N = weight.shape[0]
+def linear(owner, name, x2, weight, bias=None, out=None, add=None):
+    """``(x2 [+ add]) @ weight.T (+ bias)`` for a frozen ``weight`` [N, K]; the planes are cached on ``owner`` under ``name``.
+    ``add`` [M, K]: a second operand summed with ``x2`` on the way in (inside the panel kernel where it takes the product)."""
+    N, K = weight.shape
     if bias is None:
         bias = _zeros(N, x2.device)
-    return _gemm_cached(_cache(owner, name, False), x2, weight, N, EPI_BIAS, bias=bias, out=out)
+    return _gemm_cached(_cache(owner, name, False, N, K), x2, weight, N, EPI_BIAS, add=add, bias=bias, out=out)
 
 
 def linear_input_grad(owner, name, g2, weight, accumulate_into=None):
     """``g2 @ weight`` for a frozen ``weight`` [N_out, K_in] (the input gradient of ``F.linear``): [M, N_out] -> [M, K_in];
     ``accumulate_into`` [M, K_in]: added to IN PLACE (the gradient that meets this one) and returned."""
-    sw, N = _cache(owner, name, True), weight.shape[1]          # B[n][k] = weight[k][n]
+    K, N = weight.shape                                             # B[n][k] = weight[k][n]
+    sw = _cache(owner, name, True, N, K)
     if accumulate_into is not None:
         return _gemm_cached(sw, g2, weight, N, EPI_ADD, aux=accumulate_into, out=accumulate_into)
     return _gemm_cached(sw, g2, weight, N, EPI_BIAS, bias=_zeros(N, g2.device))
