@@ -162,6 +162,11 @@ __global__ __launch_bounds__(kThreads) void ffn_f16x2_kernel(const float *__rest
     const unsigned char *const lbase = smem + lane * 16;
     unsigned char *const tbase = smem + kLdsT + pair * kTBytes + lane * 16;   // + buffer * 4 * kTBytes + g * 1024
 
+#if defined(ZIRA_FFN_PRIO) && ZIRA_FFN_PRIO == 1
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(ZIRA_FFN_PRIO) && ZIRA_FFN_PRIO == 2
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     if (wave < 4) {
         // ================= first wave of the pair: D = P_step A^T, phi, the hidden tile to LDS =================================
         // lane (lm, hf) holds columns 32 p + 16 hf .. + 15, p = 0 .. 7, of row m
