@@ -14,7 +14,7 @@ for line in open(sys.argv[1]):
 fam = {}
 def family(n):
     if n.startswith("Cijk_"): return "library GEMM"
-    if "gemm_bf16x3" in n or "gemm_nn_drelu" in n or "rowgemm" in n: return "own GEMM"
+    if "gemm_bf16x3" in n or "gemm_nn_drelu" in n or "rowgemm" in n or "gemm_f16x2" in n or "ffn_f16x2" in n: return "own GEMM"
     if "msda_" in n: return "MSDA"
     if re.search(r"direct_copy|copyBuffer|CatArray|fillBuffer|FillFunctor", n): return "ATen copy / fill / cat"
     if re.search(r"elementwise|vectorized_|reduce_kernel|layer_norm|softmax|GroupNorm|group_norm|index|gather|scatter|sort|topk|multi_tensor", n): return "ATen elementwise / norm / reduce"

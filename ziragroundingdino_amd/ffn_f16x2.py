@@ -84,7 +84,11 @@ def workspace(device, stream: int, M: int, d_ffn: int) -> torch.Tensor:
     ws = _WORKSPACES.get(key)
     if ws is None:
         n = _lib.load().zira_ffn_f16x2_workspace_bytes(M, d_ffn)
-        ws = _WORKSPACES[key] = torch.zeros(max(n, 16), device=device, dtype=torch.uint8)
+        # (zeroed by a fill KERNEL, not torch.zeros: that may be a memset node when this first call happens inside a graph
+        #  capture, and hipMemsetAsync nodes are replayed out of order on ROCm 7.2 -- scripts/repro_memset_graph.py;
+        #  only the tickets at the front need the zeros: at most 256 row blocks of the last round, 256 bytes each)
+        ws = _WORKSPACES[key] = torch.empty(max(n, 16), device=device, dtype=torch.uint8)
+        ws[:min(ws.numel(), 256 * 256)].view(torch.int32).fill_(0)
     return ws
 
 
