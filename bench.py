@@ -916,6 +916,10 @@ def main():
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world, "transformer_graph": bool(args.transformer_graph),
                 "launch_mode": reported_mode, "launch_mode_default": primary_mode,
+                "graphed_pieces": (lambda G: {"encoder_layers": bool(G.graph_encoder), "decoder": bool(G.graph_decoder),
+                                              "fusion_blocks": bool(G.graph_fusion), "query_selection": bool(G.graph_selection),
+                                              "front_end": True})(__import__("ziragroundingdino_amd.graphs", fromlist=["GraphedTransformer"]).GraphedTransformer)
+                if args.transformer_graph else {},
                 "frontend_prefetch": bool(args.prefetch), "collectives_forced": bool(dist_on and world == 1),
                 "text_tokens": 2 + 2 * args.categories, "distinct_minibatches": len(batches),
                 "launch_modes": {k: {"images_per_s": images / v, "ms_per_step": v / args.steps * 1e3,

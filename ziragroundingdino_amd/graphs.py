@@ -208,8 +208,11 @@ class GraphedTransformer:
     # 36.6-36.7 against 39.6-39.9 ms per step launched eagerly.  The six encoder pieces are ~120 launches for ~4 ms of GPU time
     # each -- the host stays ahead of them on any machine -- and run 0.5 ms per step FASTER launched eagerly (36.57 / 36.75
     # against 37.13 / 37.27 ms with them graphed; both eager 36.99 / 36.74: scripts/ab_step.py graph_encoder=0|1
-    # graph_decoder=0|1, alternating processes on one box).  graph_encoder = True remains supported and tested.
-    graph_encoder = False
+    # graph_decoder=0|1, alternating processes on one box).  ROUND 6: with the fused f16x2 FFN and the panel GEMMs an encoder
+    # piece is ~1.0 / 1.5 ms of GPU time forward / backward instead of ~4, and the host no longer stays ahead of the eager
+    # launches on every box: 26.0-32.9 ms per step launched eagerly (noisy) against 25.3-25.6 replayed on a box with a busy host,
+    # equal on others -- the encoder pieces replay from graphs again by default (graph_encoder = False remains supported).
+    graph_encoder = True
     graph_decoder = True
     graph_fusion = False     # True: each fusion block replays from its own graph pair as well (300-step soak passes; SLOWER: 37.2-37.4 against 36.5-36.7 ms per step)
     graph_selection = False  # two-stage query selection runs eagerly with torch.topk -- the indices the eager path and the
