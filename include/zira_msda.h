@@ -462,6 +462,22 @@ int zira_ffn_f16x2_pack_f32(const float *p, long long p_row_stride, long long p_
 int zira_ffn_f16x2_f32(const float *A, const void *packed, int M, int F, int backward, const float *q_bias, const float *aux,
                        void *mask, float *out, void *workspace, void *stream);
 
+/* ---- The THIN products of the fusion block's image side, batched over the images, in fp32 accuracy on the f16 matrix cores
+ * (csrc/thin_f16x2.hip; the re-bracketed BiMultiHeadAttention.forward of models/GroundingDINO/fuse_modules.py:170-248 and
+ * its autograd: one side of every product is the text side's H * T):
+ *     C[b] [M, N] = A[b] [M, K] Wn[b]^T  (+ A2[b] [M, K] Wn2[b]^T)  (+ bias[b] [N])  (+ res[b] [M, N])
+ * K <= 128 or K == 256, N <= 2048, K % 4 == 0, N % 4 == 0; all tensors dense, 16-byte aligned.  The small operand changes with
+ * every step; it is split per call:
+ *   zira_thin_f16x2_frag_bytes(N, K): bytes of ONE batch element's fragments (0: unsupported K).
+ *   zira_thin_f16x2_split_f32: w [batch][N][K] (w_is_kn = 0) or [batch][K][N] (w_is_kn = 1) -> frags [batch][frag_bytes].
+ *   zira_thin_f16x2_f32: a2 / frags2 (both or neither; K <= 128): a second source whose product is added -- a contraction over
+ *     the concatenated index with each source scaled on its own; bias [batch][N] or NULL; res [batch][M][N] or NULL (may be c).
+ * Return 0, a hipError_t, or -1 for unsupported arguments.  Device pointers; enqueue only. */
+size_t zira_thin_f16x2_frag_bytes(int N, int K);
+int zira_thin_f16x2_split_f32(const float *w, int batch, int N, int K, int w_is_kn, void *frags, void *stream);
+int zira_thin_f16x2_f32(const float *a, const void *frags, const float *a2, const void *frags2, int batch, int M, int N, int K,
+                        const float *bias, const float *res, float *c, void *stream);
+
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):
  *   pos [rows, C] (x, y[, w, h]), C = 2 or 4;  dim_t [T] = temperature^(2 (i // 2) / T);  scale = 2 pi;

@@ -42,6 +42,9 @@ for kv in sys.argv[1:]:
     elif k == "panel":
         from ziragroundingdino_amd import gemm_bf16x3 as _g3
         _g3.USE_PANEL = bool(int(v))
+    elif k == "thin":
+        from ziragroundingdino_amd import dense as _dense
+        _dense.USE_THIN = bool(int(v))
     elif k == "prefetch_after_encoder":
         ZiraTrainer.prefetch_after_encoder = bool(int(v))
     elif k == "prefetch_at_start":   # (hangs with gemm_arith=f32: two streams of Stream-K library GEMMs, scripts/repro_streamk_two_streams.py)

@@ -9,13 +9,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ziragroundingdino_amd.config import zira_swint_config  # noqa: E402
 from ziragroundingdino_amd.groundingdino import build_model  # noqa: E402
-from ziragroundingdino_amd.train import synthetic_batch  # noqa: E402
+from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()
 model.use_frontend_graphs = False
+ZiraTrainer(model)        # freezes what the task freezes (the frozen linears pick their arithmetic by requires_grad)
 data = synthetic_batch(2, 800, 1333, device=dev)
 which = os.environ.get("PART", "both")
 if os.environ.get("GEMM_ARITH"):      # f32 | bf16x3

@@ -32,5 +32,5 @@ for name in want:
     sel = sorted([r for r in rows if r.key == name], key=lambda r: -r.self_device_time_total)
     tot = sum(r.self_device_time_total for r in sel)
     print("== %s: %.2f ms device, %d calls" % (name, tot / 1e3, sum(r.count for r in sel)))
-    for r in sel[:8]:
+    for r in sel[:int(os.environ.get("TOP", "8"))]:
         print("   %8.1f us x%-4d %s" % (r.self_device_time_total, r.count, str(r.input_shapes)[:150]))

@@ -118,6 +118,85 @@ def xty(X, Y, x_transposed=False):
     return torch.bmm(X if x_transposed else X.transpose(1, 2), Y)
 
 
+# ---- thin products of the fusion block's image side (csrc/thin_f16x2.hip) ----------------------
+USE_THIN = True          # developer switch (scripts/ab_step.py thin=0): the library's bmm / the row GEMM instead
+THIN_MIN_ROWS = 2048
+
+
+def thin_supported(A, N, K, res=None):
+    """A [B, M, K] fp32 on the GPU against a [K, N] matrix per image: K <= 128 or K == 256 (the panel of 32 rows and all of K
+    fits LDS four times per CU), both multiples of 4."""
+    from . import gemm_bf16x3 as g3
+    return (USE_THIN and g3.enabled() and A.is_cuda and A.dtype == torch.float32 and A.dim() == 3 and A.shape[1] >= THIN_MIN_ROWS
+            and A.shape[0] <= 64 and K % 4 == 0 and N % 4 == 0 and (K <= 128 or K == 256) and N <= 2048
+            and (res is None or res.dtype == torch.float32) and not torch.is_autocast_enabled("cuda"))
+
+
+def _thin_frags(lib, W, w_is_kn, B, N, K, stream):
+    W = W.contiguous()
+    assert W.shape == ((B, K, N) if w_is_kn else (B, N, K)) and W.dtype == torch.float32
+    fb = lib.zira_thin_f16x2_frag_bytes(N, K)
+    frags = torch.empty(B * fb, dtype=torch.uint8, device=W.device)
+    rc = lib.zira_thin_f16x2_split_f32(W.data_ptr(), B, N, K, int(bool(w_is_kn)), frags.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError("zira_thin_f16x2_split_f32 failed with code %d" % rc)
+    return frags
+
+
+def thin_bmm(A, W, w_is_kn, A2=None, W2=None, bias=None, res=None, out=None):
+    """A [B, M, K] @ W (+ A2 @ W2) (+ bias [B, N]) (+ res [B, M, N]) -> [B, M, N], no autograd; W [B, K, N] (``w_is_kn``) or
+    [B, N, K] (then it is W^T that multiplies).  Call only when ``thin_supported``."""
+    from . import _lib
+
+    lib = _lib.load()
+    A = A.contiguous()
+    B, M, K = A.shape
+    N = W.shape[2] if w_is_kn else W.shape[1]
+    with torch.cuda.device(A.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        f1 = _thin_frags(lib, W, w_is_kn, B, N, K, stream)
+        f2 = None
+        if A2 is not None:
+            A2 = A2.contiguous()
+            assert A2.shape == A.shape and A2.dtype == torch.float32
+            f2 = _thin_frags(lib, W2, w_is_kn, B, N, K, stream)
+        if bias is not None:
+            bias = bias.contiguous()
+            assert bias.shape == (B, N) and bias.dtype == torch.float32
+        if res is not None:
+            res = res.contiguous()
+            assert res.shape == (B, M, N)
+        if out is None:
+            out = torch.empty((B, M, N), dtype=torch.float32, device=A.device)
+        else:
+            assert out.shape == (B, M, N) and out.is_contiguous() and out.dtype == torch.float32
+        rc = lib.zira_thin_f16x2_f32(A.data_ptr(), f1.data_ptr(), A2.data_ptr() if A2 is not None else None,
+                                     f2.data_ptr() if f2 is not None else None, B, M, N, K,
+                                     bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None,
+                                     out.data_ptr(), stream)
+    if rc != 0:
+        raise RuntimeError("zira_thin_f16x2_f32 failed with code %d" % rc)
+    thin_bmm.calls += 1
+    return out
+
+
+thin_bmm.calls = 0
+
+
+def _bmm_nn(A, W):
+    """A [B, M, K] @ W [B, K, N]"""
+    if thin_supported(A, W.shape[2], W.shape[1]):
+        return thin_bmm(A, W, True)
+    return torch.bmm(A, W)
+
+
+def _bmm_nt(A, W):
+    """A [B, M, K] @ W [B, N, K]^T"""
+    if thin_supported(A, W.shape[1], W.shape[2]):
+        return thin_bmm(A, W, False)
+    return torch.bmm(A, W.transpose(1, 2))
+
+
 class _TallReduce(torch.autograd.Function):
     """P [B, a, N] @ V [B, N, b] -> [B, a, b]  (the forward itself is the tall reduction)."""
 
@@ -147,7 +226,9 @@ class _WideMatmul(torch.autograd.Function):
         ctx.save_for_backward(L, R)
         ctx.has_bias = bias is not None
         if bias is None:
-            return torch.bmm(L, R)
+            return _bmm_nn(L, R)
+        if bias.dim() == 1 and thin_supported(L, R.shape[2], R.shape[1]):
+            return thin_bmm(L, R, True, bias=bias.view(1, -1).expand(L.shape[0], -1))
         if L.is_cuda and L.dim() == 3 and L.shape[0] <= 4 and bias.dim() == 1:
             # baddbmm first broadcasts the bias into the [B, N, m] result (a 45 MB copy at the encoder's size) and then reads
             # it back as the GEMM's addend; per image the bias rides in the GEMM epilogue instead
@@ -162,7 +243,7 @@ class _WideMatmul(torch.autograd.Function):
     def backward(ctx, g):
         L, R = ctx.saved_tensors
         g = g.to(L.dtype).contiguous()
-        gL = torch.bmm(g, R.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gL = _bmm_nt(g, R) if ctx.needs_input_grad[0] else None
         gR = xty(L, g) if ctx.needs_input_grad[1] else None
         gb = g.sum((0, 1)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gL, gR, gb
@@ -196,9 +277,12 @@ class _WideMatmulResidual(torch.autograd.Function):
         Rs = (R * sc).contiguous()                                    # [B, k, m]
         bs = (bias.view(1, -1) * sc.reshape(-1, sc.shape[-1])).expand(B, -1).contiguous()   # [B, m]
         L, res = L.contiguous(), res.contiguous()
-        out = torch.empty_like(res)
-        for i in range(B):
-            rowgemm(L[i], Rs[i], w_is_nk=False, bias=bs[i], res=res[i], out=out[i])
+        if thin_supported(L, Rs.shape[2], Rs.shape[1], res):
+            out = thin_bmm(L, Rs, True, bias=bs, res=res)
+        else:
+            out = torch.empty_like(res)
+            for i in range(B):
+                rowgemm(L[i], Rs[i], w_is_nk=False, bias=bs[i], res=res[i], out=out[i])
         ctx.save_for_backward(L, Rs, sc)
         return out
 
@@ -207,7 +291,7 @@ class _WideMatmulResidual(torch.autograd.Function):
     def backward(ctx, g):
         L, Rs, sc = ctx.saved_tensors
         g = g.contiguous()
-        gL = torch.bmm(g, Rs.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gL = _bmm_nt(g, Rs) if ctx.needs_input_grad[0] else None
         gR = xty(L, g) * sc if ctx.needs_input_grad[1] else None
         gb = (g * sc).sum((0, 1)) if ctx.needs_input_grad[2] else None
         return gL, gR, gb, (g if ctx.needs_input_grad[3] else None), None
@@ -221,7 +305,7 @@ def wide_matmul_residual_supported(L, R, bias, res, scale) -> bool:
         return False
     if scale.requires_grad or L.shape[0] > 4 or res.shape != (L.shape[0], L.shape[1], R.shape[2]):
         return False
-    return rg.supported(L.shape[1], R.shape[2], L.shape[2])
+    return thin_supported(L, R.shape[2], R.shape[1], res) or rg.supported(L.shape[1], R.shape[2], L.shape[2])
 
 
 def wide_matmul_residual(L, R, bias, res, scale):
@@ -243,8 +327,8 @@ class _TallReduceNT(torch.autograd.Function):
     def backward(ctx, g):
         E, V = ctx.saved_tensors
         g = g.to(E.dtype)
-        gE = torch.bmm(V, g.transpose(1, 2)) if ctx.needs_input_grad[0] else None
-        gV = torch.bmm(E, g) if ctx.needs_input_grad[1] else None
+        gE = _bmm_nt(V, g) if ctx.needs_input_grad[0] else None
+        gV = _bmm_nn(E, g) if ctx.needs_input_grad[1] else None
         return gE, gV
 
 
