@@ -424,6 +424,13 @@ int zira_gemm_bf16x3_f32(const float *A, const void *b_planes, int M, int N, int
 int zira_split_f16x2_f32(const float *w, int rows, int cols, int transpose, void *planes, void *stream);
 int zira_gemm_f16x2_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
                         const float *aux, float *C, void *stream);
+/* ... with the epilogues of the frozen backbone's blocks (reference models/GroundingDINO/backbone/swin_transformer.py:40-62,
+ * :237-262) and N % 32 == 0 (N = 96, 192, 288, 576 of Swin-T's first stages):
+ *   4: C = gelu(A B^T + bias), the exact (erf) form, the arithmetic of ATen's kernel;
+ *   5: C = aux + row_scale[m / rows_per_scale] * (A B^T + bias): the block's residual with its per-image stochastic-depth
+ *      factor (row_scale NULL: 1).  Epilogues 0-3 as above (row_scale must be NULL). */
+int zira_gemm_f16x2_ex_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
+                           const float *aux, const float *row_scale, int rows_per_scale, float *C, void *stream);
 
 /* ---- The skinny ones among them (K = 256 or 384, N % 32 == 0: the 256-wide projections of the deformable attention and their
  * input gradients), bound by memory: a block takes 32 rows and ALL of K -- one burst of loads, one barrier, no K loop -- and the

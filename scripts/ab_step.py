@@ -42,6 +42,11 @@ for kv in sys.argv[1:]:
     elif k == "panel":
         from ziragroundingdino_amd import gemm_bf16x3 as _g3
         _g3.USE_PANEL = bool(int(v))
+    elif k == "fused_image_side":
+        zt.BiAttentionBlock.fused_image_side = bool(int(v))
+    elif k == "swin_epilogues":
+        from ziragroundingdino_amd import backbone as _bb
+        _bb.FUSED_EPILOGUES = bool(int(v))
     elif k == "thin":
         from ziragroundingdino_amd import dense as _dense
         _dense.USE_THIN = bool(int(v))

@@ -170,3 +170,74 @@ def test_panel_epilogues_and_the_cached_helpers_choose_it(monkeypatch):
     assert len(calls) == 1 and close(y, (x + pos).double() @ owner.weight.double().t() + owner.bias.detach().double())
     gx = g3.linear_input_grad(owner, "w", y, owner.weight)                  # K = 384 -> N = 256
     assert len(calls) == 2 and float((gx.double() - y.double() @ owner.weight.double()).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1000, 288, 96), (259, 192, 768), (130, 576, 192), (8400, 1152, 384)])
+def test_widths_that_are_multiples_of_32_only(M, N, K):
+    """Swin-T's 96 / 192 / 288 / 576-wide linears: the last column tile is partly outside the matrix."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+    w = torch.randint(-8, 9, (N, K), device="cuda", generator=g).float() + torch.arange(N, device="cuda")[:, None] % 3
+    bias = torch.randint(-4, 5, (N,), device="cuda", generator=g).float()
+    buf = torch.full((M * N + 4096,), float("nan"), device="cuda")
+    out = buf[: M * N].view(M, N)
+    got = g3.gemm_f16x2(a, g3.split_planes_f16x2(w, False), N, g3.EPI_BIAS, bias=bias, out=out)
+    assert torch.equal(got, a @ w.t() + bias) and bool(torch.isnan(buf[M * N:]).all())
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(4000, 384, 96, 2000), (1000, 96, 384, 250), (777, 192, 192, 777), (9000, 1536, 384, 4500)])
+def test_gelu_and_scaled_residual_epilogues(M, N, K, rows):
+    """The backbone's block epilogues (reference swin_transformer.py:40-62, :237-262): exact GELU of (product + bias) -- the same
+    bits as ATen's GELU of this kernel's own bias epilogue -- and residual + scale[image] * (product + bias) beside addcmul."""
+    torch.manual_seed(12)
+    a, w, bias = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.1, torch.randn(N, device="cuda")
+    planes = g3.split_planes_f16x2(w, False)
+    lin = g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS, bias=bias)
+    assert float((lin.double() - (a.double() @ w.double().t() + bias.double())).abs().max()) < 2e-5
+    assert torch.equal(g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS_GELU, bias=bias), torch.nn.functional.gelu(lin))
+    res = torch.randn(M, N, device="cuda")
+    scale = torch.tensor([0.0, 1.25, 1.0, 2.5], device="cuda")[: (M + rows - 1) // rows].contiguous()
+    got = g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS_RES, bias=bias, aux=res, row_scale=scale, rows_per_scale=rows)
+    want = torch.addcmul(res, lin, scale.repeat_interleave(rows)[:M, None])
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    assert torch.equal(got[:rows], res[:rows])                                  # a dropped branch leaves the residual untouched
+    plain = g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS_RES, bias=bias, aux=res)     # no scale: residual + product
+    assert torch.equal(plain, res + lin)
+    acc = res.clone()
+    g3.gemm_f16x2(a, planes, N, g3.EPI_BIAS_RES, bias=bias, aux=acc, out=acc)    # in place over the residual
+    assert torch.equal(acc, plain)
+
+
+def test_swin_block_with_fused_epilogues_beside_the_composition():
+    """One frozen Swin-T stage-1 block pair at 8k+ tokens: GELU and both residuals inside the GEMMs against GEMM + ATen ops
+    (same products: only the residual's multiply-add may round differently), in training mode (stochastic depth drawn by the
+    caller) and in eval mode."""
+    from ziragroundingdino_amd import backbone as bb
+    from ziragroundingdino_amd import transformer as zt
+    assert zt.Switches.gemm_arith == "f16x2"
+    torch.manual_seed(13)
+    blocks = torch.nn.ModuleList([bb.SwinTransformerBlock(96, 3, 7, 0, 4.0, 0.1), bb.SwinTransformerBlock(96, 3, 7, 3, 4.0, 0.1)]).cuda()
+    for p in blocks.parameters():
+        p.requires_grad_(False)
+    B, H, W = 2, 70, 63
+    x = torch.randn(B, H * W, 96, device="cuda")
+    dp = torch.tensor([[[1.0, 0.0], [1.25, 1.25]], [[1.25, 1.25], [0.0, 1.25]]], device="cuda").view(2, 2, B, 1, 1)
+
+    def run(fused, train):
+        bb.FUSED_EPILOGUES = fused
+        blocks.train(train)
+        try:
+            with torch.no_grad():
+                y = x
+                for i, blk in enumerate(blocks):
+                    y = blk(y, H, W, None, dp[i] if train else None)
+            return y
+        finally:
+            bb.FUSED_EPILOGUES = True
+
+    for train in (True, False):
+        before = g3.CALLS["gemm_f16x2"]
+        got = run(True, train)
+        assert g3.CALLS["gemm_f16x2"] - before == 8           # qkv, proj, fc1, fc2 of both blocks: the widths 288 and 96 included
+        want = run(False, train)
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), train

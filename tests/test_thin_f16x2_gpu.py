@@ -152,3 +152,48 @@ def test_autograd_wrappers_beside_the_library_formulation():
         eo, el = float((o - r).abs().max()) / s, float((l - r).abs().max()) / s
         print("%-4s max error / scale: thin %.3e, library %.3e" % (name, eo, el))
         assert eo <= max(1.5 * el, 2e-6), name
+
+
+@pytest.mark.parametrize("N,T,masked", [(22223, 16, False), (22223, 32, True), (2500, 7, True)])
+def test_fused_image_side_node_beside_the_four_ops_it_holds(N, T, masked):
+    """dense._FusionImageSide against wide_matmul -> bi_softmax -> tall_reduce_nt / wide_matmul_residual on the same inputs: the
+    forward launches the same kernels (bit-equal); the gradients differ only in the order in which the three contributions to
+    g_vn are added (one pass instead of two accumulations)."""
+    torch.manual_seed(7)
+    B, C, H = 2, 256, 4
+    n = H * T
+    vn = torch.randn(B, N, C, device="cuda")
+    a, c = torch.randn(B, C, n, device="cuda") * 0.05, torch.randn(B, n, device="cuda") * 0.1
+    z = torch.randn(B, n, C, device="cuda") * 0.05
+    bias, scale = torch.randn(C, device="cuda"), torch.rand(B, 1, C, device="cuda") * 1e-2
+    ml = mv = None
+    if masked:
+        ml = torch.zeros(B, T, dtype=torch.bool, device="cuda"); ml[1, T - 2:] = True
+        mv = torch.zeros(B, N, dtype=torch.bool, device="cuda"); mv[0, N - 100:] = True
+    g_out, g_t, g_cs = torch.randn(B, N, C, device="cuda"), torch.randn(B, n, C, device="cuda") * 1e-3, torch.randn(B, n, device="cuda") * 1e-3
+    assert dense.fusion_image_side_supported(vn, a, z, bias, scale, H, T, False)
+
+    def run(fused):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (vn, a, c, z)]
+        v_, a_, c_, z_ = leaves
+        if fused:
+            out, t, colsum = dense.fusion_image_side(v_, a_, c_, z_, bias, scale, ml, mv, H, T)
+        else:
+            xm = dense.wide_matmul(v_, a_)
+            pv, e, colsum = dense.bi_softmax(xm, c_, ml, mv, H, T)
+            t = dense.tall_reduce_nt(e, v_)
+            out = dense.wide_matmul_residual(pv, z_, bias, v_, scale)
+        # (e and colsum must be used as e / colsum: the text output divides)
+        ((out * g_out).sum() + ((t / colsum[..., None]) * g_t).sum()).backward()
+        return [out.detach(), t.detach(), colsum.detach()] + [x.grad for x in leaves]
+
+    before = dense.thin_bmm.calls
+    got = run(True)
+    assert dense.thin_bmm.calls - before == 5           # scores, output; g_pv, g_e, and g_vn in one pass
+    want = run(False)
+    for name, g, w in zip(("out", "t", "colsum", "g_vn", "g_a", "g_c", "g_z"), got, want):
+        if name in ("out", "t", "colsum"):
+            assert torch.equal(g, w), name
+        else:
+            s = float(w.abs().max())
+            assert float((g - w).abs().max()) <= 2e-6 * s, (name, float((g - w).abs().max()) / s)

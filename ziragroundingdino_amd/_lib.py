@@ -23,7 +23,7 @@ SYMBOLS = (
     "zira_cat_logits_fwd_f32", "zira_cat_logits_bwd_f32", "zira_window_attn_f32", "zira_window_attn_bf16",
     "zira_sine_embed_f32", "zira_attn_fwd_f32", "zira_attn_bwd_f32", "zira_attn_bwd_ld_f32", "zira_attn_bwd_scratch_floats", "zira_msda_sampling_fwd_f32", "zira_msda_sampling_bwd_f32", "zira_gemm_drelu_f32",
     "zira_rowgemm_f32", "zira_box_refine_fwd_f32", "zira_box_refine_bwd_f32", "zira_decoder_prep_f32",
-    "zira_split_bf16x3_f32", "zira_gemm_bf16x3_f32", "zira_split_f16x2_f32", "zira_gemm_f16x2_f32", "zira_split_f16x2_frag_f32", "zira_gemm_f16x2_panel_f32",
+    "zira_split_bf16x3_f32", "zira_gemm_bf16x3_f32", "zira_split_f16x2_f32", "zira_gemm_f16x2_f32", "zira_gemm_f16x2_ex_f32", "zira_split_f16x2_frag_f32", "zira_gemm_f16x2_panel_f32",
     "zira_ffn_f16x2_pack_bytes", "zira_ffn_f16x2_workspace_bytes", "zira_ffn_f16x2_pack_f32", "zira_ffn_f16x2_f32",
     "zira_thin_f16x2_frag_bytes", "zira_thin_f16x2_split_f32", "zira_thin_f16x2_f32",
     "zira_stacked_losses_scratch_bytes", "zira_stacked_losses_fwd_f32", "zira_stacked_losses_bwd_f32",
@@ -191,6 +191,8 @@ def load():
     lib.zira_split_f16x2_f32.restype = i
     lib.zira_gemm_f16x2_f32.argtypes = [vp, vp, i, i, i, i, vp, vp, vp, vp]
     lib.zira_gemm_f16x2_f32.restype = i
+    lib.zira_gemm_f16x2_ex_f32.argtypes = [vp, vp, i, i, i, i, vp, vp, vp, i, vp, vp]
+    lib.zira_gemm_f16x2_ex_f32.restype = i
     lib.zira_split_f16x2_frag_f32.argtypes = [vp, i, i, i, vp, vp]
     lib.zira_split_f16x2_frag_f32.restype = i
     lib.zira_gemm_f16x2_panel_f32.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, vp]

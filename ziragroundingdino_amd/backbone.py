@@ -29,19 +29,48 @@ SWIN_VARIANTS = {  # reference swin_transformer.py:772-788
 }
 
 
-def _frozen_linear(owner, name, lin, x):
-    """``lin(x)`` for a frozen Linear of the backbone: under ``transformer.Switches.gemm_arith = "bf16x3"`` the fp32-accurate
-    split-bf16 product on the bf16 matrix cores (gemm_bf16x3.py; the weight's planes are cached on ``owner`` and follow the
-    parameter in place), where the shapes fit the kernel (N a multiple of 128, K of 32) and it wins (1.08-2.7 x at 8400+ rows);
-    else the library."""
+FUSED_EPILOGUES = True    # developer switch (scripts/ab_step.py swin_epilogues=0): GELU and the residuals as kernels of their own
+MIN_ROWS = 8192           # (at the last stage's 2100 rows the library's kernels are 1.2-1.8 x faster, scripts/gemm_bf16x3_swin.py)
+
+
+def _frozen_ok(lin, x):
     from . import gemm_bf16x3 as g3
-    if (g3.enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and lin.bias is not None
-            and not lin.weight.requires_grad and not torch.is_autocast_enabled("cuda")):
+    return (g3.enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and lin.bias is not None
+            and not lin.weight.requires_grad and not torch.is_autocast_enabled("cuda"))
+
+
+def _frozen_linear(owner, name, lin, x, epilogue=None, residual=None, scale=None):
+    """``lin(x)`` for a frozen Linear of the backbone: under ``transformer.Switches.gemm_arith`` = "bf16x3" / "f16x2" the
+    fp32-accurate split product on the matrix cores (gemm_bf16x3.py; the weight's planes are cached on ``owner`` and follow the
+    parameter in place) from 8192 rows, else the library.
+
+    With "f16x2" the tiled kernel also takes the widths that are multiples of 32 only (Swin-T's 96, 192, 288, 576) and what
+    follows the product in a block: ``epilogue="gelu"`` (the MLP's activation) or ``residual`` [.., N] (+ ``scale`` [B, 1, 1],
+    the stochastic-depth factor per image): ``residual + scale * lin(x)`` -- one launch instead of GEMM + GELU / GEMM + addcmul,
+    and no round trip of the 4x-wide hidden activation.  Returns None when an epilogue was asked for and the fused kernel does
+    not take the call (the caller composes it from ATen ops then)."""
+    from . import gemm_bf16x3 as g3
+    fused = epilogue is not None or residual is not None
+    if _frozen_ok(lin, x):
         x2 = x.reshape(-1, x.shape[-1])
-        # (from 8192 rows: at the last stage's 2100 rows the library's kernels are 1.2-1.8 x faster, scripts/gemm_bf16x3_swin.py)
-        if x2.shape[0] >= 8192 and g3.supported(x2.contiguous(), lin.weight.shape[0], lin.weight.shape[1]):
-            return g3.linear(owner, name, x2.contiguous(), lin.weight, lin.bias).view(*x.shape[:-1], -1)
-    return lin(x)
+        N, K = lin.weight.shape
+        if x2.shape[0] >= MIN_ROWS:
+            if fused:
+                if FUSED_EPILOGUES and g3.supported_f16x2(x2.contiguous(), N, K):
+                    if residual is None:
+                        out = g3.linear_tiled_f16x2(owner, name, x2.contiguous(), lin.weight, lin.bias, g3.EPI_BIAS_GELU)
+                    else:
+                        r2 = residual.reshape(-1, N).contiguous()
+                        rs = None if scale is None else scale.reshape(-1).contiguous()
+                        out = g3.linear_tiled_f16x2(owner, name, x2.contiguous(), lin.weight, lin.bias, g3.EPI_BIAS_RES, residual=r2,
+                                                    row_scale=rs, rows_per_scale=0 if rs is None else x2.shape[0] // rs.numel())
+                    return out.view(*x.shape[:-1], -1)
+                return None
+            if g3.supported(x2.contiguous(), N, K):
+                return g3.linear(owner, name, x2.contiguous(), lin.weight, lin.bias).view(*x.shape[:-1], -1)
+            if g3.supported_f16x2(x2.contiguous(), N, K):
+                return g3.linear_tiled_f16x2(owner, name, x2.contiguous(), lin.weight, lin.bias).view(*x.shape[:-1], -1)
+    return None if fused else lin(x)
 
 
 class Mlp(nn.Module):
@@ -51,8 +80,18 @@ class Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = nn.Linear(hidden_features, in_features)
 
-    def forward(self, x):
-        return _frozen_linear(self, "fc2", self.fc2, self.act(_frozen_linear(self, "fc1", self.fc1, x)))
+    def forward(self, x, residual=None, scale=None):
+        """fc2(gelu(fc1(x))); with ``residual``: residual + scale * that (``scale`` [B, 1, 1] or None), the block's second half."""
+        h = _frozen_linear(self, "fc1", self.fc1, x, epilogue="gelu")
+        if h is None:
+            h = self.act(_frozen_linear(self, "fc1", self.fc1, x))
+        if residual is None:
+            return _frozen_linear(self, "fc2", self.fc2, h)
+        out = _frozen_linear(self, "fc2", self.fc2, h, residual=residual, scale=scale)
+        if out is None:
+            y = _frozen_linear(self, "fc2", self.fc2, h)
+            out = residual + y if scale is None else torch.addcmul(residual, y, scale)
+        return out
 
 
 def window_partition(x, ws):
@@ -96,7 +135,7 @@ class WindowAttention(nn.Module):
             self._bias_t_key = key
         return self._bias_t
 
-    def forward_native(self, xn, H, W, shift):
+    def forward_native(self, xn, H, W, shift, residual=None, scale=None):
         """``proj(window attention(qkv(xn)))`` for the normalised token map ``xn [B, H*W, C]`` through the C ABI
         (csrc/winattn.hip): pad, shift, window partition / reverse and crop are index arithmetic inside the kernel.
         Forward only (the backbone is frozen)."""
@@ -119,7 +158,13 @@ class WindowAttention(nn.Module):
                     torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("%s failed with code %d" % (name, rc))
-        return _frozen_linear(self, "proj", self.proj, out)
+        if residual is None:
+            return _frozen_linear(self, "proj", self.proj, out)
+        y = _frozen_linear(self, "proj", self.proj, out, residual=residual, scale=scale)   # the block's first residual in the epilogue
+        if y is None:
+            y = _frozen_linear(self, "proj", self.proj, out)
+            y = residual + y if scale is None else torch.addcmul(residual, y, scale)
+        return y
 
     def forward(self, x, mask=None):
         Bw, N, C = x.shape
@@ -171,6 +216,10 @@ class SwinTransformerBlock(nn.Module):
         shortcut = x
         dp0, dp1 = (dp[0], dp[1]) if dp is not None else (None, None)
         if self._native_ok(x, C):
+            plain = isinstance(self.drop_path, nn.Identity) or not self.training
+            if dp0 is not None or plain:      # (a scale drawn by the caller, or none to draw: the residuals ride in the GEMMs)
+                x = self.attn.forward_native(self.norm1(x), H, W, self.shift_size, residual=shortcut, scale=dp0)
+                return self.mlp(self.norm2(x), residual=x, scale=dp1)
             x = self._residual(shortcut, self.attn.forward_native(self.norm1(x), H, W, self.shift_size), dp0)
             return self._residual(x, self.mlp(self.norm2(x)), dp1)
         x = self.norm1(x).view(B, H, W, C)

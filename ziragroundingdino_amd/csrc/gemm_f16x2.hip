@@ -15,7 +15,11 @@
 // Kernel: a block = BM x 128 tile of C (BM = 128 or 192), 256 threads = 2 x 2 waves of (BM / 2) x 64; K in steps of 32 through
 // ONE LDS stage per operand and plane (rows padded to 80 bytes), the next step's global loads in flight during the MFMAs, two
 // blocks per CU.  The matrix core computes C^T tiles (its A operand is the weight fragment): a lane holds four consecutive
-// columns of one row of C per four accumulator registers.  Epilogues: + bias, + bias and ReLU, mask by (aux > 0), + aux.
+// columns of one row of C per four accumulator registers.  Epilogues: + bias, + bias and ReLU, mask by (aux > 0), + aux, + bias
+// and exact GELU (the backbone's MLP, reference models/GroundingDINO/backbone/swin_transformer.py:40-62), and
+// aux + row_scale[m / rows_per_scale] * (product + bias): a Swin block's residual with its stochastic-depth factor per image
+// (swin_transformer.py:237-262).  N is a multiple of 32: the last column tile may be partly outside (its weight rows repeat
+// the last one, nothing of theirs is stored).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,7 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBN = 128, kBK = 32, kThreads = 256;
 constexpr int kRow = 80;   // bytes of an LDS row: 32 f16 + 16 bytes of padding
 
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_ADD = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_ADD = 3, EPI_BIAS_GELU = 4, EPI_BIAS_RES = 5 };
 
 __device__ __forceinline__ unsigned pk_f16(float a, float b)
 {
@@ -70,15 +74,19 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &p1, uint2 &p2)
 // The epilogue: accumulator register 4 g + i of block (ni, mi) is C[m][n], m = row (lane & 31) of the block, n = 8 g + 4 (lane >> 5) + i
 template <int MI, int NI, int EPI>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][MI], const float *__restrict__ winv, const float *__restrict__ bias,
-                                           const float *aux, float *C, int M, int N, int mbase, int nbase, int lane)
+                                           const float *aux, const float *__restrict__ rscale, int rows_per_scale, float *C, int M, int N,
+                                           int mbase, int nbase, int lane)
 {
     const int lm = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = mbase + mi * 32 + lm;
         if (m >= M) continue;
+        float rs = 1.f;
+        if (EPI == EPI_BIAS_RES && rscale) rs = rscale[m / rows_per_scale];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni) {
+            if (nbase + ni * 32 >= N) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nbase + ni * 32 + 8 * g + 4 * lh;
@@ -86,11 +94,21 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][MI], const fl
                 const float4 wi = *reinterpret_cast<const float4 *>(winv + n);
                 float4 o = make_float4(c[4 * g] * wi.x, c[4 * g + 1] * wi.y, c[4 * g + 2] * wi.z, c[4 * g + 3] * wi.w);
                 const size_t at = (size_t)m * N + n;
-                if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
                     const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
                     o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
                     if (EPI == EPI_BIAS_RELU) {
                         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                    }
+                    if (EPI == EPI_BIAS_GELU) {   // 0.5 x (1 + erf(x / sqrt 2)), the arithmetic of ATen's GELU kernel
+                        o.x = 0.5f * o.x * (1.f + erff(o.x * 0.70710678118654752440f));
+                        o.y = 0.5f * o.y * (1.f + erff(o.y * 0.70710678118654752440f));
+                        o.z = 0.5f * o.z * (1.f + erff(o.z * 0.70710678118654752440f));
+                        o.w = 0.5f * o.w * (1.f + erff(o.w * 0.70710678118654752440f));
+                    }
+                    if (EPI == EPI_BIAS_RES) {
+                        const float4 h = *reinterpret_cast<const float4 *>(aux + at);
+                        o.x = fmaf(o.x, rs, h.x); o.y = fmaf(o.y, rs, h.y); o.z = fmaf(o.z, rs, h.z); o.w = fmaf(o.w, rs, h.w);
                     }
                 } else {
                     const float4 h = *reinterpret_cast<const float4 *>(aux + at);
@@ -103,14 +121,15 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][MI], const fl
                 }
                 *reinterpret_cast<float4 *>(C + at) = o;
             }
+        }
     }
 }
 
 template <int BM, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__restrict__ A, const unsigned short *__restrict__ Bp,
                                                                 const float *__restrict__ winv, const float *__restrict__ bias,
-                                                                const float *aux, float *C, int M, int N, int K, int row_tiles,
-                                                                int col_tiles, int rt_per_xcd)
+                                                                const float *aux, const float *__restrict__ rscale, int rows_per_scale,
+                                                                float *C, int M, int N, int K, int row_tiles, int col_tiles, int rt_per_xcd)
 {
     constexpr int WM = BM / 2, MI = WM / 32, NI = 2;   // a wave: WM x 64 of C = MI x NI blocks of 32 x 32
     constexpr int AJ = BM / 32;                        // float4 loads of A per thread and K step
@@ -139,8 +158,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__
         r = r < M ? r : M - 1;                         // (rows past the end: any finite data, their results are not stored)
         ag[j] = A + (size_t)r * K + a_chunk * 4;
     }
-    const unsigned short *bg = Bp + (size_t)(n0 + b_row) * K + b_chunk * 8;
-    const size_t bplane = (size_t)N * K, bj = (size_t)64 * K;
+    // (weight rows past N -- the last column tile of an N that is not a multiple of 128 -- repeat row N - 1)
+    const unsigned short *bg = Bp + (size_t)(n0 + b_row < N ? n0 + b_row : N - 1) * K + b_chunk * 8;
+    const size_t bplane = (size_t)N * K;
+    const size_t bj = (size_t)((n0 + b_row + 64 < N ? n0 + b_row + 64 : N - 1) - (n0 + b_row < N ? n0 + b_row : N - 1)) * K;
 
     float4 ra[AJ];
     uint4 rb00, rb01, rb10, rb11;
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__
     }
 
 #undef ZIRA_GLOAD
-    store_tile<MI, NI, EPI>(acc, winv, bias, aux, C, M, N, m0 + wm * WM, n0 + wn * 64, lane);
+    store_tile<MI, NI, EPI>(acc, winv, bias, aux, rscale, rows_per_scale, C, M, N, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
 // W [rows][cols] fp32 -> planes [2][N][K] f16 of W[n][k] * scale[n] and 1 / scale [N], with B[n][k] = W[n][k] (transpose = 0:
@@ -268,10 +289,10 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restric
 }
 
 template <int BM, int EPI>
-int launch(const float *a, const unsigned short *bp, const float *winv, const float *bias, const float *aux, float *c, int M, int N, int K,
-           hipStream_t st)
+int launch(const float *a, const unsigned short *bp, const float *winv, const float *bias, const float *aux, const float *rscale, int rps,
+           float *c, int M, int N, int K, hipStream_t st)
 {
-    const int rt = (M + BM - 1) / BM, ct = N / kBN, per = (rt + 7) / 8;
+    const int rt = (M + BM - 1) / BM, ct = (N + kBN - 1) / kBN, per = (rt + 7) / 8;
     static bool attr_set = false;
     const size_t lds = (size_t)2 * (BM + kBN) * kRow + (size_t)BM * sizeof(float);
     if (!attr_set) {
@@ -280,19 +301,22 @@ int launch(const float *a, const unsigned short *bp, const float *winv, const fl
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, EPI>), dim3(8 * per * ct), dim3(kThreads), lds, st, a, bp, winv, bias, aux, c, M, N, K, rt, ct, per);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, EPI>), dim3(8 * per * ct), dim3(kThreads), lds, st, a, bp, winv, bias, aux, rscale, rps, c, M, N, K, rt, ct,
+                       per);
     return (int)hipGetLastError();
 }
 
 template <int BM>
-int launch_epi(int epi, const float *a, const unsigned short *bp, const float *winv, const float *bias, const float *aux, float *c, int M,
-               int N, int K, hipStream_t st)
+int launch_epi(int epi, const float *a, const unsigned short *bp, const float *winv, const float *bias, const float *aux, const float *rscale,
+               int rps, float *c, int M, int N, int K, hipStream_t st)
 {
     switch (epi) {
-    case EPI_BIAS: return launch<BM, EPI_BIAS>(a, bp, winv, bias, aux, c, M, N, K, st);
-    case EPI_BIAS_RELU: return launch<BM, EPI_BIAS_RELU>(a, bp, winv, bias, aux, c, M, N, K, st);
-    case EPI_MASK: return launch<BM, EPI_MASK>(a, bp, winv, bias, aux, c, M, N, K, st);
-    case EPI_ADD: return launch<BM, EPI_ADD>(a, bp, winv, bias, aux, c, M, N, K, st);
+    case EPI_BIAS: return launch<BM, EPI_BIAS>(a, bp, winv, bias, aux, rscale, rps, c, M, N, K, st);
+    case EPI_BIAS_RELU: return launch<BM, EPI_BIAS_RELU>(a, bp, winv, bias, aux, rscale, rps, c, M, N, K, st);
+    case EPI_MASK: return launch<BM, EPI_MASK>(a, bp, winv, bias, aux, rscale, rps, c, M, N, K, st);
+    case EPI_ADD: return launch<BM, EPI_ADD>(a, bp, winv, bias, aux, rscale, rps, c, M, N, K, st);
+    case EPI_BIAS_GELU: return launch<BM, EPI_BIAS_GELU>(a, bp, winv, bias, aux, rscale, rps, c, M, N, K, st);
+    case EPI_BIAS_RES: return launch<BM, EPI_BIAS_RES>(a, bp, winv, bias, aux, rscale, rps, c, M, N, K, st);
     }
     return -1;
 }
@@ -311,12 +335,15 @@ extern "C" int zira_split_f16x2_f32(const float *w, int rows, int cols, int tran
     return (int)hipGetLastError();
 }
 
-extern "C" int zira_gemm_f16x2_f32(const float *a, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
-                                   const float *aux, float *c, void *stream_)
+extern "C" int zira_gemm_f16x2_ex_f32(const float *a, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
+                                      const float *aux, const float *row_scale, int rows_per_scale, float *c, void *stream_)
 {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!a || !b_planes || !c || M <= 0 || N <= 0 || K <= 0 || N % kBN || K % kBK) return -1;
-    if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) ? !bias : !aux) return -1;
+    if (!a || !b_planes || !c || M <= 0 || N <= 0 || K <= 0 || N % 32 || K % kBK) return -1;
+    const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_RES;
+    const bool needs_aux = epilogue == EPI_MASK || epilogue == EPI_ADD || epilogue == EPI_BIAS_RES;
+    if ((needs_bias && !bias) || (needs_aux && !aux)) return -1;
+    if (row_scale && (epilogue != EPI_BIAS_RES || rows_per_scale <= 0)) return -1;
     if (((uintptr_t)a | (uintptr_t)b_planes | (uintptr_t)c | (uintptr_t)bias | (uintptr_t)aux) & 15) return -1;
     if ((unsigned long long)M * N >= (1ull << 40)) return -1;
     const unsigned short *bp = reinterpret_cast<const unsigned short *>(b_planes);
@@ -324,11 +351,18 @@ extern "C" int zira_gemm_f16x2_f32(const float *a, const void *b_planes, int M, 
     // tile height: the one that wastes fewer of the chip's 512 block slots in its last round
     auto waste = [&](int bm) {
         const long long slots = 512;
-        const long long tiles = (long long)((M + bm - 1) / bm) * (N / kBN), rounds = (tiles + slots - 1) / slots;
+        const long long tiles = (long long)((M + bm - 1) / bm) * ((N + kBN - 1) / kBN), rounds = (tiles + slots - 1) / slots;
         return (double)(rounds * slots - tiles) / (double)(rounds * slots);
     };
     static const int force_bm = [] { const char *e = getenv("ZIRA_G2_BM"); return e ? atoi(e) : 0; }();   // developer override
     if (force_bm == 192 || (force_bm != 128 && waste(192) + ZIRA_G2_BM192_MARGIN < waste(128)))
-        return launch_epi<192>(epilogue, a, bp, winv, bias, aux, c, M, N, K, stream);
-    return launch_epi<128>(epilogue, a, bp, winv, bias, aux, c, M, N, K, stream);
+        return launch_epi<192>(epilogue, a, bp, winv, bias, aux, row_scale, rows_per_scale, c, M, N, K, stream);
+    return launch_epi<128>(epilogue, a, bp, winv, bias, aux, row_scale, rows_per_scale, c, M, N, K, stream);
+}
+
+extern "C" int zira_gemm_f16x2_f32(const float *a, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
+                                   const float *aux, float *c, void *stream_)
+{
+    if (epilogue < EPI_BIAS || epilogue > EPI_ADD) return -1;
+    return zira_gemm_f16x2_ex_f32(a, b_planes, M, N, K, epilogue, bias, aux, nullptr, 0, c, stream_);
 }

@@ -143,9 +143,9 @@ def _thin_frags(lib, W, w_is_kn, B, N, K, stream):
     return frags
 
 
-def thin_bmm(A, W, w_is_kn, A2=None, W2=None, bias=None, res=None, out=None):
+def thin_bmm(A, W, w_is_kn, A2=None, W2=None, bias=None, res=None, out=None, w2_is_kn=None):
     """A [B, M, K] @ W (+ A2 @ W2) (+ bias [B, N]) (+ res [B, M, N]) -> [B, M, N], no autograd; W [B, K, N] (``w_is_kn``) or
-    [B, N, K] (then it is W^T that multiplies).  Call only when ``thin_supported``."""
+    [B, N, K] (then it is W^T that multiplies); ``w2_is_kn`` for W2 (default: as W).  Call only when ``thin_supported``."""
     from . import _lib
 
     lib = _lib.load()
@@ -159,7 +159,7 @@ def thin_bmm(A, W, w_is_kn, A2=None, W2=None, bias=None, res=None, out=None):
         if A2 is not None:
             A2 = A2.contiguous()
             assert A2.shape == A.shape and A2.dtype == torch.float32
-            f2 = _thin_frags(lib, W2, w_is_kn, B, N, K, stream)
+            f2 = _thin_frags(lib, W2, w_is_kn if w2_is_kn is None else w2_is_kn, B, N, K, stream)
         if bias is not None:
             bias = bias.contiguous()
             assert bias.shape == (B, N) and bias.dtype == torch.float32
@@ -353,31 +353,57 @@ def bi_softmax_supported(xm, H, T, dropout_active):
             and not torch.is_autocast_enabled())
 
 
+def _bis_fwd(xm, c, ml, mv, B, N, H, T, stable, clo, chi):
+    """csrc/bisoftmax.hip forward on contiguous fp32 tensors (masks as uint8 or None) -> pv, e, colsum, colmax, gmax"""
+    from . import _lib
+
+    lib = _lib.load()
+    pv, e = torch.empty_like(xm), torch.empty_like(xm)
+    colsum, colmax = torch.empty_like(c), torch.empty_like(c)
+    gmax = torch.empty(1, dtype=torch.float32, device=xm.device)
+    ws = _bis_workspace(lib, xm.device, B, N, H, T)
+    rc = lib.zira_bisoftmax_fwd_f32(
+        xm.data_ptr(), c.data_ptr(), ml.data_ptr() if ml is not None else None,
+        mv.data_ptr() if mv is not None else None, B, N, H, T, int(stable), int(clo), int(chi),
+        pv.data_ptr(), e.data_ptr(), colsum.data_ptr(), colmax.data_ptr(), gmax.data_ptr(), ws.data_ptr(),
+        torch.cuda.current_stream(xm.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError("zira_bisoftmax_fwd_f32 failed with HIP error %d" % rc)
+    return pv, e, colsum, colmax, gmax
+
+
+def _bis_bwd(xm, c, ml, pv, e, colmax, gmax, g_pv, g_e, g_cs, B, N, H, T, stable, clo, chi):
+    """csrc/bisoftmax.hip backward -> g_xm, g_c (None gradients count as zeros)"""
+    from . import _lib
+
+    lib = _lib.load()
+    g_pv = torch.zeros_like(xm) if g_pv is None else g_pv.contiguous()
+    g_e = torch.zeros_like(xm) if g_e is None else g_e.contiguous()
+    g_cs = torch.zeros_like(c) if g_cs is None else g_cs.contiguous()
+    g_xm, g_c = torch.empty_like(xm), torch.empty_like(c)
+    ws = _bis_workspace(lib, xm.device, B, N, H, T)
+    rc = lib.zira_bisoftmax_bwd_f32(
+        xm.data_ptr(), c.data_ptr(), ml.data_ptr() if ml is not None else None, B, N, H, T,
+        stable, clo, chi, pv.data_ptr(), e.data_ptr(), colmax.data_ptr(), gmax.data_ptr(), g_pv.data_ptr(),
+        g_e.data_ptr(), g_cs.data_ptr(), g_xm.data_ptr(), g_c.data_ptr(), ws.data_ptr(),
+        torch.cuda.current_stream(xm.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError("zira_bisoftmax_bwd_f32 failed with HIP error %d" % rc)
+    return g_xm, g_c
+
+
 class _BiSoftmax(torch.autograd.Function):
     """(xm [B,N,H*T], c [B,H*T], mask_l [B,T] | None, mask_v [B,N] | None) -> (pv, e, colsum); see
     include/zira_msda.h.  The gradient is only valid when e and colsum are used as e / colsum."""
 
     @staticmethod
     def forward(ctx, xm, c, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi):
-        from . import _lib
-
-        lib = _lib.load()
         xm, c = xm.contiguous(), c.contiguous()
         B, N, HT = xm.shape
         assert HT == H * T and c.shape == (B, HT)
         ml = mask_l.contiguous().view(torch.uint8) if mask_l is not None else None
         mv = mask_v.contiguous().view(torch.uint8) if mask_v is not None else None
-        pv, e = torch.empty_like(xm), torch.empty_like(xm)
-        colsum, colmax = torch.empty_like(c), torch.empty_like(c)
-        gmax = torch.empty(1, dtype=torch.float32, device=xm.device)
-        ws = _bis_workspace(lib, xm.device, B, N, H, T)
-        rc = lib.zira_bisoftmax_fwd_f32(
-            xm.data_ptr(), c.data_ptr(), ml.data_ptr() if ml is not None else None,
-            mv.data_ptr() if mv is not None else None, B, N, H, T, int(stable), int(clamp_lo), int(clamp_hi),
-            pv.data_ptr(), e.data_ptr(), colsum.data_ptr(), colmax.data_ptr(), gmax.data_ptr(), ws.data_ptr(),
-            torch.cuda.current_stream(xm.device).cuda_stream)
-        if rc != 0:
-            raise RuntimeError("zira_bisoftmax_fwd_f32 failed with HIP error %d" % rc)
+        pv, e, colsum, colmax, gmax = _bis_fwd(xm, c, ml, mv, B, N, H, T, stable, clamp_lo, clamp_hi)
         ctx.save_for_backward(xm, c, pv, e, colmax, gmax)
         ctx.ml = ml
         ctx.dims = (B, N, H, T, int(stable), int(clamp_lo), int(clamp_hi))
@@ -385,28 +411,74 @@ class _BiSoftmax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_pv, g_e, g_cs):
-        from . import _lib
-
-        lib = _lib.load()
         xm, c, pv, e, colmax, gmax = ctx.saved_tensors
-        B, N, H, T, stable, clo, chi = ctx.dims
-        g_pv = torch.zeros_like(xm) if g_pv is None else g_pv.contiguous()
-        g_e = torch.zeros_like(xm) if g_e is None else g_e.contiguous()
-        g_cs = torch.zeros_like(c) if g_cs is None else g_cs.contiguous()
-        g_xm, g_c = torch.empty_like(xm), torch.empty_like(c)
-        ws = _bis_workspace(lib, xm.device, B, N, H, T)
-        rc = lib.zira_bisoftmax_bwd_f32(
-            xm.data_ptr(), c.data_ptr(), ctx.ml.data_ptr() if ctx.ml is not None else None, B, N, H, T,
-            stable, clo, chi, pv.data_ptr(), e.data_ptr(), colmax.data_ptr(), gmax.data_ptr(), g_pv.data_ptr(),
-            g_e.data_ptr(), g_cs.data_ptr(), g_xm.data_ptr(), g_c.data_ptr(), ws.data_ptr(),
-            torch.cuda.current_stream(xm.device).cuda_stream)
-        if rc != 0:
-            raise RuntimeError("zira_bisoftmax_bwd_f32 failed with HIP error %d" % rc)
+        g_xm, g_c = _bis_bwd(xm, c, ctx.ml, pv, e, colmax, gmax, g_pv, g_e, g_cs, *ctx.dims)
         return g_xm, g_c, None, None, None, None, None, None, None
 
 
 def bi_softmax(xm, c, mask_l, mask_v, H, T, stable=True, clamp_lo=True, clamp_hi=True):
     return _BiSoftmax.apply(xm, c, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi)
+
+
+# ---- the image side of a fusion block as ONE autograd node ---------------------------------------
+class _FusionImageSide(torch.autograd.Function):
+    """(vn [B,N,C], a [B,C,HT], c [B,HT], z [B,HT,C], bias [C], scale [C] | [B,1,C]) ->
+           out = vn + scale * (pv z + bias)   [B,N,C],    t = e^T vn   [B,HT,C],    colsum [B,HT]
+    with (pv, e, colsum) = bi_softmax(vn a, c): ``wide_matmul`` -> ``bi_softmax`` -> ``tall_reduce_nt`` /
+    ``wide_matmul_residual`` of BiAttentionBlock._forward_native_text (reference fuse_modules.py:170-248, :292-303 re-bracketed)
+    held by one node, so that the backward forms the gradient of ``vn`` -- which autograd would add up from three nodes with
+    two 45 MB passes -- in ONE pass over it:  g_vn = g_out + e g_t + g_xm a^T  is a contraction over the concatenated index
+    with a residual (csrc/thin_f16x2.hip, two sources).  ``scale`` is constant (frozen layer scale x stochastic depth): it is
+    folded into z and the bias as in ``_WideMatmulResidual``."""
+
+    @staticmethod
+    def forward(ctx, vn, a, c, z, bias, scale, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi):
+        vn, a, c = vn.contiguous(), a.contiguous(), c.contiguous()
+        B, N, C = vn.shape
+        ml = mask_l.contiguous().view(torch.uint8) if mask_l is not None else None
+        mv = mask_v.contiguous().view(torch.uint8) if mask_v is not None else None
+        sc = scale if scale.dim() == 3 else scale.view(1, 1, -1)
+        Rs = (z * sc).contiguous()                                                             # [B, HT, C]
+        bs = (bias.view(1, -1) * sc.reshape(-1, sc.shape[-1])).expand(B, -1).contiguous()      # [B, C]
+        xm = thin_bmm(vn, a, True)
+        pv, e, colsum, colmax, gmax = _bis_fwd(xm, c, ml, mv, B, N, H, T, stable, clamp_lo, clamp_hi)
+        t = xty(e, vn)
+        out = thin_bmm(pv, Rs, True, bias=bs, res=vn)
+        ctx.save_for_backward(vn, a, Rs, sc, xm, c, pv, e, colmax, gmax)
+        ctx.ml = ml
+        ctx.dims = (B, N, H, T, int(stable), int(clamp_lo), int(clamp_hi))
+        return out, t, colsum
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_t, g_cs):
+        vn, a, Rs, sc, xm, c, pv, e, colmax, gmax = ctx.saved_tensors
+        B, N = ctx.dims[:2]
+        g_out = torch.zeros_like(vn) if g_out is None else g_out.contiguous()
+        g_t = torch.zeros_like(Rs) if g_t is None else g_t.contiguous()
+        g_pv = thin_bmm(g_out, Rs, False)                                  # [B, N, HT]
+        g_e = thin_bmm(vn, g_t, False)                                     # [B, N, HT]
+        g_xm, g_c = _bis_bwd(xm, c, ctx.ml, pv, e, colmax, gmax, g_pv, g_e, g_cs, *ctx.dims)
+        g_vn = thin_bmm(e, g_t, True, A2=g_xm, W2=a, w2_is_kn=False, res=g_out) if ctx.needs_input_grad[0] else None
+        g_a = xty(vn, g_xm) if ctx.needs_input_grad[1] else None           # [B, C, HT]
+        g_z = xty(pv, g_out) * sc if ctx.needs_input_grad[3] else None     # [B, HT, C]
+        g_b = (g_out * sc).sum((0, 1)) if ctx.needs_input_grad[4] else None
+        return g_vn, g_a, (g_c if ctx.needs_input_grad[2] else None), g_z, g_b, None, None, None, None, None, None, None, None
+
+
+def fusion_image_side_supported(vn, a, z, bias, scale, H, T, dropout_active) -> bool:
+    if not (vn.is_cuda and vn.dim() == 3 and a.dim() == 3 and z.dim() == 3 and bias is not None and bias.dim() == 1):
+        return False
+    if any(t.dtype != torch.float32 for t in (vn, a, z, bias, scale)) or scale.requires_grad or vn.shape[0] > 4:
+        return False
+    n, C = H * T, vn.shape[2]
+    return (n <= 128 and a.shape == (vn.shape[0], C, n) and z.shape == (vn.shape[0], n, C) and thin_supported(vn, n, C)
+            and thin_supported(vn, C, n, vn) and bi_softmax_supported(vn, H, T, dropout_active))
+
+
+def fusion_image_side(vn, a, c, z, bias, scale, mask_l, mask_v, H, T, stable=True, clamp_lo=True, clamp_hi=True):
+    """-> (vn + scale * (pv z + bias), e^T vn, colsum); call only when ``fusion_image_side_supported``."""
+    return _FusionImageSide.apply(vn, a, c, z, bias, scale, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi)
 
 
 # ---- row LayerNorm (csrc/layernorm.hip) ------------------------------------------------------

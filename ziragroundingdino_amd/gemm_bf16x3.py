@@ -15,6 +15,8 @@ import torch
 from . import _lib
 
 EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_ADD = 0, 1, 2, 3
+EPI_BIAS_GELU, EPI_BIAS_RES = 4, 5      # the tiled f16x2 kernel only (csrc/gemm_f16x2.hip)
+CALLS = {"gemm_f16x2": 0}              # launches so far (tests)
 
 
 def _stream(t):
@@ -105,6 +107,12 @@ def supported(a: torch.Tensor, N: int, K: int) -> bool:
             and N % 128 == 0 and K % 32 == 0 and a.data_ptr() % 16 == 0)
 
 
+def supported_f16x2(a: torch.Tensor, N: int, K: int) -> bool:
+    """The tiled two-plane f16 kernel alone: N a multiple of 32 (``supported`` is what all three arithmetics take)."""
+    return (_two_plane() and a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.is_contiguous() and a.shape[1] == K
+            and N % 32 == 0 and K % 32 == 0 and a.data_ptr() % 16 == 0)
+
+
 def gemm(a: torch.Tensor, planes: torch.Tensor, epilogue: int, bias: torch.Tensor = None, aux: torch.Tensor = None,
          out: torch.Tensor = None) -> torch.Tensor:
     """epilogue(a [M, K] @ B^T) -> [M, N] with B = ``planes`` [3, N, K] (split_planes).  ``out`` may be ``aux`` (EPI_ADD)."""
@@ -128,8 +136,9 @@ def gemm(a: torch.Tensor, planes: torch.Tensor, epilogue: int, bias: torch.Tenso
 
 
 def gemm_f16x2(a: torch.Tensor, planes: torch.Tensor, N: int, epilogue: int, bias: torch.Tensor = None, aux: torch.Tensor = None,
-               out: torch.Tensor = None) -> torch.Tensor:
-    """epilogue(a [M, K] @ B^T) -> [M, N] with B = ``planes`` (split_planes_f16x2 of an [N, K] weight).  ``out`` may be ``aux``."""
+               out: torch.Tensor = None, row_scale: torch.Tensor = None, rows_per_scale: int = 0) -> torch.Tensor:
+    """epilogue(a [M, K] @ B^T) -> [M, N] with B = ``planes`` (split_planes_f16x2 of an [N, K] weight).  ``out`` may be ``aux``.
+    ``row_scale`` [ceil(M / rows_per_scale)] with EPI_BIAS_RES: aux + row_scale[m // rows_per_scale] * (product + bias)."""
     M, K = a.shape
     assert planes.shape == (2 * N * K + 2 * N,) and planes.dtype == torch.int16 and planes.is_contiguous() and planes.device == a.device
     if out is None:
@@ -139,12 +148,17 @@ def gemm_f16x2(a: torch.Tensor, planes: torch.Tensor, N: int, epilogue: int, bia
         assert bias.shape == (N,) and bias.is_contiguous() and bias.dtype == torch.float32
     if aux is not None:
         assert aux.shape == (M, N) and aux.is_contiguous() and aux.dtype == torch.float32
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.is_contiguous() and rows_per_scale > 0
+        assert row_scale.numel() * rows_per_scale >= M
     with torch.cuda.device(a.device):
-        rc = _lib.load().zira_gemm_f16x2_f32(a.data_ptr(), planes.data_ptr(), M, N, K, epilogue,
-                                             0 if bias is None else bias.data_ptr(), 0 if aux is None else aux.data_ptr(),
-                                             out.data_ptr(), _stream(a))
+        rc = _lib.load().zira_gemm_f16x2_ex_f32(a.data_ptr(), planes.data_ptr(), M, N, K, epilogue,
+                                                0 if bias is None else bias.data_ptr(), 0 if aux is None else aux.data_ptr(),
+                                                0 if row_scale is None else row_scale.data_ptr(), int(rows_per_scale),
+                                                out.data_ptr(), _stream(a))
     if rc != 0:
-        raise RuntimeError("zira_gemm_f16x2_f32 failed with code %d (M=%d N=%d K=%d epilogue=%d)" % (rc, M, N, K, epilogue))
+        raise RuntimeError("zira_gemm_f16x2_ex_f32 failed with code %d (M=%d N=%d K=%d epilogue=%d)" % (rc, M, N, K, epilogue))
+    CALLS["gemm_f16x2"] += 1
     return out
 
 
@@ -215,6 +229,20 @@ def linear(owner, name, x2, weight, bias=None, out=None, add=None):
     if bias is None:
         bias = _zeros(N, x2.device)
     return _gemm_cached(_cache(owner, name, False, N, K), x2, weight, N, EPI_BIAS, add=add, bias=bias, out=out)
+
+
+def linear_tiled_f16x2(owner, name, x2, weight, bias, epilogue=EPI_BIAS, residual=None, row_scale=None, rows_per_scale=0, out=None):
+    """``epilogue(x2 @ weight.T + bias)`` through the TILED two-plane f16 kernel whatever the shape (the backbone's linears:
+    N % 32 == 0): EPI_BIAS, EPI_BIAS_GELU, or EPI_BIAS_RES with ``residual`` [M, N] and an optional ``row_scale`` (one factor
+    per ``rows_per_scale`` rows).  Planes cached on ``owner`` as in ``linear``."""
+    N, K = weight.shape
+    store = owner.__dict__.setdefault("_bf16x3_split", {})
+    key = (name, False, "tiled")
+    sw = store.get(key)
+    if sw is None:
+        sw = store[key] = SplitWeight(False, f16x2=True, panel=False)
+    return gemm_f16x2(x2, sw.planes(weight), N, epilogue, bias=bias, aux=residual, out=out, row_scale=row_scale,
+                      rows_per_scale=rows_per_scale)
 
 
 def linear_input_grad(owner, name, g2, weight, accumulate_into=None):

@@ -21,8 +21,8 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .dense import (LayerNorm, bi_softmax, bi_softmax_supported, tall_reduce, tall_reduce_nt, wide_matmul, wide_matmul_residual,
-                    wide_matmul_residual_supported)
+from .dense import (LayerNorm, bi_softmax, bi_softmax_supported, fusion_image_side, fusion_image_side_supported, tall_reduce,
+                    tall_reduce_nt, wide_matmul, wide_matmul_residual, wide_matmul_residual_supported)
 from .ms_deform_attn import MultiScaleDeformableAttention as MSDeformAttn
 from .ms_deform_attn import multi_value_projections
 from .utils import (MLP, _get_activation_fn, _get_clones, gen_encoder_output_proposals,
@@ -669,6 +669,7 @@ class BiAttentionBlock(nn.Module):
     fused_residual = True     # class-level switches for A/B runs
     residual_in_gemm = True
     native_text_side = True   # frozen composed projections: the text side as two native nodes (text_side.py)
+    fused_image_side = True   # ... and the image side as one (dense._FusionImageSide; H T <= 128)
 
     def _forward_native_text(self, v, l, attention_mask_v, attention_mask_l):
         """The fused, re-bracketed block with its text side on csrc/textside.hip: LayerNorm of the text, the composed
@@ -691,11 +692,16 @@ class BiAttentionBlock(nn.Module):
             kp = 1 - dp.drop_prob
             keep = v.new_empty((2, bsz)).bernoulli_(kp).div_(kp)      # one draw: image side, text side
         l_ln, a, c, z = text_side.text_prep(l, self.layer_norm_l, W1, b1, W1T, H, att.v_dim)
+        scale = self.gamma_v if keep is None else self.gamma_v * keep[0].view(bsz, 1, 1)
+        if self.fused_image_side and fusion_image_side_supported(v, a, z, att.out_v_proj.bias, scale, H, T, False):
+            # the four image-side ops below as one autograd node (the gradient of v in one pass, dense._FusionImageSide)
+            out_v, t, colsum = fusion_image_side(v, a, c, z, att.out_v_proj.bias, scale, attention_mask_l, attention_mask_v, H, T,
+                                                 att.stable_softmax_2d, att.clamp_min_for_underflow, att.clamp_max_for_overflow)
+            return out_v, text_side.text_out(t, colsum, l_ln, O, OT, o0, self.gamma_l, None if keep is None else keep[1], H)
         xm = wide_matmul(v, a)
         pv, e, colsum = bi_softmax(xm, c, attention_mask_l, attention_mask_v, H, T, att.stable_softmax_2d,
                                    att.clamp_min_for_underflow, att.clamp_max_for_overflow)
         out_l = text_side.text_out(tall_reduce_nt(e, v), colsum, l_ln, O, OT, o0, self.gamma_l, None if keep is None else keep[1], H)
-        scale = self.gamma_v if keep is None else self.gamma_v * keep[0].view(bsz, 1, 1)
         if wide_matmul_residual_supported(pv, z, att.out_v_proj.bias, v, scale):
             return wide_matmul_residual(pv, z, att.out_v_proj.bias, v, scale), out_l
         return torch.addcmul(v, wide_matmul(pv, z, att.out_v_proj.bias), scale), out_l
