@@ -89,9 +89,10 @@ def test_fused_bi_softmax_matches_unfused_attention(T, with_masks):
 
 @pytest.mark.parametrize("drop_path", [0.0, 0.4])
 def test_fusion_block_residual_in_gemm_matches_addcmul(drop_path):
-    """v + drop_path(gamma_v * delta_v) inside the attention's last GEMM (dense._WideMatmulResidual: layer scale folded into
-    the small operands, residual rows added by the row-GEMM epilogue) against the addcmul pass behind the GEMM: same RNG
-    draws, values and gradients to fp32 re-association."""
+    """v + drop_path(gamma_v * delta_v) inside the attention's last GEMM (dense._FusionImageSide, the node that holds the block's
+    image side since round 6 -- layer scale folded into the small operands, residual rows added by the GEMM's epilogue -- and
+    dense._WideMatmulResidual with that node switched off) against the addcmul pass behind the GEMM: same RNG draws, values and
+    gradients to fp32 re-association."""
     from ziragroundingdino_amd import transformer
     torch.manual_seed(0)
     blk = transformer.BiAttentionBlock(v_dim=256, l_dim=256, embed_dim=1024, num_heads=4, dropout=0.0, drop_path=drop_path,
@@ -105,25 +106,33 @@ def test_fusion_block_residual_in_gemm_matches_addcmul(drop_path):
     gv, gl = torch.randn_like(v), torch.randn_like(l)
     res = {}
     calls = []
-    real = dense._WideMatmulResidual.forward
+    real, real_node = dense._WideMatmulResidual.forward, dense._FusionImageSide.forward
 
     def spy(ctx, *a):
-        calls.append(1)
+        calls.append("gemm")
         return real(ctx, *a)
 
+    def spy_node(ctx, *a):
+        calls.append("node")
+        return real_node(ctx, *a)
+
     dense._WideMatmulResidual.forward = staticmethod(spy)
+    dense._FusionImageSide.forward = staticmethod(spy_node)
     try:
-        for flag in (True, False):
-            transformer.BiAttentionBlock.residual_in_gemm = flag
+        for flag in ("node", "gemm", False):
+            transformer.BiAttentionBlock.residual_in_gemm = bool(flag)
+            transformer.BiAttentionBlock.fused_image_side = flag == "node"
             torch.manual_seed(11)
             ov, ol = blk(v, l, attention_mask_v=None, attention_mask_l=mask_l)
             res[flag] = (ov.detach(), ol.detach()) + torch.autograd.grad([ov, ol], [v, l], [gv, gl])
     finally:
-        transformer.BiAttentionBlock.residual_in_gemm = True
+        transformer.BiAttentionBlock.residual_in_gemm = transformer.BiAttentionBlock.fused_image_side = True
         dense._WideMatmulResidual.forward = staticmethod(real)
-    assert len(calls) == 1                                   # the GEMM form ran, and only when switched on
-    for a, b in zip(res[True], res[False]):
-        assert _rel(a, b.double()) < 2e-6
+        dense._FusionImageSide.forward = staticmethod(real_node)
+    assert calls == ["node", "gemm"]                         # each GEMM form ran when it was switched on, and only then
+    for flag in ("node", "gemm"):
+        for a, b in zip(res[flag], res[False]):
+            assert _rel(a, b.double()) < 2e-6
 
 
 def test_composed_text_side_matches_two_step_projections():
