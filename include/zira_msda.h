@@ -469,6 +469,14 @@ int zira_ffn_f16x2_pack_f32(const float *p, long long p_row_stride, long long p_
 int zira_ffn_f16x2_f32(const float *A, const void *packed, int M, int F, int backward, const float *q_bias, const float *aux,
                        void *mask, float *out, void *workspace, void *stream);
 
+/* ---- The tall reductions again, on the bf16 matrix cores in fp32 accuracy (csrc/xty_bf16x3.hip): out[b] = P[b]^T Q[b] with
+ * P [B][N][n], Q [B][N][256] token-major, n % 4 == 0; each operand split into three bfloat16 planes, six product terms, fp32
+ * sums; partial tiles per token chunk meet in a second launch in a fixed order (results repeat bit for bit).
+ *   out [B][n][256], or with transpose != 0 [B][256][n] (= Q^T P).  workspace: zira_xty_bf16x3_workspace_floats(B, N, n) floats,
+ *   not shared by launches that may run at the same time.  Return 0, a hipError_t, or -1 for unsupported arguments. */
+size_t zira_xty_bf16x3_workspace_floats(int B, int N, int n);
+int zira_xty_bf16x3_f32(const float *P, const float *Q, int B, int N, int n, int transpose, float *out, float *workspace, void *stream);
+
 /* ---- The THIN products of the fusion block's image side, batched over the images, in fp32 accuracy on the f16 matrix cores
  * (csrc/thin_f16x2.hip; the re-bracketed BiMultiHeadAttention.forward of models/GroundingDINO/fuse_modules.py:170-248 and
  * its autograd: one side of every product is the text side's H * T):

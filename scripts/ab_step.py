@@ -50,6 +50,9 @@ for kv in sys.argv[1:]:
     elif k == "skip_text_layer":     # upper bound of what the text enhancer layers cost the step (results are wrong)
         if int(v):
             zt.TransformerEncoderLayer.forward = lambda self, src, src_mask=None, src_key_padding_mask=None, pos=None: src + 0.0 * self.norm2.weight.sum()
+    elif k == "tall":
+        from ziragroundingdino_amd import dense as _dense
+        _dense.USE_TALL_BF16X3 = bool(int(v))
     elif k == "thin":
         from ziragroundingdino_amd import dense as _dense
         _dense.USE_THIN = bool(int(v))

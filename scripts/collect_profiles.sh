@@ -9,7 +9,7 @@ out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command (fewer steps: the trace inflates host time)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-gemm-arith-mode > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-gemm-arith-mode --no-accuracy > $out/bench_under_rocprof.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, re
 out = sys.argv[1]
@@ -19,7 +19,7 @@ for f in glob.glob(out + "/bench_trace/**/*kernel_stats.csv", recursive=True):
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(out + "/bench_kernel_stats.txt", "w") as fh:
-    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-gemm-arith-mode\n")
+    fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-gemm-arith-mode --no-accuracy\n")
     fh.write("total kernel time %.1f ms over %d kernel names (3 warm-up steps, 3 timed regions of 10 steps in the configured launch mode and as many in the other one, the capture of\n"
              "the graphs -- 3 warm-up passes and one capture pass per piece -- and 1 + 4 eager steps for the MSDA event timing)\n" % (tot / 1e6, len(rows)))
     fh.write("%7s %11s %8s %12s  %s\n" % ("share", "total_ms", "calls", "avg_us", "kernel"))
@@ -28,7 +28,7 @@ with open(out + "/bench_kernel_stats.txt", "w") as fh:
         fh.write("%6.2f%% %11.3f %8s %12.2f  %s\n" % (100 * float(r["TotalDurationNs"]) / tot, float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, name))
     fh.write("\nhand-written kernels of this package (all of them, whatever their rank):\n")
     for r in rows:
-        if re.search(r"msda_|rsb_|xty_|bis_|rowgemm|box_refine|decoder_prep|gemm_nn_drelu|gemm_bf16x3|split_bf16x3|ffn_f16x2|ln_fwd_rows|ln_bwd_rows|attn_fwd|attn_bwd|window_attn|lsap|match_cost|cat_logits|sine_embed|sampling_fwd|sampling_bwd|attn_sum_parts|text_prep|text_out|text_colsum|text_ln|focal_fwd|losses_|level_counts|encoder_ref_points|encoder_proposals|box_head", r["Name"]):
+        if re.search(r"msda_|rsb_|xty_|bis_|rowgemm|box_refine|decoder_prep|gemm_nn_drelu|gemm_bf16x3|split_bf16x3|gemm_f16x2|split_f16x2|thin_f16x2|thin_split|ffn_f16x2|sine_pos|ln_fwd_rows|ln_bwd_rows|attn_fwd|attn_bwd|window_attn|lsap|match_cost|cat_logits|sine_embed|sampling_fwd|sampling_bwd|attn_sum_parts|text_prep|text_out|text_colsum|text_ln|focal_fwd|losses_|level_counts|encoder_ref_points|encoder_proposals|box_head", r["Name"]):
             name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Name"]).split("(")[0]
             fh.write("%6.2f%% %11.3f %8s %12.2f  %s\n" % (100 * float(r["TotalDurationNs"]) / tot, float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, name))
 print(open(out + "/bench_kernel_stats.txt").read()[:3000])

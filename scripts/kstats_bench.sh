@@ -25,7 +25,7 @@ with open("%s/%s_bench_kernel_stats.txt" % (out, tag), "w") as fh:
         fh.write("%6.2f%% %11.3f %8s %12.2f  %s\n" % (100 * float(r["TotalDurationNs"]) / tot, float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, name))
     fh.write("\nhand-written kernels of this package (all of them, whatever their rank):\n")
     for r in rows:
-        if re.search(r"msda_|rsb_|xty_|bis_|rowgemm|box_refine|decoder_prep|gemm_nn_drelu|gemm_bf16x3|split_bf16x3|ffn_f16x2|gemm_f16x2|ln_fwd_rows|ln_bwd_rows|attn_fwd|attn_bwd|window_attn|lsap|match_cost|cat_logits|sine_embed|sampling_fwd|sampling_bwd|attn_sum_parts|text_prep|text_out|text_colsum|text_ln|focal_fwd|losses_|level_counts|encoder_ref_points|encoder_proposals|box_head", r["Name"]):
+        if re.search(r"msda_|rsb_|xty_|bis_|rowgemm|box_refine|decoder_prep|gemm_nn_drelu|gemm_bf16x3|split_bf16x3|ffn_f16x2|gemm_f16x2|split_f16x2|thin_f16x2|thin_split|sine_pos|ln_fwd_rows|ln_bwd_rows|attn_fwd|attn_bwd|window_attn|lsap|match_cost|cat_logits|sine_embed|sampling_fwd|sampling_bwd|attn_sum_parts|text_prep|text_out|text_colsum|text_ln|focal_fwd|losses_|level_counts|encoder_ref_points|encoder_proposals|box_head", r["Name"]):
             name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Name"]).split("(")[0]
             fh.write("%6.2f%% %11.3f %8s %12.2f  %s\n" % (100 * float(r["TotalDurationNs"]) / tot, float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, name))
 PY

@@ -175,3 +175,26 @@ def test_composed_text_side_matches_two_step_projections():
     assert [t.data_ptr() for t in att._text_side[1]] == ptrs
     att.l_proj.weight.requires_grad_(True)      # a trainable Linear: the two-step form
     assert att._composed_text_side(l) is None
+
+
+@pytest.mark.parametrize("B,N,n,thin_first", [(2, 22223, 776, True), (2, 22223, 776, False), (1, 5000, 196, True), (3, 4101, 388, False),
+                                              (2, 2500, 1024, True), (2, 3333, 36, True), (1, 40, 256, False), (2, 22223, 128, True)])
+def test_tall_reduction_on_the_bf16_matrix_cores(B, N, n, thin_first):
+    """csrc/xty_bf16x3.hip (three bfloat16 planes, six product terms, fp32 sums) at COCO-length captions (776 = 4 heads x 194
+    tokens), ragged widths and row counts, both output orientations: against fp64 no worse than 1.5e-6 of the largest element
+    (the fp32 matrix-instruction kernel of csrc/xty.hip: 3e-7; torch.bmm: 3e-6), bit-stable, beside the fp32 kernel."""
+    g = torch.Generator().manual_seed(N + n)
+    X = torch.randn((B, N, n if thin_first else 256), generator=g).to(DEV)
+    Y = torch.randn((B, N, 256 if thin_first else n), generator=g).to(DEV)
+    if thin_first:
+        X = X.softmax(1) * 50.0                      # (probabilities over the tokens: a few large, most tiny)
+    want = torch.bmm(X.double().transpose(1, 2), Y.double())
+    got = dense._tall_bf16x3(X, Y)
+    assert got.shape == want.shape
+    assert _rel(got, want) < 1.5e-6
+    assert torch.equal(got, dense._tall_bf16x3(X, Y))
+    if N >= 2048:
+        fp32 = dense._xty_native(X, Y, False)
+        assert _rel(got, fp32.double()) < 2e-6
+    # the dispatcher takes it from 192 columns (under the split arithmetics)
+    assert dense._use_tall_bf16x3(X, Y, X.shape[2], Y.shape[2], N, False) == (n >= 192)

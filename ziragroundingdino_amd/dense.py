@@ -108,12 +108,49 @@ def _xty_native(X, Y, x_transposed):
     return out
 
 
+TALL_BF16X3_MIN_COLS = 192
+USE_TALL_BF16X3 = True    # developer switch (scripts/ab_step.py tall=0): csrc/xty.hip (fp32 matrix instruction) instead
+_TALL_WS = {}
+
+
+def _use_tall_bf16x3(X, Y, a, b, N, x_transposed):
+    """Both operands token-major, one of them 256 wide and the other at least TALL_BF16X3_MIN_COLS, under the split arithmetics
+    (csrc/xty_bf16x3.hip against the fp32 matrix instruction of csrc/xty.hip at 22223 tokens x 2 images: 27.8 / 28.8 us at 64
+    columns, 36.7 / 41.0 at 128, 88 / 210 at 388, 154 / 399 at 776; inside the training step the 128-column calls did not repay
+    it -- 24.10 against 24.03 ms per step -- so the narrow ones stay with csrc/xty.hip)."""
+    from . import gemm_bf16x3 as g3
+    n = b if a == 256 else a
+    return (USE_TALL_BF16X3 and not x_transposed and g3.enabled() and (a == 256 or b == 256) and a % 4 == 0 and b % 4 == 0
+            and TALL_BF16X3_MIN_COLS <= n <= 2048 and X.shape[0] <= 64 and not torch.is_autocast_enabled("cuda"))
+
+
+def _tall_bf16x3(X, Y):
+    from . import _lib
+
+    lib = _lib.load()
+    X, Y = X.contiguous(), Y.contiguous()
+    B, N, a = X.shape
+    b = Y.shape[2]
+    out = torch.empty((B, a, b), dtype=torch.float32, device=X.device)
+    thin_first = b == 256                       # P = the operand that is not (necessarily) 256 wide
+    P, Q, n = (X, Y, a) if thin_first else (Y, X, b)
+    ws = _scratch(_TALL_WS, X.device, lib.zira_xty_bf16x3_workspace_floats(B, N, n))
+    with torch.cuda.device(X.device):
+        rc = lib.zira_xty_bf16x3_f32(P.data_ptr(), Q.data_ptr(), B, N, n, 0 if thin_first else 1, out.data_ptr(), ws.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("zira_xty_bf16x3_f32 failed with code %d" % rc)
+    return out
+
+
 def xty(X, Y, x_transposed=False):
     """X^T @ Y per batch element, no autograd: X [B, N, a] (or [B, a, N] with ``x_transposed``),
     Y [B, N, b] -> [B, a, b]."""
     N, b = Y.shape[1], Y.shape[2]
     a = X.shape[1] if x_transposed else X.shape[2]
     if _use_xty(X, Y, a, b, N):
+        if _use_tall_bf16x3(X, Y, a, b, N, x_transposed):
+            return _tall_bf16x3(X, Y)
         return _xty_native(X, Y, x_transposed)
     return torch.bmm(X if x_transposed else X.transpose(1, 2), Y)
 
