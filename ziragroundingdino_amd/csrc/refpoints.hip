@@ -259,48 +259,81 @@ __global__ __launch_bounds__(256) void box_head_bwd_kernel(const float *__restri
 // column x in rows 0 .. y (cumsum), embed_x along the row; normalised: embed / (last + eps) * scale.  As ATen ops: two cumsums, the
 // normalisation, two pow / div, four sin / cos, two stacks, a cat -- ~15 launches per level, most of them passes over the level's
 // [B, H, W, 256] output.  Here: a block per (b, y) image row; same separately rounded fp32 operations, bit-identical.
+// grid (B * H, ceil(W / 64)): a block writes 64 pixels of one image row.  (Until round 6 a block took a whole row and every thread
+// walked its column's H mask bytes and its row's x + 1 alone: 64 us for the 100 x 167 level, all of it latency of one block per CU.)
 __global__ __launch_bounds__(256) void sine_pos_hw_kernel(const unsigned char *__restrict__ mask, int H, int W, int F, int normalize,
                                                           float scale, float eps, const float *__restrict__ dim_t_y,
                                                           const float *__restrict__ dim_t_x, float *__restrict__ out)
 {
 #pragma clang fp contract(off)
-    extern __shared__ float sm[];     // [W] embed_y, [W] embed_x
-    float *ey = sm, *ex = sm + W;
+    __shared__ int part_upto[4][64], part_total[4][64], wave_count[4];
+    __shared__ float ey[64], ex[64];
     __shared__ float x_last;
     const int b = blockIdx.x / H, y = blockIdx.x - b * H;
+    const int x0 = blockIdx.y * 64, x1 = x0 + 64 < W ? x0 + 64 : W;
     const unsigned char *m = mask + (size_t)b * H * W;
-    for (int x = threadIdx.x; x < W; x += 256) {
+    const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // column counts of the block's 64 columns: wave w sums rows w, w + 4, ...
+    {
+        const int x = x0 + tx;
         int upto = 0, total = 0;
-        for (int yy = 0; yy < H; ++yy) {
-            const int v = m[(size_t)yy * W + x] ? 0 : 1;
-            total += v;
-            upto += yy <= y ? v : 0;
-        }
-        int left = 0;
-        for (int xx = 0; xx <= x; ++xx) left += m[(size_t)y * W + xx] ? 0 : 1;
-        float fy = (float)upto, fx = (float)left;
-        if (normalize) fy = __fmul_rn(__fdiv_rn(fy, __fadd_rn((float)total, eps)), scale);
-        ey[x] = fy;
-        ex[x] = fx;                       // (normalised below: the row's last element first)
-        if (x == W - 1) x_last = fx;
+        if (x < x1)
+            for (int yy = wv; yy < H; yy += 4) {
+                const int v = m[(size_t)yy * W + x] ? 0 : 1;
+                total += v;
+                upto += yy <= y ? v : 0;
+            }
+        part_upto[wv][tx] = upto;
+        part_total[wv][tx] = total;
     }
+    // the row's running count of unpadded pixels up to the block's columns, and the row's total (its last element): 256 pixels per
+    // pass, a wave's 64 by ballot, the waves joined through LDS
+    int row_total = 0;
+    for (int xb = 0; xb < W; xb += 256) {
+        const int x = xb + threadIdx.x;
+        const bool v = x < W && !m[(size_t)y * W + x];
+        const unsigned long long bal = __ballot(v);
+        if (tx == 0) wave_count[wv] = __popcll(bal);
+        __syncthreads();
+        int carry = 0;
+        for (int w = 0; w < wv; ++w) carry += wave_count[w];
+        const int incl = row_total + carry + __popcll(bal & ((2ull << tx) - 1ull));   // unpadded pixels in [0, x]
+        if (x >= x0 && x < x1) ex[x - x0] = (float)incl;
+        row_total += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        __syncthreads();
+    }
+    if (threadIdx.x < 64 && x0 + (int)threadIdx.x < x1) {
+        const int upto = part_upto[0][tx] + part_upto[1][tx] + part_upto[2][tx] + part_upto[3][tx];
+        const int total = part_total[0][tx] + part_total[1][tx] + part_total[2][tx] + part_total[3][tx];
+        float fy = (float)upto;
+        if (normalize) fy = __fmul_rn(__fdiv_rn(fy, __fadd_rn((float)total, eps)), scale);
+        ey[tx] = fy;
+    }
+    if (threadIdx.x == 0) x_last = (float)row_total;     // (the running count at x = W - 1)
     __syncthreads();
     const float xl = x_last;
     const int C = 2 * F;
-    float *o = out + ((size_t)b * H + y) * W * C;
-    for (int i = threadIdx.x; i < W * C; i += 256) {
-        const int x = i / C, c = i - x * C;
-        float e, d;
+    float *o = out + (((size_t)b * H + y) * W + x0) * C;
+    // channels 2 k and 2 k + 1 share dim_t (temperature^(2 (i // 2) / F)) and so the angle: its sine and cosine in one evaluation
+    // (the same bits as sinf / cosf on their own: tests/test_geometry_gpu.py)
+    for (int i = threadIdx.x; i < (x1 - x0) * F; i += 256) {
+        const int x = i / F, c = 2 * (i - x * F);
+        float e, d, d1;
         if (c < F) {
             e = ey[x];
             d = dim_t_y[c];
+            d1 = dim_t_y[c + 1];
         } else {
             e = ex[x];
             if (normalize) e = __fmul_rn(__fdiv_rn(e, __fadd_rn(xl, eps)), scale);
             d = dim_t_x[c - F];
+            d1 = dim_t_x[c - F + 1];
         }
         const float a = __fdiv_rn(e, d);
-        o[i] = (c & 1) ? cosf(a) : sinf(a);
+        float sn, cs;
+        sincosf(a, &sn, &cs);
+        if (d1 != d) cs = cosf(__fdiv_rn(e, d1));        // (a caller's own dim_t table)
+        *reinterpret_cast<float2 *>(o + (size_t)x * C + c) = make_float2(sn, cs);
     }
 }
 
@@ -407,7 +440,7 @@ extern "C" int zira_sine_pos_hw_f32(const void *mask, int B, int H, int W, int F
                                     const float *dim_t_y, const float *dim_t_x, float *out, void *stream)
 {
     if (!mask || !dim_t_y || !dim_t_x || !out || B <= 0 || H <= 0 || W <= 0 || F <= 0 || (F & 1) || W > 8192) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sine_pos_hw_kernel, dim3((unsigned)(B * H)), dim3(256), 2 * (size_t)W * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(sine_pos_hw_kernel, dim3((unsigned)(B * H), (unsigned)((W + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const unsigned char *>(mask), H, W, F, normalize, scale, eps, dim_t_y, dim_t_x, out);
     return (int)hipGetLastError();
 }
