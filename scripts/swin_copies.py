@@ -3,11 +3,12 @@ from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, "/root/repo")
 from ziragroundingdino_amd.config import zira_swint_config
 from ziragroundingdino_amd.groundingdino import build_model
-from ziragroundingdino_amd.train import synthetic_batch
+from ziragroundingdino_amd.train import ZiraTrainer, synthetic_batch
 from ziragroundingdino_amd.utils import nested_tensor_from_tensor_list
 dev = torch.device("cuda"); torch.manual_seed(0)
 model = build_model(zira_swint_config(device="cuda")).to(dev).train()
 model.use_frontend_graphs = False
+ZiraTrainer(model)   # (freezes what the task freezes)
 data = synthetic_batch(2, 800, 1333, device=dev)
 with torch.no_grad():
     samples = nested_tensor_from_tensor_list(model.preprocess_image(data))
