@@ -420,7 +420,8 @@ int zira_gemm_bf16x3_f32(const float *A, const void *b_planes, int M, int N, int
 /* ---- The same products in two-plane f16 arithmetic (csrc/gemm_f16x2.hip): each fp32 operand, scaled by a power of two per
  * (row, 32-deep K step) of A and per row of the weight, is a1 + a2 to 2^-22 with a_i f16; three exact product terms, fp32
  * sums.  Same shapes, epilogues and return codes as zira_gemm_bf16x3_f32.
- *   zira_split_f16x2_f32: planes = 2 * N * K halves followed by N floats (1 / scale of every row): 4 N K + 4 N bytes. */
+ *   zira_split_f16x2_f32: planes = 2 * N * Kp halves (Kp = K rounded up to 32: rows padded with zeros) followed by N floats
+ *   (1 / scale of every row): 4 N Kp + 4 N bytes.  zira_gemm_f16x2_f32 / _ex_f32 take any K % 4 == 0 with such planes. */
 int zira_split_f16x2_f32(const float *w, int rows, int cols, int transpose, void *planes, void *stream);
 int zira_gemm_f16x2_f32(const float *A, const void *b_planes, int M, int N, int K, int epilogue, const float *bias,
                         const float *aux, float *C, void *stream);

@@ -241,3 +241,56 @@ def test_swin_block_with_fused_epilogues_beside_the_composition():
         assert g3.CALLS["gemm_f16x2"] - before == 8           # qkv, proj, fc1, fc2 of both blocks: the widths 288 and 96 included
         want = run(False, train)
         assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), train
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 776), (1000, 128, 36), (22223, 256, 776), (515, 96, 100)])
+def test_contraction_lengths_that_are_multiples_of_4_only(M, N, K):
+    """K = 776 (4 heads x 194 text tokens on the contraction side of the fusion block): the planes' rows are padded with zeros to
+    whole 32-deep steps, the activation's missing columns are zeros.  Exact on small integers; beside fp64 on random data."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    a = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+    w = torch.randint(-8, 9, (N, K), device="cuda", generator=g).float()
+    bias = torch.randint(-4, 5, (N,), device="cuda", generator=g).float()
+    want = (a.double() @ w.double().t()).float() + bias
+    assert torch.equal(g3.gemm_f16x2(a, g3.split_planes_f16x2(w, False), N, g3.EPI_BIAS, bias=bias), want)
+    assert torch.equal(g3.gemm_f16x2(a, g3.split_planes_f16x2(w.t().contiguous(), True), N, g3.EPI_BIAS, bias=bias), want)
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") * 0.05
+    ref = a.double() @ w.double().t()
+    ours = g3.gemm_f16x2(a, g3.split_planes_f16x2(w, False), N, g3.EPI_BIAS, bias=torch.zeros(N, device="cuda")).double()
+    lib = (a @ w.t()).double()
+    assert float((ours - ref).abs().max()) <= 1.25 * float((lib - ref).abs().max())
+
+
+def test_long_text_side_on_the_contraction_index_through_the_autograd_wrappers():
+    """dense.wide_matmul / wide_matmul_residual / tall_reduce_nt at 194 text tokens (H T = 776): the K = 776 products leave the
+    library for one tiled two-plane GEMM per image; values and gradients beside the library formulation."""
+    from ziragroundingdino_amd import dense
+    torch.manual_seed(22)
+    B, M, C, n = 2, 5003, 256, 776
+    v = torch.randn(B, M, C, device="cuda")
+    a, z = torch.randn(B, C, n, device="cuda") * 0.05, torch.randn(B, n, C, device="cuda") * 0.05
+    bias, scale = torch.randn(C, device="cuda"), torch.rand(C, device="cuda") * 1e-2
+    gout, gu = torch.randn(B, M, C, device="cuda"), torch.randn(B, n, C, device="cuda")
+
+    def run(on):
+        dense.USE_THIN = on
+        try:
+            vv, aa, zz = (t.detach().clone().requires_grad_(True) for t in (v, a, z))
+            xm = dense.wide_matmul(vv, aa)
+            e = xm.softmax(-1)
+            if dense.wide_matmul_residual_supported(e, zz, bias, vv, scale):
+                out = dense.wide_matmul_residual(e, zz, bias, vv, scale)
+            else:                                    # (what the module does then: the residual as a pass of its own)
+                out = torch.addcmul(vv, dense.wide_matmul(e, zz, bias), scale)
+            u = dense.tall_reduce_nt(e, vv)
+            ((out * gout).sum() + (u * gu).sum()).backward()
+            return [t.detach().double() for t in (xm, out, u, vv.grad, aa.grad, zz.grad)]
+        finally:
+            dense.USE_THIN = True
+
+    before = dense.wide_k_bmm.calls
+    ours = run(True)
+    assert dense.wide_k_bmm.calls - before == 3          # the image output, and the two [M, 776] x [776, 256] gradients
+    lib = run(False)
+    for name, o, l in zip(("xm", "out", "u", "g_v", "g_a", "g_z"), ours, lib):
+        assert float((o - l).abs().max()) <= 3e-6 * float(l.abs().max()), name

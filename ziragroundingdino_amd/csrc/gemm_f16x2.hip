@@ -19,7 +19,8 @@
 // and exact GELU (the backbone's MLP, reference models/GroundingDINO/backbone/swin_transformer.py:40-62), and
 // aux + row_scale[m / rows_per_scale] * (product + bias): a Swin block's residual with its stochastic-depth factor per image
 // (swin_transformer.py:237-262).  N is a multiple of 32: the last column tile may be partly outside (its weight rows repeat
-// the last one, nothing of theirs is stored).
+// the last one, nothing of theirs is stored).  K is a multiple of 4: the planes' rows are padded with zeros to whole 32-deep steps
+// and the activation's missing columns are zeros (776 = 4 heads x 194 text tokens on the contraction side of the fusion block).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -159,15 +160,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__
         ag[j] = A + (size_t)r * K + a_chunk * 4;
     }
     // (weight rows past N -- the last column tile of an N that is not a multiple of 128 -- repeat row N - 1)
-    const unsigned short *bg = Bp + (size_t)(n0 + b_row < N ? n0 + b_row : N - 1) * K + b_chunk * 8;
-    const size_t bplane = (size_t)N * K;
-    const size_t bj = (size_t)((n0 + b_row + 64 < N ? n0 + b_row + 64 : N - 1) - (n0 + b_row < N ? n0 + b_row : N - 1)) * K;
+    const int Kp = (K + kBK - 1) / kBK * kBK;          // the planes' row length: K in whole steps, zeros behind K
+    const unsigned short *bg = Bp + (size_t)(n0 + b_row < N ? n0 + b_row : N - 1) * Kp + b_chunk * 8;
+    const size_t bplane = (size_t)N * Kp;
+    const size_t bj = (size_t)((n0 + b_row + 64 < N ? n0 + b_row + 64 : N - 1) - (n0 + b_row < N ? n0 + b_row : N - 1)) * Kp;
 
     float4 ra[AJ];
     uint4 rb00, rb01, rb10, rb11;
 #define ZIRA_GLOAD(k0_)                                                                             \
     do {                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4 *>(ag[j] + (k0_)); \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                               \
+            ra[j] = (a_chunk * 4 + (k0_) < K) ? *reinterpret_cast<const float4 *>(ag[j] + (k0_)) : make_float4(0.f, 0.f, 0.f, 0.f); \
         rb00 = *reinterpret_cast<const uint4 *>(bg + (k0_));                                        \
         rb01 = *reinterpret_cast<const uint4 *>(bg + bj + (k0_));                                   \
         rb10 = *reinterpret_cast<const uint4 *>(bg + bplane + (k0_));                               \
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__
     const float *fs = sS + wm * WM + (lane & 31);
 
     ZIRA_GLOAD(0);
-    for (int k0 = 0; k0 < K; k0 += kBK) {
+    for (int k0 = 0; k0 < Kp; k0 += kBK) {
         __syncthreads();   // the previous step's fragment reads are done
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__
         *reinterpret_cast<uint4 *>(wb + kBN * kRow) = rb10;
         *reinterpret_cast<uint4 *>(wb + kBN * kRow + 64 * kRow) = rb11;
         __syncthreads();
-        if (k0 + kBK < K) ZIRA_GLOAD(k0 + kBK);
+        if (k0 + kBK < Kp) ZIRA_GLOAD(k0 + kBK);
         // Three terms per 16-deep slice, the small ones first; matrix-core A operand = weight fragment (rows n), B operand =
         // activation fragment (rows m): the accumulator block is C^T [n][m].  The six terms of a K step are summed inside the
         // matrix core FROM ZERO and the step's sum, times 1 / (the row's scale in this step), is added to the running sum by
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x2_kernel(const float *__
     store_tile<MI, NI, EPI>(acc, winv, bias, aux, rscale, rows_per_scale, C, M, N, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
-// W [rows][cols] fp32 -> planes [2][N][K] f16 of W[n][k] * scale[n] and 1 / scale [N], with B[n][k] = W[n][k] (transpose = 0:
+// W [rows][cols] fp32 -> planes [2][N][Kp] f16 (Kp = K rounded up to 32, zeros behind K) of W[n][k] * scale[n] and 1 / scale [N], with B[n][k] = W[n][k] (transpose = 0:
 // N = rows, K = cols) or W[k][n] (transpose = 1: N = cols, K = rows); one block per row n
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restrict__ w, int rows, int cols, int transpose,
                                                           unsigned short *__restrict__ planes, float *__restrict__ winv)
@@ -278,13 +281,14 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float *__restric
     float s, inv;
     pow2_scale(red[0], s, inv);
     if (threadIdx.x == 0) winv[n] = inv;
-    const size_t total = (size_t)N * K;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float v = at(k) * s;
+    const int Kp = (K + kBK - 1) / kBK * kBK;              // rows padded with zeros to whole K steps
+    const size_t total = (size_t)N * Kp;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        const float v = k < K ? at(k) * s : 0.f;
         const unsigned p1 = pk_f16(v, 0.f);
         const unsigned p2 = pk_f16(v - f16_lo(p1), 0.f);
-        planes[(size_t)n * K + k] = (unsigned short)(p1 & 0xFFFFu);
-        planes[total + (size_t)n * K + k] = (unsigned short)(p2 & 0xFFFFu);
+        planes[(size_t)n * Kp + k] = (unsigned short)(p1 & 0xFFFFu);
+        planes[total + (size_t)n * Kp + k] = (unsigned short)(p2 & 0xFFFFu);
     }
 }
 
@@ -330,7 +334,8 @@ extern "C" int zira_split_f16x2_f32(const float *w, int rows, int cols, int tran
     if (!w || !planes || rows <= 0 || cols <= 0) return -1;
     const int N = transpose ? cols : rows, K = transpose ? rows : cols;
     unsigned short *p = reinterpret_cast<unsigned short *>(planes);
-    float *winv = reinterpret_cast<float *>(p + (size_t)2 * N * K);
+    const int Kp = (K + kBK - 1) / kBK * kBK;
+    float *winv = reinterpret_cast<float *>(p + (size_t)2 * N * Kp);
     hipLaunchKernelGGL(split_f16x2_kernel, dim3(N), dim3(256), 0, stream, w, rows, cols, transpose ? 1 : 0, p, winv);
     return (int)hipGetLastError();
 }
@@ -339,7 +344,7 @@ extern "C" int zira_gemm_f16x2_ex_f32(const float *a, const void *b_planes, int 
                                       const float *aux, const float *row_scale, int rows_per_scale, float *c, void *stream_)
 {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (!a || !b_planes || !c || M <= 0 || N <= 0 || K <= 0 || N % 32 || K % kBK) return -1;
+    if (!a || !b_planes || !c || M <= 0 || N <= 0 || K <= 0 || N % 32 || K % 4) return -1;
     const bool needs_bias = epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_RES;
     const bool needs_aux = epilogue == EPI_MASK || epilogue == EPI_ADD || epilogue == EPI_BIAS_RES;
     if ((needs_bias && !bias) || (needs_aux && !aux)) return -1;
@@ -347,7 +352,7 @@ extern "C" int zira_gemm_f16x2_ex_f32(const float *a, const void *b_planes, int 
     if (((uintptr_t)a | (uintptr_t)b_planes | (uintptr_t)c | (uintptr_t)bias | (uintptr_t)aux) & 15) return -1;
     if ((unsigned long long)M * N >= (1ull << 40)) return -1;
     const unsigned short *bp = reinterpret_cast<const unsigned short *>(b_planes);
-    const float *winv = reinterpret_cast<const float *>(bp + (size_t)2 * N * K);
+    const float *winv = reinterpret_cast<const float *>(bp + (size_t)2 * N * ((K + kBK - 1) / kBK * kBK));
     // tile height: the one that wastes fewer of the chip's 512 block slots in its last round
     auto waste = [&](int bm) {
         const long long slots = 512;

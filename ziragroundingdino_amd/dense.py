@@ -220,10 +220,43 @@ def thin_bmm(A, W, w_is_kn, A2=None, W2=None, bias=None, res=None, out=None, w2_
 thin_bmm.calls = 0
 
 
+def wide_k_supported(A, N, K):
+    """The products with the LONG text side on the contraction index (K = H T > 256: COCO-length captions), one tiled two-plane
+    GEMM per image (csrc/gemm_f16x2.hip; K a multiple of 4, the small operand split per call)."""
+    from . import gemm_bf16x3 as g3
+    return (USE_THIN and g3._two_plane() and A.is_cuda and A.dtype == torch.float32 and A.dim() == 3 and A.shape[1] >= THIN_MIN_ROWS
+            and A.shape[0] <= 8 and K > 256 and K % 4 == 0 and N % 32 == 0 and not torch.is_autocast_enabled("cuda"))
+
+
+def wide_k_bmm(A, W, w_is_kn, bias=None, res=None):
+    """A [B, M, K] @ W (+ bias [B, N]) (+ res [B, M, N]), W [B, K, N] (``w_is_kn``) or [B, N, K]; call when ``wide_k_supported``."""
+    from . import gemm_bf16x3 as g3
+    A = A.contiguous()
+    B, M, K = A.shape
+    N = W.shape[2] if w_is_kn else W.shape[1]
+    out = torch.empty((B, M, N), dtype=torch.float32, device=A.device)
+    if res is not None:
+        res = res.contiguous()
+    for i in range(B):
+        planes = g3.split_planes_f16x2(W[i].contiguous(), bool(w_is_kn))
+        bi = bias[i].contiguous() if bias is not None else g3._zeros(N, A.device)
+        if res is None:
+            g3.gemm_f16x2(A[i], planes, N, g3.EPI_BIAS, bias=bi, out=out[i])
+        else:
+            g3.gemm_f16x2(A[i], planes, N, g3.EPI_BIAS_RES, bias=bi, aux=res[i], out=out[i])
+    wide_k_bmm.calls += 1
+    return out
+
+
+wide_k_bmm.calls = 0
+
+
 def _bmm_nn(A, W):
     """A [B, M, K] @ W [B, K, N]"""
     if thin_supported(A, W.shape[2], W.shape[1]):
         return thin_bmm(A, W, True)
+    if wide_k_supported(A, W.shape[2], W.shape[1]):
+        return wide_k_bmm(A, W, True)
     return torch.bmm(A, W)
 
 
@@ -231,6 +264,8 @@ def _bmm_nt(A, W):
     """A [B, M, K] @ W [B, N, K]^T"""
     if thin_supported(A, W.shape[1], W.shape[2]):
         return thin_bmm(A, W, False)
+    if wide_k_supported(A, W.shape[1], W.shape[2]):
+        return wide_k_bmm(A, W, False)
     return torch.bmm(A, W.transpose(1, 2))
 
 
@@ -266,6 +301,8 @@ class _WideMatmul(torch.autograd.Function):
             return _bmm_nn(L, R)
         if bias.dim() == 1 and thin_supported(L, R.shape[2], R.shape[1]):
             return thin_bmm(L, R, True, bias=bias.view(1, -1).expand(L.shape[0], -1))
+        if bias.dim() == 1 and wide_k_supported(L, R.shape[2], R.shape[1]):
+            return wide_k_bmm(L, R, True, bias=bias.view(1, -1).expand(L.shape[0], -1))
         if L.is_cuda and L.dim() == 3 and L.shape[0] <= 4 and bias.dim() == 1:
             # baddbmm first broadcasts the bias into the [B, N, m] result (a 45 MB copy at the encoder's size) and then reads
             # it back as the GEMM's addend; per image the bias rides in the GEMM epilogue instead
@@ -316,6 +353,8 @@ class _WideMatmulResidual(torch.autograd.Function):
         L, res = L.contiguous(), res.contiguous()
         if thin_supported(L, Rs.shape[2], Rs.shape[1], res):
             out = thin_bmm(L, Rs, True, bias=bs, res=res)
+        elif wide_k_supported(L, Rs.shape[2], Rs.shape[1]):
+            out = wide_k_bmm(L, Rs, True, bias=bs, res=res)
         else:
             out = torch.empty_like(res)
             for i in range(B):
@@ -342,7 +381,8 @@ def wide_matmul_residual_supported(L, R, bias, res, scale) -> bool:
         return False
     if scale.requires_grad or L.shape[0] > 4 or res.shape != (L.shape[0], L.shape[1], R.shape[2]):
         return False
-    return thin_supported(L, R.shape[2], R.shape[1], res) or rg.supported(L.shape[1], R.shape[2], L.shape[2])
+    return (thin_supported(L, R.shape[2], R.shape[1], res) or wide_k_supported(L, R.shape[2], R.shape[1])
+            or rg.supported(L.shape[1], R.shape[2], L.shape[2]))
 
 
 def wide_matmul_residual(L, R, bias, res, scale):

@@ -39,12 +39,18 @@ def split_planes(weight: torch.Tensor, transpose: bool, out: torch.Tensor = None
     return out
 
 
+def f16x2_plane_halves(N: int, K: int) -> int:
+    """int16 elements of split_planes_f16x2's result: two planes [N][K rounded up to 32] and N floats"""
+    return 2 * N * ((K + 31) // 32 * 32) + 2 * N
+
+
 def split_planes_f16x2(weight: torch.Tensor, transpose: bool, out: torch.Tensor = None) -> torch.Tensor:
     """weight [rows, cols] fp32 on the GPU -> flat int16 [2 N K + 2 N]: the two f16 planes [2, N, K] of the row-scaled weight,
     then 1 / scale of every row as N floats; B[n][k] = weight[n][k] (``transpose`` False) or weight[k][n] (True)."""
     assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
     rows, cols = weight.shape
-    n = 2 * rows * cols + 2 * (cols if transpose else rows)
+    N, K = (cols, rows) if transpose else (rows, cols)
+    n = f16x2_plane_halves(N, K)
     if out is None:
         out = torch.empty(n, device=weight.device, dtype=torch.int16)
     assert out.shape == (n,) and out.dtype == torch.int16 and out.is_contiguous()
@@ -140,7 +146,7 @@ def gemm_f16x2(a: torch.Tensor, planes: torch.Tensor, N: int, epilogue: int, bia
     """epilogue(a [M, K] @ B^T) -> [M, N] with B = ``planes`` (split_planes_f16x2 of an [N, K] weight).  ``out`` may be ``aux``.
     ``row_scale`` [ceil(M / rows_per_scale)] with EPI_BIAS_RES: aux + row_scale[m // rows_per_scale] * (product + bias)."""
     M, K = a.shape
-    assert planes.shape == (2 * N * K + 2 * N,) and planes.dtype == torch.int16 and planes.is_contiguous() and planes.device == a.device
+    assert planes.shape == (f16x2_plane_halves(N, K),) and planes.dtype == torch.int16 and planes.is_contiguous() and planes.device == a.device
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
