@@ -724,8 +724,12 @@ __global__ __launch_bounds__(NTHR, ZIRA_TILE_SLOTS_PER_CU) void msda_bwd_tile_ac
         for (unsigned cc = 0; cc < 4; ++cc) {
             char *ap = reinterpret_cast<char *>(acc) + oc[cc];
 #pragma unroll
-            for (unsigned kk = 0; kk < 4; ++kk)   // (tt[kk] belongs to channel 4 j + (kk ^ swap) in the odd groups)
+            for (unsigned kk = 0; kk < 4; ++kk) {   // (tt[kk] belongs to channel 4 j + (kk ^ swap) in the odd groups)
+#ifdef ZIRA_DEV_HALF_ADDS   // developer ablation (results wrong): the LDS adds of a packed two-channel form, at best
+                if (kk & 1u) continue;
+#endif
                 atomicAdd(reinterpret_cast<double *>(ap + lbk[kk]), wc[cc] * tt[kk]);
+            }
         }
     };
 
