@@ -1277,6 +1277,9 @@ __global__ __launch_bounds__(NTHR, ZIRA_ACC_MINW) void msda_bwd_accum(
 #endif
 #pragma unroll
                 for (unsigned k = 0; k < 4; ++k) {
+#ifdef ZIRA_DEV_HALF_ADDS   // developer ablation (results wrong): the LDS adds of a packed two-channel form, at best
+                    if (k & 1u) continue;
+#endif
                     const double dd = fma(wc[c], tt[k], kMagic);   // (the product of two floats is exact in double)
                     atomicAdd(ap + (k ^ oddg) * LPS, (unsigned long long)__double_as_longlong(dd));
                 }
