@@ -494,6 +494,17 @@ int zira_thin_f16x2_split_f32(const float *w, int batch, int N, int K, int w_is_
 int zira_thin_f16x2_f32(const float *a, const void *frags, const float *a2, const void *frags2, int batch, int M, int N, int K,
                         const float *bias, const float *res, float *c, void *stream);
 
+/* ---- GroupNorm of the input projections (reference groundingdino_dual_zero_rep_branch.py:487-529: nn.GroupNorm(32, 256) behind each
+ * level's conv + side branch), NCHW fp32, forward and input gradient (csrc/groupnorm.hip).  x, res, y, sum_out, dy, dx: [B, C, HW];
+ * gamma / beta [C] or NULL; mean / rstd [B * G].  res (or NULL) is added to x on the way in and the sum written to sum_out (the
+ * backward's x).  The backward is for FROZEN gamma / beta: it returns dx only.  (C / G) * HW % 4 == 0, HW >= 4.
+ * workspace: zira_groupnorm_workspace_floats(B, C, HW, G) floats (0: unsupported shape).  Return 0, a hipError_t, or -1. */
+size_t zira_groupnorm_workspace_floats(int B, int C, int HW, int G);
+int zira_groupnorm_fwd_f32(const float *x, const float *res, const float *gamma, const float *beta, int B, int C, int HW, int G, float eps,
+                           float *sum_out, float *y, float *mean, float *rstd, float *workspace, void *stream);
+int zira_groupnorm_bwd_f32(const float *dy, const float *x, const float *gamma, const float *mean, const float *rstd, int B, int C, int HW,
+                           int G, float *dx, float *workspace, void *stream);
+
 /* ---- Decoder reference boxes: sine embedding, forward only -------------------------------------
  * zira_sine_embed_f32 replaces gen_sineembed_for_position (groundingdino/models/GroundingDINO/utils.py:204-231):
  *   pos [rows, C] (x, y[, w, h]), C = 2 or 4;  dim_t [T] = temperature^(2 (i // 2) / T);  scale = 2 pi;

@@ -53,6 +53,9 @@ for kv in sys.argv[1:]:
     elif k == "tall":
         from ziragroundingdino_amd import dense as _dense
         _dense.USE_TALL_BF16X3 = bool(int(v))
+    elif k == "group_norm":
+        from ziragroundingdino_amd import dense as _dense
+        _dense.USE_GROUP_NORM = bool(int(v))
     elif k == "thin":
         from ziragroundingdino_amd import dense as _dense
         _dense.USE_THIN = bool(int(v))

@@ -27,6 +27,7 @@ SYMBOLS = (
     "zira_ffn_f16x2_pack_bytes", "zira_ffn_f16x2_workspace_bytes", "zira_ffn_f16x2_pack_f32", "zira_ffn_f16x2_f32",
     "zira_thin_f16x2_frag_bytes", "zira_thin_f16x2_split_f32", "zira_thin_f16x2_f32",
     "zira_xty_bf16x3_workspace_floats", "zira_xty_bf16x3_f32",
+    "zira_groupnorm_workspace_floats", "zira_groupnorm_fwd_f32", "zira_groupnorm_bwd_f32",
     "zira_stacked_losses_scratch_bytes", "zira_stacked_losses_fwd_f32", "zira_stacked_losses_bwd_f32",
     "zira_text_side_scratch_floats", "zira_text_prep_fwd_f32", "zira_text_prep_bwd_f32", "zira_text_out_fwd_f32", "zira_text_out_bwd_f32",
     "zira_sine_pos_hw_f32", "zira_box_head_fwd_f32", "zira_box_head_bwd_f32",
@@ -206,6 +207,12 @@ def load():
     lib.zira_ffn_f16x2_workspace_bytes.restype = ctypes.c_size_t
     lib.zira_ffn_f16x2_f32.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp]
     lib.zira_ffn_f16x2_f32.restype = i
+    lib.zira_groupnorm_workspace_floats.argtypes = [i, i, i, i]
+    lib.zira_groupnorm_workspace_floats.restype = ctypes.c_size_t
+    lib.zira_groupnorm_fwd_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, f32, vp, vp, vp, vp, vp, vp]
+    lib.zira_groupnorm_fwd_f32.restype = i
+    lib.zira_groupnorm_bwd_f32.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp]
+    lib.zira_groupnorm_bwd_f32.restype = i
     lib.zira_xty_bf16x3_workspace_floats.argtypes = [i, i, i]
     lib.zira_xty_bf16x3_workspace_floats.restype = ctypes.c_size_t
     lib.zira_xty_bf16x3_f32.argtypes = [vp, vp, i, i, i, i, vp, vp, vp]

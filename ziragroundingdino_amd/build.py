@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libzira_msda.so")
 OBJ_DIR = os.path.join(_HERE, "csrc", "_obj")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("msda.hip", "msda_cells.hip", "msda_tiles.hip", "msda_cpu.cpp", "rsb.hip", "xty.hip", "xty_bf16x3.hip", "bisoftmax.hip", "layernorm.hip", "lsap.hip", "catlogits.hip", "winattn.hip", "refpoints.hip", "attn.hip", "sampling.hip", "gemm_drelu.hip", "rowgemm.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_f16x2_panel.hip", "ffn_f16x2.hip", "thin_f16x2.hip", "criterion.hip", "textside.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("msda.hip", "msda_cells.hip", "msda_tiles.hip", "msda_cpu.cpp", "rsb.hip", "xty.hip", "xty_bf16x3.hip", "bisoftmax.hip", "layernorm.hip", "groupnorm.hip", "lsap.hip", "catlogits.hip", "winattn.hip", "refpoints.hip", "attn.hip", "sampling.hip", "gemm_drelu.hip", "rowgemm.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_f16x2_panel.hip", "ffn_f16x2.hip", "thin_f16x2.hip", "criterion.hip", "textside.hip")]
 HEADERS = [os.path.join(_ROOT, "include", "zira_msda.h"), os.path.join(_HERE, "csrc", "msda_internal.h"),
            os.path.join(_HERE, "csrc", "msda_fwd_lean.h")]
 HIPCC_FLAGS = [

@@ -558,6 +558,74 @@ def fusion_image_side(vn, a, c, z, bias, scale, mask_l, mask_v, H, T, stable=Tru
     return _FusionImageSide.apply(vn, a, c, z, bias, scale, mask_l, mask_v, H, T, stable, clamp_lo, clamp_hi)
 
 
+# ---- GroupNorm of the input projections (csrc/groupnorm.hip) ---------------------------------------
+_GN_WS = {}
+USE_GROUP_NORM = True    # developer switch (scripts/ab_step.py group_norm=0): ATen's native_group_norm
+
+
+def group_norm_supported(x, gn, res=None) -> bool:
+    """NCHW fp32 on the GPU through a FROZEN nn.GroupNorm (the kernels return the input gradient only)."""
+    if not (USE_GROUP_NORM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled("cuda")):
+        return False
+    if gn.weight is None or gn.bias is None or gn.weight.requires_grad or gn.bias.requires_grad or gn.weight.dtype != torch.float32:
+        return False
+    if res is not None and (res.shape != x.shape or res.dtype != torch.float32):
+        return False
+    B, C, H, W = x.shape
+    from . import _lib
+    return C == gn.num_channels and _lib.load().zira_groupnorm_workspace_floats(B, C, H * W, gn.num_groups) > 0
+
+
+class _GroupNormFrozen(torch.autograd.Function):
+    """y = GroupNorm(x (+ res)) with frozen affine parameters; the gradient goes to x (and res) unchanged in form."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, groups, eps):
+        from . import _lib
+
+        lib = _lib.load()
+        x = x.contiguous()
+        res = res.contiguous() if res is not None else None
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        xs = torch.empty_like(x) if res is not None else x
+        mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = _scratch(_GN_WS, x.device, lib.zira_groupnorm_workspace_floats(B, C, H * W, groups))
+        with torch.cuda.device(x.device):
+            rc = lib.zira_groupnorm_fwd_f32(x.data_ptr(), res.data_ptr() if res is not None else None, weight.data_ptr(), bias.data_ptr(),
+                                            B, C, H * W, groups, float(eps), xs.data_ptr() if res is not None else None, y.data_ptr(),
+                                            mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_groupnorm_fwd_f32 failed with code %d" % rc)
+        ctx.save_for_backward(xs, weight, mean, rstd)
+        ctx.groups, ctx.two = groups, res is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        from . import _lib
+
+        lib = _lib.load()
+        xs, weight, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, H, W = xs.shape
+        dx = torch.empty_like(xs)
+        ws = _scratch(_GN_WS, xs.device, lib.zira_groupnorm_workspace_floats(B, C, H * W, ctx.groups))
+        with torch.cuda.device(xs.device):
+            rc = lib.zira_groupnorm_bwd_f32(gy.data_ptr(), xs.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, C, H * W,
+                                            ctx.groups, dx.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("zira_groupnorm_bwd_f32 failed with code %d" % rc)
+        return dx, (dx if ctx.two else None), None, None, None, None
+
+
+def group_norm_frozen(x, gn, res=None):
+    """``gn(x + res)`` (``gn(x)`` without res) for a frozen nn.GroupNorm; call when ``group_norm_supported``."""
+    return _GroupNormFrozen.apply(x, res, gn.weight, gn.bias, gn.num_groups, gn.eps)
+
+
 # ---- row LayerNorm (csrc/layernorm.hip) ------------------------------------------------------
 LN_MIN_ROWS = 8192   # below this the launch is latency-bound either way and ATen's call path is leaner
 

@@ -260,13 +260,17 @@ class GroundingDINO(nn.Module):
 
     def _project_level(self, l, feat):
         """GroupNorm(input_proj conv + side branch); returns (src, zero-interference loss | None)."""
+        from .dense import group_norm_frozen, group_norm_supported
         main = conv_module_as_gemm(self.input_proj[l][0], feat)  # GEMM library instead of MIOpen
+        gn = self.input_proj[l][1]
         if not self.use_project_adapter:
-            return self.input_proj[l][1](main), None
+            return (group_norm_frozen(main, gn) if group_norm_supported(main, gn) else gn(main)), None
         branch, zero_loss = self.input_proj_conv_adapter[l](feat)
         if self.side_branch == "multilayer":   # the branch carries its own GroupNorm (reference :575-576)
-            return self.input_proj[l][1](main) + branch, zero_loss
-        return self.input_proj[l][1](main + branch), zero_loss
+            return (group_norm_frozen(main, gn) if group_norm_supported(main, gn) else gn(main)) + branch, zero_loss
+        if group_norm_supported(main, gn, branch):   # the sum is formed inside the kernel (csrc/groupnorm.hip)
+            return group_norm_frozen(main, gn, branch), zero_loss
+        return gn(main + branch), zero_loss
 
     def encode_text(self, captions, device, defer=False, hidden_only=False):
         # Tokenisation, the sub-sentence masks and their upload are a pure function of the caption
